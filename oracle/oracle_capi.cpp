@@ -1,0 +1,192 @@
+/*
+ * TEST INFRASTRUCTURE — C entry points of the CPU oracle for ctypes (tests/, smoke(), bench.py cpu_baseline).
+ * Not part of the product; nothing under cpp_audio_amd/ or include/ links this.
+ */
+#include "oracle_resynth.hpp"
+#include <cstring>
+#include <memory>
+#include <thread>
+
+using namespace ora;
+
+extern "C" {
+
+void ora_default_config(ora_config *c) { *c = default_config(); }
+
+int ora_even_window_size_frames(float seconds, int sr) { return even_window_size_frames(seconds, sr); }
+int ora_window_center_stride_frames(float seconds, int sr) { return window_center_stride_frames(seconds, sr); }
+int ora_good_stride(float seconds, int sr) { return good_stride(seconds, sr); }
+int ora_modulator_window_size(float seconds, int sr) { return modulator_window_size(static_cast<double>(seconds), sr); }
+int ora_fft_length_for(int n) { return get_fft_length_for(n, 1); }
+
+// ---- known-answer helpers (rt.resynth.lib.test.cpp) ---------------------------------------------
+void ora_note_add_halftones(int note, int octave, long n, int *out_note, int *out_octave) {
+  NoteOctave r = NoteOctave{note, octave}.add_halftones(n);
+  *out_note = r.note;
+  *out_octave = r.octave;
+}
+int ora_note_dist_halftones(int note, int octave, int note2, int octave2) { return NoteOctave{note, octave}.dist_halftones(NoteOctave{note2, octave2}); }
+double ora_midi_get_pitch(int note, int octave) { return Midi().get_pitch(NoteOctave{note, octave}); }
+double ora_scale_closest_pitch(int mode, double root_pitch, double pitch) { return getMusicalScale(mode).closest_pitch(root_pitch, pitch); }
+double ora_frequency_to_midi_pitch(double f) { auto p = Midi().frequency_to_midi_pitch(f); return p ? *p : NAN; }
+double ora_midi_pitch_to_freq(double p) { return Midi().midi_pitch_to_freq(p); }
+float ora_equal_loudness_volume_db(double pitch, int level) { return loudness::equal_loudness_volume_db(pitch, level); }
+void ora_stereo(double pan, double *l, double *r) { auto g = stereo(pan); *l = g.gains[0]; *r = g.gains[1]; }
+float ora_hash_uniform_pm1(uint64_t seed, uint64_t noteid, uint64_t salt) { return hash_uniform_pm1(seed, noteid, salt); }
+
+double ora_autotune(const ora_config *c, double pitch) {
+  Autotune a;
+  a.build(c->use_autotune, c->autotune_type, c->autotune_scale_mode, c->autotune_root_note, c->autotune_root_transpose,
+          c->autotune_chord_frequencies, c->autotune_bit_chord, c->autotune_factor);
+  auto r = a(pitch);
+  return r ? *r : NAN;
+}
+int ora_autotune_allowed(const ora_config *c, double *out, int cap) {
+  Autotune a;
+  a.build(c->use_autotune, c->autotune_type, c->autotune_scale_mode, c->autotune_root_note, c->autotune_root_transpose,
+          c->autotune_chord_frequencies, c->autotune_bit_chord, c->autotune_factor);
+  int n = static_cast<int>(a.allowed.size());
+  for (int i = 0; i < n && i < cap; ++i) out[i] = a.allowed[i];
+  return n;
+}
+
+// ---- DSP primitives -------------------------------------------------------------------------------
+void ora_half_window(int kind, int n, double *out) {
+  std::vector<double> hw;
+  make_half_window(kind, n, hw);
+  std::memcpy(out, hw.data(), sizeof(double) * n);
+}
+// out: (L/2+1) interleaved complex
+void ora_real_fft(const double *x, int L, double *out) {
+  RealFft f(L);
+  std::vector<std::complex<double>> X(L / 2 + 1);
+  f.forward(x, X.data());
+  for (int k = 0; k <= L / 2; ++k) { out[2 * k] = X[k].real(); out[2 * k + 1] = X[k].imag(); }
+}
+void ora_real_ifft(const double *bins, int L, double *x) {
+  RealFft f(L);
+  std::vector<std::complex<double>> X(L / 2 + 1);
+  for (int k = 0; k <= L / 2; ++k) X[k] = {bins[2 * k], bins[2 * k + 1]};
+  f.inverse(X.data(), x);
+  for (int i = 0; i < L; ++i) x[i] /= L;
+}
+// returns fft length; out has L/2 values
+int ora_sqmag(const double *x, int n, int window_kind, double *out) {
+  SqMagOp op;
+  op.window_kind = window_kind;
+  op.init_data(n);
+  op(x, n);
+  std::memcpy(out, op.result.frequencies_sqmag.data(), sizeof(double) * op.result.frequencies_sqmag.size());
+  return op.result.fft_length;
+}
+int ora_peaks(double sr, const double *sqmag, int n_bins, int fft_length, double *freq, double *db, int cap) {
+  FrequenciesSqMag s;
+  s.frequencies_sqmag.assign(sqmag, sqmag + n_bins);
+  s.fft_length = fft_length;
+  std::vector<FreqMag> out;
+  extract_local_max_freqs_mags(sr, s, out);
+  int n = static_cast<int>(out.size());
+  for (int i = 0; i < n && i < cap; ++i) { freq[i] = out[i].freq; db[i] = out[i].mag_db; }
+  return n;
+}
+
+// The stateless half of RtResynth::step on one peak list: returns count of autotuned pitches.
+int ora_step_stateless(const ora_config *c, const double *freq, const double *db, int n_peaks, double *pitch, double *vol, float *key, int cap) {
+  ora_config cfg = *c;
+  RtResynthOffline r(cfg);
+  std::vector<FreqMag> fs(n_peaks);
+  for (int i = 0; i < n_peaks; ++i) fs[i] = {freq[i], db[i]};
+  frequencies_to_pitches(r.midi, fs, r.freqmags_data);
+  aggregate_pitches(cfg.nearby_distance_tones, r.freqmags_data, r.pitch_intervals);
+  reduce_pitches(cfg.min_volume, r.pitch_intervals, r.reduced_pitches);
+  shift_pitches(cfg.pitch_shift_pre_autotune, r.reduced_pitches);
+  harmonize_pitches(cfg.pitch_harmonize_pre_autotune, r.pitches_tmp, r.reduced_pitches);
+  autotune_pitches(static_cast<double>(cfg.autotune_max_pitch), cfg.autotune_tolerance_pitches, r.autotune, r.reduced_pitches, r.autotuned_pitches);
+  shift_pitches(cfg.pitch_shift_post_autotune, r.autotuned_pitches);
+  harmonize_pitches(cfg.pitch_harmonize_post_autotune, r.pitches_tmp, r.autotuned_pitches);
+  order_pitches_by_perceived_loudness(r.autotuned_pitches, r.loudness_keys, r.order);
+  int n = static_cast<int>(r.autotuned_pitches.size());
+  for (int i = 0; i < n && i < cap; ++i) { pitch[i] = r.autotuned_pitches[i].midipitch; vol[i] = r.autotuned_pitches[i].volume; key[i] = r.loudness_keys[i]; }
+  return n;
+}
+
+// ---- the offline job ------------------------------------------------------------------------------
+typedef struct ora_event {
+  int64_t sample;
+  int32_t type;    /* 0 on, 1 off, 2 change, 3 dropped note-on */
+  int32_t channel;
+  int64_t noteid;
+  float frequency, velocity;
+} ora_event;
+
+// voice / carrier may be NULL.  out: [n_frames][2] float.  Returns number of events (may exceed log_cap; only log_cap are stored).
+int64_t ora_run_offline(const ora_config *c, const float *voice, const float *carrier, int64_t n_frames, float *out, ora_event *log,
+                        int64_t log_cap, int32_t *dropped_note_on) {
+  RtResynthOffline r(*c);
+  r.run(voice, carrier, n_frames, out);
+  if (dropped_note_on) *dropped_note_on = r.dropped_note_on;
+  int64_t n = static_cast<int64_t>(r.event_log.size());
+  for (int64_t i = 0; i < n && i < log_cap; ++i) {
+    auto const &e = r.event_log[i];
+    log[i] = {e.sample, e.type, e.channel, e.noteid, e.frequency, e.velocity};
+  }
+  return n;
+}
+
+// Per-frame autotuned pitch lists of one stream (the output of the stateless half of step()).
+// fire_sample[f] = iteration index at which frame f fired; offsets[f]..offsets[f+1] index pitch/vol.
+int64_t ora_run_frames(const ora_config *c, const float *voice, int64_t n_frames, int64_t *fire_sample, int64_t *offsets, int64_t frame_cap,
+                       double *pitch, double *vol, int64_t item_cap) {
+  RtResynthOffline r(*c);
+  std::vector<RtResynthOffline::FrameDump> dump;
+  r.frame_dump = &dump;
+  std::vector<float> out(static_cast<size_t>(n_frames) * 2);
+  r.run(voice, nullptr, n_frames, out.data());
+  int64_t nf = static_cast<int64_t>(dump.size());
+  int64_t pos = 0;
+  for (int64_t f = 0; f < nf && f < frame_cap; ++f) {
+    fire_sample[f] = dump[f].fire_sample;
+    offsets[f] = pos;
+    for (auto const &pv : dump[f].pitches) {
+      if (pos < item_cap) { pitch[pos] = pv.midipitch; vol[pos] = pv.volume; }
+      ++pos;
+    }
+    offsets[f + 1] = pos;
+  }
+  return nf;
+}
+
+// Many independent streams over n_threads host threads, streams statically partitioned
+// (BASELINE.md §3 CPU-baseline plan).  seed of stream s = c->seed + s.
+void ora_run_offline_batch(const ora_config *c, const float *voice, const float *carrier, int32_t n_streams, int64_t n_frames, float *out,
+                           int32_t n_threads) {
+  if (n_threads < 1) n_threads = 1;
+  auto work = [&](int t) {
+    for (int s = t; s < n_streams; s += n_threads) {
+      ora_config cfg = *c;
+      cfg.seed = c->seed + static_cast<uint64_t>(s);
+      RtResynthOffline r(cfg);
+      r.run(voice ? voice + static_cast<size_t>(s) * n_frames : nullptr, carrier ? carrier + static_cast<size_t>(s) * n_frames : nullptr, n_frames,
+            out + static_cast<size_t>(s) * n_frames * 2);
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto &t : th) t.join();
+}
+
+// ---- driver (A) -----------------------------------------------------------------------------------
+// returns the number of frames the reference loop would write; fills out up to cap.
+int64_t ora_resynth_notes(const int32_t *start, const int32_t *end, const double *freq, const double *amp_db, int32_t n_notes, int32_t stride,
+                          int32_t sr, double *out, int64_t cap) {
+  std::vector<DeducedNote> notes(n_notes);
+  for (int i = 0; i < n_notes; ++i) notes[i] = {start[i], end[i], freq[i], amp_db[i]};
+  std::vector<double> o;
+  resynth_notes(notes, stride, sr, o);
+  int64_t n = static_cast<int64_t>(o.size());
+  for (int64_t i = 0; i < n && i < cap; ++i) out[i] = o[i];
+  return n;
+}
+
+} // extern "C"

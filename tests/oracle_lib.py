@@ -1,0 +1,202 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+
+
+class OraConfig(C.Structure):
+    """Mirror of oracle/oracle_config.h:ora_config."""
+    _fields_ = [
+        ("sample_rate", C.c_int32), ("window_size", C.c_int32), ("stride", C.c_int32),
+        ("n_channels", C.c_int32), ("window_kind", C.c_int32),
+        ("min_volume", C.c_float), ("nearby_distance_tones", C.c_float), ("max_track_pitches", C.c_float),
+        ("autotune_tolerance_pitches", C.c_float),
+        ("pitch_shift_pre_autotune", C.c_float), ("pitch_shift_post_autotune", C.c_float),
+        ("pitch_harmonize_pre_autotune", C.c_float), ("pitch_harmonize_post_autotune", C.c_float),
+        ("stereo_spread", C.c_float),
+        ("env_attack_seconds", C.c_float), ("env_hold_seconds", C.c_float), ("env_decay_seconds", C.c_float),
+        ("env_release_seconds", C.c_float), ("env_sustain_level", C.c_float),
+        ("use_autotune", C.c_int32), ("autotune_type", C.c_int32), ("autotune_max_pitch", C.c_int32),
+        ("autotune_factor", C.c_int32), ("autotune_scale_mode", C.c_int32), ("autotune_root_note", C.c_int32),
+        ("autotune_root_transpose", C.c_int32), ("autotune_chord_frequencies", C.c_int32),
+        ("autotune_bit_chord", C.c_uint64),
+        ("vocoder_modulator_window_size_seconds", C.c_float), ("vocoder_stride_seconds", C.c_float),
+        ("vocoder_count_bands", C.c_int32), ("vocoder_min_freq", C.c_float), ("vocoder_max_freq", C.c_float),
+        ("voice_volume", C.c_float), ("carrier_volume", C.c_float), ("vocoder_volume", C.c_float),
+        ("analysis_volume", C.c_float), ("analysis_input_gain", C.c_float),
+        ("phase_policy", C.c_int32), ("seed", C.c_uint64),
+    ]
+
+
+class OraEvent(C.Structure):
+    _fields_ = [("sample", C.c_int64), ("type", C.c_int32), ("channel", C.c_int32), ("noteid", C.c_int64),
+                ("frequency", C.c_float), ("velocity", C.c_float)]
+
+
+EVENT_DTYPE = np.dtype([("sample", "<i8"), ("type", "<i4"), ("channel", "<i4"), ("noteid", "<i8"),
+                        ("frequency", "<f4"), ("velocity", "<f4")])
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        L.ora_midi_get_pitch.restype = C.c_double
+        L.ora_scale_closest_pitch.restype = C.c_double
+        L.ora_scale_closest_pitch.argtypes = [C.c_int, C.c_double, C.c_double]
+        L.ora_frequency_to_midi_pitch.restype = C.c_double
+        L.ora_frequency_to_midi_pitch.argtypes = [C.c_double]
+        L.ora_midi_pitch_to_freq.restype = C.c_double
+        L.ora_midi_pitch_to_freq.argtypes = [C.c_double]
+        L.ora_equal_loudness_volume_db.restype = C.c_float
+        L.ora_equal_loudness_volume_db.argtypes = [C.c_double, C.c_int]
+        L.ora_stereo.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.ora_hash_uniform_pm1.restype = C.c_float
+        L.ora_hash_uniform_pm1.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+        L.ora_autotune.restype = C.c_double
+        L.ora_autotune.argtypes = [C.POINTER(OraConfig), C.c_double]
+        L.ora_run_offline.restype = C.c_int64
+        L.ora_run_frames.restype = C.c_int64
+        L.ora_resynth_notes.restype = C.c_int64
+        L.ora_peaks.argtypes = [C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.ora_note_add_halftones.argtypes = [C.c_int, C.c_int, C.c_long, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.ora_even_window_size_frames.argtypes = [C.c_float, C.c_int]
+        L.ora_window_center_stride_frames.argtypes = [C.c_float, C.c_int]
+        L.ora_good_stride.argtypes = [C.c_float, C.c_int]
+        L.ora_modulator_window_size.argtypes = [C.c_float, C.c_int]
+        _lib = L
+    return _lib
+
+
+def default_config(**kw):
+    c = OraConfig()
+    lib().ora_default_config(C.byref(c))
+    for k, v in kw.items():
+        if not hasattr(c, k):
+            raise AttributeError(k)
+        setattr(c, k, v)
+    return c
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def half_window(kind, n):
+    out = np.empty(n, np.float64)
+    lib().ora_half_window(C.c_int(kind), C.c_int(n), _p(out))
+    return out
+
+
+def real_fft(x):
+    x = np.ascontiguousarray(x, np.float64)
+    L = len(x)
+    out = np.empty(2 * (L // 2 + 1), np.float64)
+    lib().ora_real_fft(_p(x), C.c_int(L), _p(out))
+    return out[0::2] + 1j * out[1::2]
+
+
+def real_ifft(X, L):
+    b = np.empty(2 * (L // 2 + 1), np.float64)
+    b[0::2] = X.real
+    b[1::2] = X.imag
+    x = np.empty(L, np.float64)
+    lib().ora_real_ifft(_p(b), C.c_int(L), _p(x))
+    return x
+
+
+def sqmag(x, window_kind=0):
+    x = np.ascontiguousarray(x, np.float64)
+    n = len(x)
+    L = lib().ora_fft_length_for(C.c_int(n))
+    out = np.empty(L // 2, np.float64)
+    L2 = lib().ora_sqmag(_p(x), C.c_int(n), C.c_int(window_kind), _p(out))
+    assert L2 == L
+    return out, L
+
+
+def peaks(sr, sq, L):
+    sq = np.ascontiguousarray(sq, np.float64)
+    cap = len(sq)
+    f = np.empty(cap, np.float64)
+    d = np.empty(cap, np.float64)
+    n = lib().ora_peaks(C.c_double(sr), _p(sq), C.c_int(len(sq)), C.c_int(L), _p(f), _p(d), C.c_int(cap))
+    return f[:n], d[:n]
+
+
+def step_stateless(cfg, freq, db):
+    freq = np.ascontiguousarray(freq, np.float64)
+    db = np.ascontiguousarray(db, np.float64)
+    cap = 2 * len(freq) + 8
+    p = np.empty(cap, np.float64)
+    v = np.empty(cap, np.float64)
+    k = np.empty(cap, np.float32)
+    n = lib().ora_step_stateless(C.byref(cfg), _p(freq), _p(db), C.c_int(len(freq)), _p(p), _p(v), _p(k), C.c_int(cap))
+    return p[:n], v[:n], k[:n]
+
+
+def run_offline(cfg, voice, carrier=None, log_cap=1 << 20):
+    """Returns (out[n,2] float32, events structured array, dropped_note_on)."""
+    n = len(voice) if voice is not None else len(carrier)
+    v = np.ascontiguousarray(voice, np.float32) if voice is not None else None
+    c = np.ascontiguousarray(carrier, np.float32) if carrier is not None else None
+    out = np.zeros((n, 2), np.float32)
+    log = np.zeros(log_cap, EVENT_DTYPE)
+    dropped = C.c_int32(0)
+    ne = lib().ora_run_offline(C.byref(cfg), _p(v) if v is not None else None, _p(c) if c is not None else None,
+                               C.c_int64(n), _p(out), _p(log), C.c_int64(log_cap), C.byref(dropped))
+    assert ne <= log_cap, "event log overflow"
+    return out, log[:ne], dropped.value
+
+
+def run_frames(cfg, voice, frame_cap=1 << 16, item_cap=1 << 22):
+    v = np.ascontiguousarray(voice, np.float32)
+    fire = np.zeros(frame_cap, np.int64)
+    offs = np.zeros(frame_cap + 1, np.int64)
+    pitch = np.zeros(item_cap, np.float64)
+    vol = np.zeros(item_cap, np.float64)
+    nf = lib().ora_run_frames(C.byref(cfg), _p(v), C.c_int64(len(v)), _p(fire), _p(offs), C.c_int64(frame_cap),
+                              _p(pitch), _p(vol), C.c_int64(item_cap))
+    assert nf <= frame_cap and offs[nf] <= item_cap
+    return fire[:nf], offs[:nf + 1], pitch[:offs[nf]], vol[:offs[nf]]
+
+
+def run_offline_batch(cfg, voice, carrier=None, n_threads=1):
+    """voice: [streams, n] float32. Returns out [streams, n, 2]."""
+    a = voice if voice is not None else carrier
+    S, n = a.shape
+    v = np.ascontiguousarray(voice, np.float32) if voice is not None else None
+    c = np.ascontiguousarray(carrier, np.float32) if carrier is not None else None
+    out = np.zeros((S, n, 2), np.float32)
+    lib().ora_run_offline_batch(C.byref(cfg), _p(v) if v is not None else None, _p(c) if c is not None else None,
+                                C.c_int32(S), C.c_int64(n), _p(out), C.c_int32(n_threads))
+    return out
+
+
+def resynth_notes(start, end, freq, amp_db, stride, sr, cap=1 << 24):
+    start = np.ascontiguousarray(start, np.int32)
+    end = np.ascontiguousarray(end, np.int32)
+    freq = np.ascontiguousarray(freq, np.float64)
+    amp_db = np.ascontiguousarray(amp_db, np.float64)
+    out = np.zeros(cap, np.float64)
+    n = lib().ora_resynth_notes(_p(start), _p(end), _p(freq), _p(amp_db), C.c_int32(len(start)), C.c_int32(stride),
+                                C.c_int32(sr), _p(out), C.c_int64(cap))
+    assert n <= cap
+    return out[:n]
