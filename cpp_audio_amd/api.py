@@ -1,0 +1,225 @@
+"""ctypes binding of libresynth_amd.so (the C ABI of include/resynth_amd.h).
+
+The HIP library is the only compute path: if it is missing this module raises at import of `lib()`,
+and if no GPU is visible `Context(...)` raises — there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libresynth_amd.so")
+
+RA_OK = 0
+
+
+class RaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"resynth_amd error {code}: {msg}")
+        self.code = code
+
+
+class RaConfig(C.Structure):
+    """Mirror of include/resynth_amd.h:ra_config (= the atomics of rt.resynth.lib.cpp:943-999)."""
+    _fields_ = [
+        ("sample_rate", C.c_int32), ("window_size", C.c_int32), ("stride", C.c_int32),
+        ("n_channels", C.c_int32), ("window_kind", C.c_int32),
+        ("min_volume", C.c_float), ("nearby_distance_tones", C.c_float), ("max_track_pitches", C.c_float),
+        ("autotune_tolerance_pitches", C.c_float),
+        ("pitch_shift_pre_autotune", C.c_float), ("pitch_shift_post_autotune", C.c_float),
+        ("pitch_harmonize_pre_autotune", C.c_float), ("pitch_harmonize_post_autotune", C.c_float),
+        ("stereo_spread", C.c_float),
+        ("env_attack_seconds", C.c_float), ("env_hold_seconds", C.c_float), ("env_decay_seconds", C.c_float),
+        ("env_release_seconds", C.c_float), ("env_sustain_level", C.c_float),
+        ("use_autotune", C.c_int32), ("autotune_type", C.c_int32), ("autotune_max_pitch", C.c_int32),
+        ("autotune_factor", C.c_int32), ("autotune_scale_mode", C.c_int32), ("autotune_root_note", C.c_int32),
+        ("autotune_root_transpose", C.c_int32), ("autotune_chord_frequencies", C.c_int32),
+        ("autotune_bit_chord", C.c_uint64),
+        ("vocoder_modulator_window_size_seconds", C.c_float), ("vocoder_stride_seconds", C.c_float),
+        ("vocoder_count_bands", C.c_int32), ("vocoder_min_freq", C.c_float), ("vocoder_max_freq", C.c_float),
+        ("voice_volume", C.c_float), ("carrier_volume", C.c_float), ("vocoder_volume", C.c_float),
+        ("analysis_volume", C.c_float), ("analysis_input_gain", C.c_float),
+        ("phase_policy", C.c_int32), ("seed", C.c_uint64),
+        ("max_pitches_per_frame", C.c_int32),
+    ]
+
+
+class RaStats(C.Structure):
+    _fields_ = [("frames_analysed", C.c_int64), ("samples_rendered", C.c_int64), ("dropped_note_on", C.c_int64),
+                ("error_flags", C.c_int32), ("reserved", C.c_int32)]
+
+
+class RaNote(C.Structure):
+    _fields_ = [("start_frame", C.c_int32), ("end_frame", C.c_int32), ("frequency", C.c_double), ("amplitude_db", C.c_double)]
+
+
+EVENT_DTYPE = np.dtype([("sample", "<i8"), ("type", "<i4"), ("channel", "<i4"), ("noteid", "<i8"),
+                        ("frequency", "<f4"), ("velocity", "<f4")])
+
+# every symbol include/resynth_amd.h declares
+EXPORTED_SYMBOLS = [
+    "ra_last_error", "ra_device_count", "ra_default_config", "ra_even_window_size_frames", "ra_window_center_stride_frames",
+    "ra_create", "ra_destroy", "ra_reset", "ra_set_hip_stream", "ra_process_device", "ra_process_host", "ra_synchronize",
+    "ra_feed", "ra_compute", "ra_get_stats", "ra_get_events", "ra_get_frame_pitches", "ra_resynth_notes", "ra_sqmag",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.ra_last_error.restype = C.c_char_p
+        L.ra_create.argtypes = [C.POINTER(RaConfig), C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        L.ra_destroy.argtypes = [C.c_void_p]
+        L.ra_destroy.restype = None
+        L.ra_reset.argtypes = [C.c_void_p]
+        L.ra_set_hip_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.ra_process_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.ra_process_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.ra_synchronize.argtypes = [C.c_void_p]
+        L.ra_feed.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+        L.ra_compute.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        L.ra_get_stats.argtypes = [C.c_void_p, C.POINTER(RaStats)]
+        L.ra_get_events.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+        L.ra_get_events.restype = C.c_int64
+        L.ra_get_frame_pitches.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]
+        L.ra_get_frame_pitches.restype = C.c_int64
+        L.ra_resynth_notes.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]
+        L.ra_resynth_notes.restype = C.c_int64
+        L.ra_sqmag.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]
+        L.ra_even_window_size_frames.argtypes = [C.c_float, C.c_int]
+        L.ra_window_center_stride_frames.argtypes = [C.c_float, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _check(code):
+    if code < 0:
+        raise RaError(code, lib().ra_last_error().decode())
+    return code
+
+
+def default_config(**kw):
+    c = RaConfig()
+    _check(lib().ra_default_config(C.byref(c)))
+    for k, v in kw.items():
+        if not hasattr(c, k):
+            raise AttributeError(k)
+        setattr(c, k, v)
+    return c
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context:
+    """n_streams independent RtResynth instances on one GPU (ra_create .. ra_destroy)."""
+
+    def __init__(self, cfg, n_streams, device=0):
+        self.cfg = cfg
+        self.n_streams = int(n_streams)
+        self._h = C.c_void_p()
+        _check(lib().ra_create(C.byref(cfg), self.n_streams, int(device), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().ra_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def reset(self):
+        _check(lib().ra_reset(self._h))
+
+    def set_hip_stream(self, stream_handle):
+        _check(lib().ra_set_hip_stream(self._h, C.c_void_p(stream_handle)))
+
+    def process_host(self, voice, carrier=None):
+        """voice/carrier: [n_streams, n] float32 (or None). Returns out [n_streams, n, 2] float32."""
+        a = voice if voice is not None else carrier
+        S, n = a.shape
+        assert S == self.n_streams
+        v = np.ascontiguousarray(voice, np.float32) if voice is not None else None
+        c = np.ascontiguousarray(carrier, np.float32) if carrier is not None else None
+        out = np.empty((S, n, 2), np.float32)
+        _check(lib().ra_process_host(self._h, _p(v), _p(c), n, _p(out)))
+        return out
+
+    def process_device(self, d_voice, d_carrier, n_frames, d_out):
+        """Raw device pointers (ints). Asynchronous; call synchronize()."""
+        _check(lib().ra_process_device(self._h, C.c_void_p(d_voice or 0), C.c_void_p(d_carrier or 0), int(n_frames), C.c_void_p(d_out)))
+
+    def synchronize(self):
+        _check(lib().ra_synchronize(self._h))
+
+    def feed(self, voice, carrier=None, stream=0):
+        v = np.ascontiguousarray(voice, np.float32) if voice is not None else None
+        c = np.ascontiguousarray(carrier, np.float32) if carrier is not None else None
+        n = len(v) if v is not None else len(c)
+        _check(lib().ra_feed(self._h, stream, _p(v), _p(c), n))
+
+    def compute(self, buf, n_frames, stream=0):
+        """Accumulates into buf ([n_frames, 2] float64), like the reference's ComputeFunc."""
+        assert buf.dtype == np.float64 and buf.flags.c_contiguous
+        return _check(lib().ra_compute(self._h, stream, _p(buf), n_frames))
+
+    def stats(self):
+        s = RaStats()
+        _check(lib().ra_get_stats(self._h, C.byref(s)))
+        return s
+
+    def events(self, stream, cap=1 << 20):
+        ev = np.zeros(cap, EVENT_DTYPE)
+        n = _check(lib().ra_get_events(self._h, stream, _p(ev), cap))
+        assert n <= cap
+        return ev[:n]
+
+    def frame_pitches(self, stream, frame_cap=1 << 16, item_cap=1 << 22):
+        fire = np.zeros(frame_cap, np.int64)
+        offs = np.zeros(frame_cap + 1, np.int64)
+        pitch = np.zeros(item_cap, np.float64)
+        vol = np.zeros(item_cap, np.float64)
+        nf = _check(lib().ra_get_frame_pitches(self._h, stream, _p(fire), _p(offs), frame_cap, _p(pitch), _p(vol), item_cap))
+        assert nf <= frame_cap and offs[nf] <= item_cap
+        return fire[:nf], offs[:nf + 1], pitch[:offs[nf]], vol[:offs[nf]]
+
+
+def sqmag(windows, window_kind=0, device=0):
+    """windows [n, N] float32 -> (|X|^2 [n, L/2] float64, L)."""
+    w = np.ascontiguousarray(windows, np.float32)
+    n, N = w.shape
+    L = 1
+    while L < N:
+        L <<= 1
+    out = np.empty((n, L // 2), np.float64)
+    fl = C.c_int32(0)
+    _check(lib().ra_sqmag(_p(w), n, N, window_kind, device, _p(out), C.byref(fl)))
+    assert fl.value == L
+    return out, L
+
+
+def resynth_notes(start, end, freq, amp_db, stride, sr, device=0):
+    notes = (RaNote * len(start))()
+    for i in range(len(start)):
+        notes[i] = RaNote(int(start[i]), int(end[i]), float(freq[i]), float(amp_db[i]))
+    n = _check(lib().ra_resynth_notes(notes, len(start), stride, sr, device, None, 0))
+    out = np.zeros(n, np.float64)
+    _check(lib().ra_resynth_notes(notes, len(start), stride, sr, device, _p(out), n))
+    return out

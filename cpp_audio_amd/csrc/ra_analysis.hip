@@ -1,0 +1,346 @@
+// K1 — analysis: one workgroup per (stream, analysis frame).
+//
+// Replaces, for every frame at once, PeriodicFFT::onFullBuffer -> SqMagFftOperation::operator()
+// (reference source/rt.resynth.lib.periodicfft.cpp:136-180, 301-312: window * x, zero pad, real FFT, |X|^2),
+// extractLocalMaxFreqsMags (call site source/rt.resynth.lib.cpp:1592-1595) and the stateless half of
+// RtResynth::step (lib.cpp:1676-1708: frequencies_to_pitches, aggregate, reduce, shift, harmonize,
+// autotune, shift, harmonize) plus the loudness sort key of lib.cpp:1717-1727.
+//
+// The window never leaves the chip: N contiguous floats are read once (coalesced), the real FFT runs
+// as an M = L/2 point complex FFT in LDS (fp64, like the reference), |X|^2 overwrites the same LDS slots,
+// peaks are compacted in bin order and only the short autotuned pitch list goes back to HBM.
+#include "ra_internal.h"
+
+extern __shared__ __align__(16) unsigned char ra_smem[];
+
+namespace {
+
+__device__ inline double sqmag_to_db(double x) { return 10.0 * log10(x > 1e-300 ? x : 1e-300); }
+
+// canonical lower_bound on .x of a double2 list (find_closest_pitch, rt.resynth.lib.autotune.cpp:189-218)
+__device__ inline int find_closest_x(const double2 *v, int n, double pitch) {
+  if (n == 0) return -1;
+  int first = 0, len = n;
+  while (len > 0) {
+    int half = len >> 1, mid = first + half;
+    if (v[mid].x < pitch) { first = mid + 1; len = len - half - 1; } else len = half;
+  }
+  int lb = first;
+  if (lb == n) return lb - 1;
+  if (lb == 0) return 0;
+  float dist_lb = fabsf((float)(pitch - v[lb].x));
+  float dist_prev = fabsf((float)(pitch - v[lb - 1].x));
+  return dist_lb < dist_prev ? lb : lb - 1;
+}
+__device__ inline int find_closest_d(const double *v, int n, double pitch) {
+  if (n == 0) return -1;
+  int first = 0, len = n;
+  while (len > 0) {
+    int half = len >> 1, mid = first + half;
+    if (v[mid] < pitch) { first = mid + 1; len = len - half - 1; } else len = half;
+  }
+  int lb = first;
+  if (lb == n) return lb - 1;
+  if (lb == 0) return 0;
+  float dist_lb = fabsf((float)(pitch - v[lb]));
+  float dist_prev = fabsf((float)(pitch - v[lb - 1]));
+  return dist_lb < dist_prev ? lb : lb - 1;
+}
+
+// shift_pitches, rt.resynth.lib.algo.cpp:307-316
+__device__ inline void shift_list(double2 *l, int n, float shift) {
+  if (!shift) return;
+  for (int i = 0; i < n; ++i) l[i].x += shift;
+}
+
+// harmonize_pitches, rt.resynth.lib.algo.cpp:318-371.  list has room for 2n entries; work likewise.
+__device__ inline int harmonize_list(double2 *&list, double2 *&work, int n, int cap, float amount, int *err) {
+  if (!amount) return n;
+  int sz = n, total = n;
+  for (int i = 0; i < sz; ++i) {
+    double2 p = list[i];
+    double harmonized = p.x + amount;
+    int c = find_closest_x(list, total, harmonized);
+    float dist = fabsf((float)(list[c].x - harmonized));
+    if (dist <= 0.0001f) list[c].y += p.y;
+    else if (total < cap) list[total++] = make_double2(harmonized, p.y);
+    else *err = 1;
+  }
+  int a = 0, b = sz, o = 0;
+  while (a < sz && b < total) {
+    if (list[b].x < list[a].x) work[o++] = list[b++]; else work[o++] = list[a++];
+  }
+  while (a < sz) work[o++] = list[a++];
+  while (b < total) work[o++] = list[b++];
+  double2 *t = list; list = work; work = t;
+  return total;
+}
+
+// mkAutotuneFunction, lib.cpp:1761-1873.  returns false for "no pitch".
+__device__ inline bool autotune_fn(const RaParams &p, const double *allowed, double pitch, double &out) {
+  if (!p.use_autotune) { out = pitch; return true; }
+  if (p.autotune_type == RA_AUTOTUNE_SCALE) { // MusicalScalePitches::closest_pitch, autotune.cpp:95-123
+    double half_tones_dist = pitch - p.scale_root;
+    double octave_dist = half_tones_dist / 12;
+    int octaves_translation = (octave_dist >= 0.) ? (int)octave_dist : (int)octave_dist - 1;
+    double translated = pitch - (octaves_translation * 12);
+    double rel = translated - p.scale_root;
+    int i = 0;
+    for (; i < 7; ++i) if (rel < p.scale_equi[i]) break;
+    out = pitch - (rel - p.scale_pitches[i]);
+    return true;
+  }
+  int i = find_closest_d(allowed, p.n_allowed, pitch);
+  if (i < 0) return false;
+  out = allowed[i];
+  return true;
+}
+
+// equal_loudness_volume_db(loudness::pitches, pitch, idx(60 phon)), include/loudness.h:159-186, 231-244
+__device__ inline float equal_loudness_db(const double *arr, const float *elv, double value) {
+  int min_ = 0, max_ = 28;
+  do {
+    int center = (min_ + max_) / 2;
+    if (value < arr[center]) max_ = center; else min_ = center;
+  } while (max_ - min_ >= 2);
+  int i; float ratio;
+  if (value <= arr[min_]) { i = min_; ratio = 1.f; }
+  else if (value >= arr[max_]) { i = max_; ratio = 1.f; }
+  else { i = max_; ratio = (float)((value - arr[min_]) / (arr[max_] - arr[min_])); }
+  if (ratio == 1.f) return elv[i];
+  return ratio * elv[i] + (1.f - ratio) * elv[i - 1];
+}
+
+__global__ void __launch_bounds__(RA_ANALYSIS_THREADS)
+ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int64_t t0, int64_t n, int64_t f_lo) {
+  const int tid = threadIdx.x;
+  const int fb = blockIdx.x;
+  const int s = blockIdx.y;
+  const int64_t f = f_lo + fb;
+  const int M = p.M, N = p.N, T = RA_ANALYSIS_THREADS;
+
+  double2 *z = reinterpret_cast<double2 *>(ra_smem);           // [max(M,1)]
+  double2 *listA = z + (M > 0 ? M : 1);                        // [2*maxr]
+  double2 *listB = listA + 2 * p.maxr;                         // [2*maxr]
+  int *scan = reinterpret_cast<int *>(listB + 2 * p.maxr);     // [T+1]
+
+  // ---- 1. load the window (coalesced), weight it, scatter to bit-reversed slots -------------------
+  {
+    const int64_t start = 2 + f * (int64_t)p.H; // absolute index of the window's first sample
+    const float *hist = b.hist + (size_t)s * N;
+    const float *vs = voice ? voice + (size_t)s * n : nullptr;
+    const int h = N / 2;
+    auto sample = [&](int i) -> double {
+      if (i >= N) return 0.0;
+      int64_t a = start + i;
+      float v;
+      if (a < t0) v = hist[N - (t0 - a)]; else v = vs ? vs[a - t0] : 0.f;
+      float sum = 0.f;
+      sum += p.input_gain * v; // analyze_until_input_starvation, lib.cpp:1626,1636 (float)
+      double x = (double)sum;  // PeriodicFFT::feed stores the float as FPT = double (periodicfft.cpp:61)
+      int j = (i >= h) ? (i - h) : (h - 1 - i);
+      return x * b.half_window[j];
+    };
+    if (M == 0) { // L == 1 cannot happen (N even >= 2), kept for safety
+    }
+    for (int k = tid; k < M; k += T) z[b.bitrev[k]] = make_double2(sample(2 * k), sample(2 * k + 1));
+  }
+  __syncthreads();
+
+  // ---- 2. in-place radix-2 DIT, M points ----------------------------------------------------------
+  for (int len = 2; len <= M; len <<= 1) {
+    const int half = len >> 1, step = M / len;
+    for (int bf = tid; bf < (M >> 1); bf += T) {
+      int grp = bf / half, j = bf - grp * half;
+      int i0 = grp * len + j;
+      double2 w = b.tw_half[j * step];
+      double2 u = z[i0], x = z[i0 + half];
+      double vr = x.x * w.x - x.y * w.y;
+      double vi = x.x * w.y + x.y * w.x;
+      z[i0] = make_double2(u.x + vr, u.y + vi);
+      z[i0 + half] = make_double2(u.x - vr, u.y - vi);
+    }
+    __syncthreads();
+  }
+
+  // ---- 3. split into the real spectrum, |X|^2 written over .x of the same slots -------------------
+  // X[k] = E[k] + W^k O[k],  E = (Z[k] + conj Z[M-k]) / 2,  O = -i/2 (Z[k] - conj Z[M-k]);  bins 0..M-1 kept
+  for (int k = tid; k <= (M >> 1); k += T) {
+    int km = (M - k) % M; // partner (k = 0 pairs with itself, k = M/2 too)
+    double2 zk = z[k], zm = z[km];
+    auto bin = [&](double2 a, double2 c, int kk) -> double { // a = Z[kk], c = Z[M-kk] (conjugated here)
+      double er = 0.5 * (a.x + c.x), ei = 0.5 * (a.y - c.y);
+      double dr = a.x - c.x, di = a.y + c.y;
+      double o_r = 0.5 * di, o_i = -0.5 * dr;
+      double2 w = b.tw_full[kk];
+      double xr = er + (w.x * o_r - w.y * o_i);
+      double xi = ei + (w.x * o_i + w.y * o_r);
+      return xr * xr + xi * xi;
+    };
+    double sk = bin(zk, zm, k);
+    double sm = (km != k) ? bin(zm, zk, km) : 0.0;
+    // the two slots are private to this thread: safe to overwrite now
+    z[k].x = sk;
+    if (km != k) z[km].x = sm;
+  }
+  __syncthreads();
+  if (b.dbg_sqmag) {
+    double *dst = b.dbg_sqmag + ((size_t)s * gridDim.x + fb) * M;
+    for (int k = tid; k < M; k += T) dst[k] = z[k].x;
+  }
+
+  // ---- 4. local maxima -> (pitch, volume) list in bin order ---------------------------------------
+  // peak entries go to the .y halves: pitch of entry j at z[j].y, volume at z[M/2 + j].y  (count <= M/2)
+  const int chunk = (M + T - 1) / T;
+  const int c0 = tid * chunk, c1 = min(M, c0 + chunk);
+  int cnt = 0;
+  for (int i = max(c0, 1); i < c1 && i + 1 < M; ++i) {
+    double a = z[i - 1].x, m = z[i].x, c = z[i + 1].x;
+    cnt += (a < m && m >= c) ? 1 : 0;
+  }
+  scan[tid] = cnt;
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int i = 0; i < T; ++i) { int v = scan[i]; scan[i] = acc; acc += v; }
+    scan[T] = acc;
+  }
+  __syncthreads();
+  {
+    int pos = scan[tid];
+    const double bin_hz = (double)p.sample_rate / (double)p.L;
+    for (int i = max(c0, 1); i < c1 && i + 1 < M; ++i) {
+      double a = z[i - 1].x, m = z[i].x, c = z[i + 1].x;
+      if (a < m && m >= c) {
+        double da = sqmag_to_db(a), db = sqmag_to_db(m), dc = sqmag_to_db(c);
+        double den = da - 2.0 * db + dc;
+        double pp = den != 0.0 ? 0.5 * (da - dc) / den : 0.0;
+        double freq = (i + pp) * bin_hz;
+        double mag_db = db - 0.25 * (da - dc) * pp;
+        // frequencies_to_pitches, algo.cpp:10-29 with midi.h:223-232 (f > 0 always holds here: i >= 1, pp > -1/2)
+        double pitch = 69.0 + (12 / 1.0) * log2(freq / (double)440.f);
+        double vol = pow(10.0, mag_db / 20.0);
+        z[pos].y = pitch;
+        z[(M >> 1) + pos].y = vol;
+        ++pos;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- 5. the sequential part of the pipeline (tens of items): one lane ---------------------------
+  if (tid == 0) {
+    const int K = scan[T];
+    const int cap = 2 * p.maxr;
+    int err = 0;
+    // aggregate_pitches + reduce_pitches (algo.cpp:124-184, PonderateByVolume / SumVolumes)
+    int R = 0;
+    bool have = false;
+    double mn = 0, mx = 0, sumV = 0, sumPV = 0;
+    auto close_interval = [&]() {
+      if (!(sumV < p.min_volume)) {
+        if (R < cap) listA[R++] = make_double2(sumPV / sumV, sumV); else err = 1;
+      }
+    };
+    for (int i = 0; i < K; ++i) {
+      double pt = z[i].y, v = z[(M >> 1) + i].y;
+      if (have) {
+        double hi = fmax(fmax(mn, mx), pt), lo = fmin(fmin(mn, mx), pt);
+        if (hi - lo > p.nearby) { close_interval(); have = false; }
+      }
+      if (!have) { mn = mx = pt; sumV = 0; sumPV = 0; have = true; }
+      else { mn = fmin(mn, pt); mx = fmax(mx, pt); }
+      sumV += v;
+      sumPV += pt * v;
+    }
+    if (have) close_interval();
+
+    double2 *cur = listA, *oth = listB;
+    shift_list(cur, R, p.shift_pre);
+    R = harmonize_list(cur, oth, R, cap, p.harm_pre, &err);
+    // autotune_pitches, algo.cpp:191-229
+    int A = 0;
+    for (int i = 0; i < R; ++i) {
+      double2 pv = cur[i];
+      double t;
+      bool has;
+      if (pv.x <= p.autotune_max_pitch) {
+        has = autotune_fn(p, b.allowed, pv.x, t);
+        if (has && t > p.autotune_max_pitch) t = pv.x;
+      } else { t = pv.x; has = true; }
+      if (has) {
+        if (fabs(t - pv.x) <= (double)p.tolerance) {
+          if (A > 0 && fabs(oth[A - 1].x - t) < (double)0.0001f) oth[A - 1].y += pv.y;
+          else oth[A++] = make_double2(t, pv.y);
+        }
+      }
+    }
+    { double2 *t = cur; cur = oth; oth = t; }
+    shift_list(cur, A, p.shift_post);
+    A = harmonize_list(cur, oth, A, cap, p.harm_post, &err);
+    if (A > p.maxr) { err = 1; A = p.maxr; }
+    if (err) atomicOr(b.error_flags, RA_ERR_OVERFLOW);
+
+    size_t base = ((size_t)s * b.frames_cap + fb) * p.maxr;
+    for (int i = 0; i < A; ++i) {
+      b.pl_pitch[base + i] = cur[i].x;
+      b.pl_vol[base + i] = cur[i].y;
+      // order_pitches_by_perceived_loudness key, lib.cpp:1717-1727 (a float vector, algo.cpp:380-395)
+      b.pl_key[base + i] = (float)(cur[i].y / (double)equal_loudness_db(b.loud_pitches, b.loud_elv, cur[i].x));
+    }
+    b.pl_count[(size_t)s * b.frames_cap + fb] = A;
+  }
+}
+
+// keeps the last N input samples of every stream for the next block's overlapping windows
+// (the memmove of periodicfft.cpp:167-175, done once per block instead of once per frame)
+__global__ void ra_roll_history_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int64_t n) {
+  const int s = blockIdx.y;
+  const int N = p.N;
+  float *hist = b.hist + (size_t)s * N;
+  const float *vs = voice ? voice + (size_t)s * n : nullptr;
+  // new_hist[i] = concat(hist, block)[n + i]  for i in [0, N)
+  if (n >= N) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) hist[i] = vs ? vs[n - N + i] : 0.f;
+  } else {
+    // shift by n inside one workgroup (grid.x == 1 for this branch)
+    extern __shared__ float tmp[];
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+      int64_t src = i + n;
+      tmp[i] = (src < N) ? hist[src] : (vs ? vs[src - N] : 0.f);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += blockDim.x) hist[i] = tmp[i];
+  }
+}
+
+} // namespace
+
+size_t ra_analysis_lds_bytes(const RaParams &p) {
+  size_t m = p.M > 0 ? p.M : 1;
+  return m * sizeof(double2) + 4 * (size_t)p.maxr * sizeof(double2) + (RA_ANALYSIS_THREADS + 1) * sizeof(int);
+}
+
+void ra_launch_analysis(const RaParams &p, const RaBuffers &b, const float *d_voice, int64_t t0, int64_t n, int64_t f_lo, int64_t n_frames_blk,
+                        hipStream_t st) {
+  if (n_frames_blk <= 0) return;
+  dim3 grid((unsigned)n_frames_blk, (unsigned)p.n_streams);
+  size_t lds = ra_analysis_lds_bytes(p);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void *>(ra_analysis_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(ra_analysis_kernel, grid, dim3(RA_ANALYSIS_THREADS), lds, st, p, b, d_voice, t0, n, f_lo);
+}
+
+void ra_launch_roll_history(const RaParams &p, const RaBuffers &b, const float *d_voice, int64_t n, hipStream_t st) {
+  if (n <= 0) return;
+  if (n >= p.N) {
+    dim3 grid((unsigned)((p.N + 255) / 256), (unsigned)p.n_streams);
+    hipLaunchKernelGGL(ra_roll_history_kernel, grid, dim3(256), 0, st, p, b, d_voice, n);
+  } else {
+    dim3 grid(1, (unsigned)p.n_streams);
+    hipLaunchKernelGGL(ra_roll_history_kernel, grid, dim3(256), (size_t)p.N * sizeof(float), st, p, b, d_voice, n);
+  }
+}

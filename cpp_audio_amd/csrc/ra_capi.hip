@@ -1,0 +1,651 @@
+// Host side of libresynth_amd.so: context, constant tables, block scheduling, the C ABI of include/resynth_amd.h.
+// There is no CPU fallback: every compute entry point needs a HIP device and fails with RA_ENODEVICE otherwise.
+#include "ra_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_last_error;
+static int fail(int code, const std::string &msg) { g_last_error = msg; return code; }
+
+#define HIP_TRY(expr)                                                                                          \
+  do {                                                                                                         \
+    hipError_t e_ = (expr);                                                                                    \
+    if (e_ != hipSuccess) return fail(RA_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));             \
+  } while (0)
+
+struct ra_context {
+  ra_config cfg;
+  RaParams p;
+  RaBuffers b;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int64_t t = 0;              // frames processed so far (per stream)
+  int64_t frames_fired = 0;   // analysis frames fired so far (per stream)
+  int64_t last_f_lo = 0, last_nfb = 0, last_n = 0, last_t0 = 0;
+  std::vector<void *> allocs;
+  // staging for the host-pointer entry points
+  float *st_voice = nullptr, *st_carrier = nullptr, *st_out = nullptr;
+  double *st_out_d = nullptr;
+  int64_t st_cap = 0;
+  std::vector<float> pending_voice, pending_carrier; // ra_feed -> ra_compute
+  double *dbg_sqmag = nullptr;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(ra_context *c, T **ptr, size_t count, bool zero = true) {
+  *ptr = nullptr;
+  if (count == 0) count = 1;
+  void *p = nullptr;
+  HIP_TRY(hipMalloc(&p, count * sizeof(T)));
+  if (zero) HIP_TRY(hipMemsetAsync(p, 0, count * sizeof(T), c->stream));
+  c->allocs.push_back(p);
+  *ptr = static_cast<T *>(p);
+  return RA_OK;
+}
+void dev_free(ra_context *c, void *p) {
+  if (!p) return;
+  auto it = std::find(c->allocs.begin(), c->allocs.end(), p);
+  if (it != c->allocs.end()) c->allocs.erase(it);
+  (void)hipFree(p);
+}
+template <typename T>
+int upload(ra_context *c, T **ptr, const std::vector<T> &v) {
+  int r = dev_alloc(c, ptr, v.size(), false);
+  if (r) return r;
+  if (!v.empty()) HIP_TRY(hipMemcpy(*ptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return RA_OK;
+}
+
+int fft_length_for(int n) { int l = 1; while (l < n) l <<= 1; return l; }
+
+// ---- host-side constants (own restatement of the reference's small pure functions; not the oracle) --------------
+constexpr int kNumHalftones = 12;
+double freq_to_pitch(double f) { return 69.0 + (kNumHalftones / 1.0) * std::log2(f / 440.f); } // midi.h:223-232
+
+const float kLoudFreqs[29] = {20.f, 25.f, 31.5f, 40.f, 50.f, 63.f, 80.f, 100.f, 125.f, 160.f, 200.f, 250.f, 315.f, 400.f, 500.f,
+                              630.f, 800.f, 1000.f, 1250.f, 1600.f, 2000.f, 2500.f, 3150.f, 4000.f, 5000.f, 6300.f, 8000.f, 10000.f, 12500.f};
+const float kAlpha[29] = {.532f, .506f, .480f, .455f, .432f, .409f, .387f, .367f, .349f, .330f, .315f, .301f, .288f, .276f, .267f,
+                          .259f, .253f, .250f, .246f, .244f, .243f, .243f, .243f, .242f, .242f, .245f, .254f, .271f, .301f};
+const float kLu[29] = {-31.6f, -27.2f, -23.0f, -19.1f, -15.9f, -13.0f, -10.3f, -8.1f, -6.2f, -4.5f, -3.1f, -2.0f, -1.1f, -0.4f, 0.f,
+                       .3f, .5f, 0.f, -2.7f, -4.1f, -1.0f, 1.7f, 2.5f, 1.2f, -2.1f, -7.1f, -11.2f, -10.7f, -3.1f};
+const float kTf[29] = {78.5f, 68.7f, 59.5f, 51.1f, 44.0f, 37.5f, 31.5f, 26.5f, 22.1f, 17.9f, 14.4f, 11.4f, 8.6f, 6.2f, 4.4f,
+                       3.0f, 2.2f, 2.4f, 3.5f, 1.7f, -1.3f, -4.2f, -6.0f, -5.4f, -1.5f, 6.0f, 12.6f, 13.9f, 12.3f};
+// include/loudness.h:188-197
+float equal_loudness_volume(int i, float LN) {
+  float Af = 4.47e-3f * (std::pow(10.f, .025f * LN) - 1.14f) + std::pow(.4f * std::pow(10.f, ((kTf[i] + kLu[i]) * .1f) - 9.f), kAlpha[i]);
+  return 94.f - kLu[i] + (10.f / kAlpha[i]) * std::log(Af) / std::log(10.f);
+}
+
+int ms_to_frames(float ms, int sr) { return static_cast<int>(0.5f + (static_cast<float>(sr) / 1000.f) * ms); } // sound.functions.h:29-35
+
+// mkAutotuneFunction tables, lib.cpp:1761-1873
+void build_autotune(const ra_config &c, RaParams &p, std::vector<double> &allowed) {
+  allowed.clear();
+  p.use_autotune = c.use_autotune ? 1 : 0;
+  p.autotune_type = c.autotune_type;
+  p.autotune_max_pitch = static_cast<double>(c.autotune_max_pitch);
+  static const double scales[3][8] = {{0., 2., 4., 5., 7., 9., 11., 12.}, {0., 2., 3., 5., 7., 8., 10., 12.}, {0., 2., 3., 5., 7., 8., 11., 12.}};
+  int mode = std::min(std::max(c.autotune_scale_mode, 0), 2);
+  for (int i = 0; i < 8; ++i) p.scale_pitches[i] = scales[mode][i];
+  for (int i = 0; i < 7; ++i) p.scale_equi[i] = 0.5 * (scales[mode][i] + scales[mode][i + 1]);
+  const int Do = 0, La = 9;
+  p.scale_root = 69.0 + c.autotune_root_transpose + (c.autotune_root_note - La);
+  if (!c.use_autotune) return;
+  if (c.autotune_type == RA_AUTOTUNE_CHORD) {
+    int offset = c.autotune_root_note - Do;
+    if (offset < 0) offset += kNumHalftones;
+    offset += c.autotune_root_transpose;
+    double const C_pitch = 69.0 + (Do - La) + kNumHalftones;
+    double const root = C_pitch + offset;
+    if (c.autotune_chord_frequencies == RA_CHORD_SINGLE || c.autotune_chord_frequencies == RA_CHORD_OCTAVES) {
+      bool single = c.autotune_chord_frequencies == RA_CHORD_SINGLE;
+      for (int octave = single ? 0 : -5; octave <= (single ? 0 : 5); ++octave)
+        for (int i = 0; i < 64; ++i)
+          if ((c.autotune_bit_chord >> i) & 1) allowed.push_back(root + i + kNumHalftones * octave);
+    } else {
+      for (int h = 0; h < 36; ++h) {
+        double add = static_cast<int>(0.5 + (kNumHalftones / 1.0) * std::log2(static_cast<float>(h + 1))); // midi.h:270-287
+        for (int i = 0; i < 64; ++i)
+          if ((c.autotune_bit_chord >> i) & 1) { allowed.push_back(root + add + i); allowed.push_back(root - add + i); }
+      }
+    }
+    std::sort(allowed.begin(), allowed.end());
+  } else if (c.autotune_type == RA_AUTOTUNE_INTERVALS) {
+    int o = c.autotune_root_note - Do;
+    if (o < 0) o += kNumHalftones;
+    double const offset = o + c.autotune_root_transpose;
+    allowed.push_back(offset);
+    int const factor = c.autotune_factor;
+    if (factor > 0) {
+      for (double v = offset - factor; v > 0.; v -= factor) allowed.push_back(v);
+      for (double v = offset + factor; v < 151.; v += factor) allowed.push_back(v);
+    }
+    std::sort(allowed.begin(), allowed.end());
+  }
+}
+
+int validate(const ra_config &c, int32_t n_streams) {
+  if (n_streams < 1) return fail(RA_EINVAL, "n_streams must be >= 1");
+  if (c.sample_rate < 1000) return fail(RA_EINVAL, "sample_rate is too small");
+  if (c.window_size < 2 || (c.window_size & 1)) return fail(RA_EINVAL, "window_size must be even and >= 2 (getEvenWindowSizeFrames)");
+  if (fft_length_for(c.window_size) > RA_MAX_FFT) return fail(RA_EINVAL, "window_size is too large (FFT length > 16384)");
+  if (c.stride < 1) return fail(RA_EINVAL, "window_center_stride is too small");
+  if (c.n_channels < 1 || c.n_channels > RA_MAX_CHANNELS) return fail(RA_EINVAL, "n_channels must be in 1..256");
+  if (c.min_volume < 0) return fail(RA_EINVAL, "min_volume is too small");
+  if (c.nearby_distance_tones < 0) return fail(RA_EINVAL, "nearby_distance_tones is too small");
+  if (c.max_track_pitches < 0) return fail(RA_EINVAL, "max_track_pitches is too small");
+  if (c.max_pitches_per_frame < 1 || c.max_pitches_per_frame > 4096) return fail(RA_EINVAL, "max_pitches_per_frame must be in 1..4096");
+  if (c.vocoder_count_bands < 1 || c.vocoder_count_bands > 50) return fail(RA_EINVAL, "vocoder_count_bands must be in 1..50");
+  if (c.window_kind < 0 || c.window_kind > 2) return fail(RA_EINVAL, "unknown window_kind");
+  if (c.autotune_factor < 0) return fail(RA_EINVAL, "autotune_factor must be >= 0");
+  return RA_OK;
+}
+
+int build_tables(ra_context *c) {
+  const ra_config &cfg = c->cfg;
+  RaParams &p = c->p;
+  std::memset(&p, 0, sizeof(p));
+  p.sample_rate = cfg.sample_rate;
+  p.N = cfg.window_size;
+  p.H = cfg.stride;
+  p.L = fft_length_for(p.N);
+  p.M = p.L / 2;
+  p.log2M = 0;
+  while ((1 << p.log2M) < p.M) ++p.log2M;
+  p.P = cfg.n_channels;
+  p.Ppad = ((p.P + 63) / 64) * 64;
+  p.maxr = cfg.max_pitches_per_frame;
+  p.min_volume = static_cast<double>(cfg.min_volume);
+  p.nearby = static_cast<double>(cfg.nearby_distance_tones);
+  p.max_track = static_cast<double>(cfg.max_track_pitches);
+  p.tolerance = cfg.autotune_tolerance_pitches;
+  p.shift_pre = cfg.pitch_shift_pre_autotune;
+  p.shift_post = cfg.pitch_shift_post_autotune;
+  p.harm_pre = cfg.pitch_harmonize_pre_autotune;
+  p.harm_post = cfg.pitch_harmonize_post_autotune;
+  p.analysis_volume = cfg.analysis_volume;
+  p.input_gain = cfg.analysis_input_gain;
+  p.stereo_spread = cfg.stereo_spread;
+  p.phase_policy = cfg.phase_policy;
+  p.seed = cfg.seed;
+  p.half_tone_ratio = std::pow(2., 1.0 / kNumHalftones); // midi.h:238-239
+  { // mkAHDSR (lib.cpp:63-82) then setAHDSR (audioelement.h:923-952)
+    int a = ms_to_frames(1000.f * cfg.env_attack_seconds, cfg.sample_rate), h = ms_to_frames(1000.f * cfg.env_hold_seconds, cfg.sample_rate);
+    int d = ms_to_frames(1000.f * cfg.env_decay_seconds, cfg.sample_rate), r = ms_to_frames(1000.f * cfg.env_release_seconds, cfg.sample_rate);
+    int min_dt = cfg.sample_rate / 1000;
+    bool hasDecay = cfg.env_sustain_level < 0.999999;
+    p.SMinusOne = hasDecay ? std::min(std::max(cfg.env_sustain_level, 0.f), 1.f) - 1.f : 0.f;
+    p.envA = std::max(a, min_dt);
+    p.envH = std::max(h, 0);
+    p.envD = hasDecay ? std::max(d, min_dt) : 0;
+    p.envR = std::max(r, min_dt);
+  }
+  p.vol_mod = cfg.voice_volume;
+  p.vol_car = cfg.carrier_volume;
+  p.vol_voc = cfg.vocoder_volume;
+  p.voc_enabled = (cfg.voice_volume != 0.f || cfg.carrier_volume != 0.f || cfg.vocoder_volume != 0.f) ? 1 : 0;
+
+  RaBuffers &b = c->b;
+  std::memset(&b, 0, sizeof(b));
+  int r;
+  { // half window: Gaussian truncated at 4 sigma, normalised so the full window sums to 2
+    int n = p.N / 2;
+    std::vector<double> hw(n);
+    double sigma = n / 4.0, sum = 0;
+    for (int j = 0; j < n; ++j) {
+      double d = j + 0.5;
+      hw[j] = cfg.window_kind == RA_WINDOW_GAUSSIAN4 ? std::exp(-(d * d) / (2.0 * sigma * sigma))
+              : cfg.window_kind == RA_WINDOW_HANN   ? 0.5 * (1.0 + std::cos(M_PI * d / n))
+                                                    : 1.0;
+      sum += hw[j];
+    }
+    for (auto &v : hw) v /= sum;
+    if ((r = upload(c, &b.half_window, hw))) return r;
+  }
+  {
+    int M = p.M;
+    std::vector<double2> tw(std::max(M / 2, 1));
+    for (int k = 0; k < M / 2; ++k) { double a = -2.0 * M_PI * k / M; tw[k] = make_double2(std::cos(a), std::sin(a)); }
+    if ((r = upload(c, &b.tw_half, tw))) return r;
+    std::vector<double2> tf(M + 1);
+    for (int k = 0; k <= M; ++k) { double a = -2.0 * M_PI * k / p.L; tf[k] = make_double2(std::cos(a), std::sin(a)); }
+    if ((r = upload(c, &b.tw_full, tf))) return r;
+    std::vector<int> rev(std::max(M, 1), 0);
+    for (int i = 0; i < M; ++i) {
+      int x = 0;
+      for (int bit = 0; bit < p.log2M; ++bit) if (i & (1 << bit)) x |= 1 << (p.log2M - 1 - bit);
+      rev[i] = x;
+    }
+    if ((r = upload(c, &b.bitrev, rev))) return r;
+  }
+  { // include/loudness.h: pitches table (:43-54) and the 60 phon row of elvs (:199-229, lib.cpp:1717)
+    std::vector<double> lp(29);
+    std::vector<float> elv(29);
+    for (int i = 0; i < 29; ++i) { lp[i] = freq_to_pitch(kLoudFreqs[i]); elv[i] = equal_loudness_volume(i, 60.f); }
+    if ((r = upload(c, &b.loud_pitches, lp))) return r;
+    if ((r = upload(c, &b.loud_elv, elv))) return r;
+  }
+  {
+    std::vector<double> allowed;
+    build_autotune(cfg, p, allowed);
+    p.n_allowed = static_cast<int>(allowed.size());
+    if ((r = upload(c, &b.allowed, allowed))) return r;
+  }
+  return RA_OK;
+}
+
+int alloc_state(ra_context *c) {
+  RaParams &p = c->p;
+  RaBuffers &b = c->b;
+  int r;
+  size_t S = p.n_streams;
+  if ((r = dev_alloc(c, &b.hist, S * p.N))) return r;
+  if ((r = dev_alloc(c, &b.track, S))) return r;
+  if ((r = dev_alloc(c, &b.played, S * p.P))) return r;
+  if ((r = dev_alloc(c, &b.chan_free_at, S * p.P))) return r;
+  if ((r = dev_alloc(c, &b.chan_held, S * p.P))) return r;
+  if ((r = dev_alloc(c, &b.chan_minch, S * p.P))) return r;
+  if ((r = dev_alloc(c, &b.sd, S * SD_COUNT * p.Ppad))) return r;
+  if ((r = dev_alloc(c, &b.si, S * SI_COUNT * p.Ppad))) return r;
+  if ((r = dev_alloc(c, &b.error_flags, 1))) return r;
+  return RA_OK;
+}
+
+// state right after construction: envelopes Done2 (audioelement.h:358-360), oscillators at angle 0 with increment 0 (:2376-2377, 2438-2441)
+int init_state(ra_context *c) {
+  RaParams &p = c->p;
+  RaBuffers &b = c->b;
+  size_t S = p.n_streams;
+  HIP_TRY(hipMemsetAsync(b.hist, 0, S * p.N * sizeof(float), c->stream));
+  HIP_TRY(hipMemsetAsync(b.track, 0, S * sizeof(RaTrackState), c->stream));
+  HIP_TRY(hipMemsetAsync(b.played, 0, S * p.P * sizeof(RaPlayed), c->stream));
+  HIP_TRY(hipMemsetAsync(b.chan_free_at, 0, S * p.P * sizeof(int64_t), c->stream));
+  HIP_TRY(hipMemsetAsync(b.chan_held, 0, S * p.P * sizeof(int32_t), c->stream));
+  HIP_TRY(hipMemsetAsync(b.chan_minch, 0, S * p.P * sizeof(int32_t), c->stream));
+  HIP_TRY(hipMemsetAsync(b.error_flags, 0, sizeof(int32_t), c->stream));
+  std::vector<double> sd(S * SD_COUNT * p.Ppad, 0.0);
+  std::vector<int32_t> si(S * SI_COUNT * p.Ppad, 0);
+  for (size_t s = 0; s < S; ++s) {
+    double *d = sd.data() + s * SD_COUNT * p.Ppad;
+    int32_t *i = si.data() + s * SI_COUNT * p.Ppad;
+    for (int l = 0; l < p.Ppad; ++l) {
+      d[SD_OSC_CRE * p.Ppad + l] = 1.0;
+      d[SD_OSC_MRE * p.Ppad + l] = 1.0;
+      d[SD_OSC_ALIAS * p.Ppad + l] = 1.0;
+      d[SD_GAIN_L * p.Ppad + l] = 0.0;
+      i[SI_ENV_STATE * p.Ppad + l] = ENV_DONE2;
+      i[SI_ENV_RELDELAY * p.Ppad + l] = -1;
+      i[SI_ENV_AHDSTATE * p.Ppad + l] = -1;
+    }
+  }
+  HIP_TRY(hipMemcpyAsync(b.sd, sd.data(), sd.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(b.si, si.data(), si.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->t = 0;
+  c->frames_fired = 0;
+  c->last_f_lo = c->last_nfb = c->last_n = c->last_t0 = 0;
+  c->pending_voice.clear();
+  c->pending_carrier.clear();
+  return RA_OK;
+}
+
+int ensure_scratch(ra_context *c, int64_t nfb, int64_t n) {
+  RaParams &p = c->p;
+  RaBuffers &b = c->b;
+  int r;
+  if (nfb > b.frames_cap) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dev_free(c, b.pl_pitch); dev_free(c, b.pl_vol); dev_free(c, b.pl_key); dev_free(c, b.pl_count); dev_free(c, b.cmd);
+    size_t S = p.n_streams, F = static_cast<size_t>(nfb);
+    b.frames_cap = nfb;
+    if ((r = dev_alloc(c, &b.pl_pitch, S * F * p.maxr, false))) return r;
+    if ((r = dev_alloc(c, &b.pl_vol, S * F * p.maxr, false))) return r;
+    if ((r = dev_alloc(c, &b.pl_key, S * F * p.maxr, false))) return r;
+    if ((r = dev_alloc(c, &b.pl_count, S * F))) return r;
+    if ((r = dev_alloc(c, &b.cmd, S * F * p.Ppad, false))) return r;
+  }
+  if (p.voc_enabled && n > b.mix_cap) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dev_free(c, b.voc_mix);
+    b.mix_cap = n;
+    if ((r = dev_alloc(c, &b.voc_mix, static_cast<size_t>(p.n_streams) * n, false))) return r;
+  }
+  return RA_OK;
+}
+
+// frames with fire sample in [t0, t0 + n)
+void frames_in_block(const RaParams &p, int64_t t0, int64_t n, int64_t &f_lo, int64_t &nfb) {
+  int64_t first = (int64_t)p.N + 1;
+  int64_t a = t0 - first;
+  f_lo = a <= 0 ? 0 : (a + p.H - 1) / p.H;
+  int64_t bnd = t0 + n - 1 - first;
+  if (bnd < 0) { nfb = 0; return; }
+  int64_t f_hi = bnd / p.H;
+  nfb = f_hi >= f_lo ? f_hi - f_lo + 1 : 0;
+}
+
+int process_block(ra_context *c, const float *d_voice, const float *d_carrier, int64_t n, float *d_out, double *d_out_d) {
+  if (n <= 0) return RA_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  RaParams &p = c->p;
+  if (p.voc_enabled) return fail(RA_EINVAL, "vocoder volumes are non-zero: vocoder path not available in this build");
+  (void)d_carrier;
+  int64_t f_lo, nfb;
+  frames_in_block(p, c->t, n, f_lo, nfb);
+  int r = ensure_scratch(c, nfb, n);
+  if (r) return r;
+  c->b.dbg_sqmag = c->dbg_sqmag;
+  ra_launch_analysis(p, c->b, d_voice, c->t, n, f_lo, nfb, c->stream);
+  ra_launch_track(p, c->b, f_lo, nfb, c->stream);
+  ra_launch_synth(p, c->b, c->t, n, f_lo, nfb, d_out, d_out_d, c->stream);
+  ra_launch_roll_history(p, c->b, d_voice, n, c->stream);
+  HIP_TRY(hipGetLastError());
+  c->last_f_lo = f_lo; c->last_nfb = nfb; c->last_n = n; c->last_t0 = c->t;
+  c->t += n;
+  c->frames_fired += nfb;
+  return RA_OK;
+}
+
+int ensure_staging(ra_context *c, int64_t n) {
+  if (n <= c->st_cap) return RA_OK;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  dev_free(c, c->st_voice); dev_free(c, c->st_carrier); dev_free(c, c->st_out); dev_free(c, c->st_out_d);
+  size_t S = c->p.n_streams;
+  int r;
+  c->st_cap = n;
+  if ((r = dev_alloc(c, &c->st_voice, S * n, false))) return r;
+  if ((r = dev_alloc(c, &c->st_carrier, S * n, false))) return r;
+  if ((r = dev_alloc(c, &c->st_out, S * n * 2, false))) return r;
+  if ((r = dev_alloc(c, &c->st_out_d, S * n * 2, false))) return r;
+  return RA_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *ra_last_error(void) { return g_last_error.c_str(); }
+
+int ra_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int ra_default_config(ra_config *c) { // source/rt.resynth.lib.cpp:943-999
+  if (!c) return fail(RA_EINVAL, "null config");
+  std::memset(c, 0, sizeof(*c));
+  c->sample_rate = 48000;
+  c->window_size = 4096;
+  c->stride = 1024;
+  c->n_channels = 64;
+  c->window_kind = RA_WINDOW_GAUSSIAN4;
+  c->min_volume = 0.0001f;
+  c->nearby_distance_tones = 0.4f;
+  c->max_track_pitches = 1.f;
+  c->autotune_tolerance_pitches = 100.f;
+  c->stereo_spread = 1.f;
+  c->env_sustain_level = 1.f;
+  c->autotune_type = RA_AUTOTUNE_SCALE;
+  c->autotune_max_pitch = 150;
+  c->autotune_factor = 2;
+  c->autotune_scale_mode = RA_SCALE_MAJOR;
+  c->autotune_chord_frequencies = RA_CHORD_HARMONICS;
+  c->autotune_bit_chord = 0b10010001;
+  c->vocoder_modulator_window_size_seconds = 0.10f;
+  c->vocoder_stride_seconds = 0.005f;
+  c->vocoder_count_bands = 5;
+  c->vocoder_min_freq = 100.f;
+  c->vocoder_max_freq = 20000.f;
+  c->voice_volume = 0.f;
+  c->carrier_volume = 0.1f;
+  c->vocoder_volume = 0.f;
+  c->analysis_volume = 0.f;
+  c->analysis_input_gain = 1.f;
+  c->phase_policy = RA_PHASE_HASH;
+  c->seed = 0;
+  c->max_pitches_per_frame = 512;
+  return RA_OK;
+}
+
+int ra_even_window_size_frames(float window_size_seconds, int sample_rate) { // lib.cpp:484-487
+  return 2 * std::max(1, sample_rate ? static_cast<int>(0.5 * window_size_seconds * sample_rate) : 0);
+}
+int ra_window_center_stride_frames(float stride_seconds, int sample_rate) { // lib.cpp:1577-1578
+  return std::max(1, static_cast<int>(0.5f + stride_seconds * sample_rate));
+}
+
+int ra_create(const ra_config *cfg, int32_t n_streams, int32_t device, ra_context **out) {
+  if (!cfg || !out) return fail(RA_EINVAL, "null argument");
+  *out = nullptr;
+  int r = validate(*cfg, n_streams);
+  if (r) return r;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(RA_ENODEVICE, "no HIP device visible (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(RA_EINVAL, "device ordinal out of range");
+  HIP_TRY(hipSetDevice(device));
+  ra_context *c = new ra_context();
+  c->cfg = *cfg;
+  c->device = device;
+  r = build_tables(c);
+  c->p.n_streams = n_streams;
+  if (!r) r = alloc_state(c);
+  if (!r) r = init_state(c);
+  if (r) { std::string keep = g_last_error; ra_destroy(c); g_last_error = keep; return r; }
+  *out = c;
+  return RA_OK;
+}
+
+void ra_destroy(ra_context *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (void *p : c->allocs) (void)hipFree(p);
+  delete c;
+}
+
+int ra_reset(ra_context *c) {
+  if (!c) return fail(RA_EINVAL, "null context");
+  HIP_TRY(hipSetDevice(c->device));
+  return init_state(c);
+}
+
+int ra_set_hip_stream(ra_context *c, void *hip_stream) {
+  if (!c) return fail(RA_EINVAL, "null context");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->stream = static_cast<hipStream_t>(hip_stream);
+  return RA_OK;
+}
+
+int ra_process_device(ra_context *c, const float *d_voice, const float *d_carrier, int64_t n_frames, float *d_out) {
+  if (!c) return fail(RA_EINVAL, "null context");
+  if (n_frames < 0) return fail(RA_EINVAL, "n_frames < 0");
+  if (!d_out && n_frames > 0) return fail(RA_EINVAL, "null output");
+  return process_block(c, d_voice, d_carrier, n_frames, d_out, nullptr);
+}
+
+int ra_synchronize(ra_context *c) {
+  if (!c) return fail(RA_EINVAL, "null context");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  int32_t flags = 0;
+  HIP_TRY(hipMemcpy(&flags, c->b.error_flags, sizeof(flags), hipMemcpyDeviceToHost));
+  if (flags & RA_ERR_OVERFLOW) return fail(RA_EOVERFLOW, "a per-frame pitch list exceeded max_pitches_per_frame");
+  if (flags & RA_ERR_BOOKKEEPING) return fail(RA_EINTERNAL, "channel bookkeeping mismatch between tracking and synthesis");
+  return RA_OK;
+}
+
+int ra_process_host(ra_context *c, const float *h_voice, const float *h_carrier, int64_t n, float *h_out) {
+  if (!c) return fail(RA_EINVAL, "null context");
+  if (n < 0) return fail(RA_EINVAL, "n_frames < 0");
+  if (n == 0) return RA_OK;
+  if (!h_out) return fail(RA_EINVAL, "null output");
+  HIP_TRY(hipSetDevice(c->device));
+  int r = ensure_staging(c, n);
+  if (r) return r;
+  size_t S = c->p.n_streams;
+  if (h_voice) HIP_TRY(hipMemcpyAsync(c->st_voice, h_voice, S * n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  if (h_carrier) HIP_TRY(hipMemcpyAsync(c->st_carrier, h_carrier, S * n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  r = process_block(c, h_voice ? c->st_voice : nullptr, h_carrier ? c->st_carrier : nullptr, n, c->st_out, nullptr);
+  if (r) return r;
+  HIP_TRY(hipMemcpyAsync(h_out, c->st_out, S * n * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  return ra_synchronize(c);
+}
+
+int ra_feed(ra_context *c, int32_t stream, const float *h_voice, const float *h_carrier, int32_t n) {
+  if (!c) return fail(RA_EINVAL, "null context");
+  if (c->p.n_streams != 1 || stream != 0) return fail(RA_EINVAL, "ra_feed/ra_compute drive a single-stream context (one RtResynth = one context)");
+  if (n < 0) return fail(RA_EINVAL, "n_frames < 0");
+  for (int i = 0; i < n; ++i) {
+    c->pending_voice.push_back(h_voice ? h_voice[i] : 0.f);
+    c->pending_carrier.push_back(h_carrier ? h_carrier[i] : 0.f);
+  }
+  return RA_OK;
+}
+
+int ra_compute(ra_context *c, int32_t stream, double *h_buffer, int32_t n) {
+  if (!c) return fail(RA_EINVAL, "null context");
+  if (c->p.n_streams != 1 || stream != 0) return fail(RA_EINVAL, "ra_feed/ra_compute drive a single-stream context (one RtResynth = one context)");
+  if (n < 1 || n > RA_N_FRAMES_PER_BUFFER) return fail(RA_EINVAL, "nFrames must be in 1..16 (max_n_frames_per_loop)");
+  if (!h_buffer) return fail(RA_EINVAL, "null buffer");
+  if (static_cast<int>(c->pending_voice.size()) < n) return fail(RA_EINVAL, "ra_compute: fewer frames fed than requested");
+  HIP_TRY(hipSetDevice(c->device));
+  int r = ensure_staging(c, n);
+  if (r) return r;
+  HIP_TRY(hipMemcpyAsync(c->st_voice, c->pending_voice.data(), n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->st_carrier, c->pending_carrier.data(), n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  r = process_block(c, c->st_voice, c->st_carrier, n, nullptr, c->st_out_d);
+  if (r) return r;
+  double tmp[RA_N_FRAMES_PER_BUFFER * 2];
+  HIP_TRY(hipMemcpyAsync(tmp, c->st_out_d, n * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  r = ra_synchronize(c);
+  if (r) return r;
+  for (int i = 0; i < 2 * n; ++i) h_buffer[i] += tmp[i]; // the reference computes accumulate (gen.crtp.h:364-369)
+  c->pending_voice.erase(c->pending_voice.begin(), c->pending_voice.begin() + n);
+  c->pending_carrier.erase(c->pending_carrier.begin(), c->pending_carrier.begin() + n);
+  return 1;
+}
+
+int ra_get_stats(ra_context *c, ra_stats *st) {
+  if (!c || !st) return fail(RA_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  std::vector<RaTrackState> ts(c->p.n_streams);
+  HIP_TRY(hipMemcpy(ts.data(), c->b.track, ts.size() * sizeof(RaTrackState), hipMemcpyDeviceToHost));
+  std::memset(st, 0, sizeof(*st));
+  for (auto &x : ts) st->dropped_note_on += x.dropped_note_on;
+  st->frames_analysed = c->frames_fired * c->p.n_streams;
+  st->samples_rendered = c->t;
+  HIP_TRY(hipMemcpy(&st->error_flags, c->b.error_flags, sizeof(int32_t), hipMemcpyDeviceToHost));
+  return RA_OK;
+}
+
+int64_t ra_get_events(ra_context *c, int32_t stream, ra_event *h_events, int64_t cap) {
+  if (!c) return fail(RA_EINVAL, "null context");
+  if (stream < 0 || stream >= c->p.n_streams) return fail(RA_EINVAL, "stream out of range");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const RaParams &p = c->p;
+  int64_t nfb = c->last_nfb;
+  if (nfb == 0) return 0;
+  std::vector<RaCmd> cmds(static_cast<size_t>(nfb) * p.Ppad);
+  HIP_TRY(hipMemcpy(cmds.data(), c->b.cmd + static_cast<size_t>(stream) * c->b.frames_cap * p.Ppad, cmds.size() * sizeof(RaCmd), hipMemcpyDeviceToHost));
+  int64_t count = 0;
+  std::vector<std::pair<int, int>> order;
+  for (int64_t fb = 0; fb < nfb; ++fb) {
+    order.clear();
+    for (int l = 0; l < p.P; ++l) {
+      const RaCmd &m = cmds[fb * p.Ppad + l];
+      if (m.type != RA_CMD_NONE) order.push_back({m.ord, l});
+    }
+    std::sort(order.begin(), order.end());
+    for (auto &o : order) {
+      const RaCmd &m = cmds[fb * p.Ppad + o.second];
+      if (count < cap && h_events) {
+        ra_event e;
+        e.sample = ra_fire_sample(p.N, p.H, c->last_f_lo + fb);
+        e.type = m.type == RA_CMD_ON ? 0 : m.type == RA_CMD_OFF ? 1 : 2;
+        e.channel = o.second;
+        e.noteid = m.noteid;
+        e.frequency = m.freq;
+        e.velocity = m.vel;
+        h_events[count] = e;
+      }
+      ++count;
+    }
+  }
+  return count;
+}
+
+int64_t ra_get_frame_pitches(ra_context *c, int32_t stream, int64_t *h_fire, int64_t *h_offsets, int64_t frame_cap, double *h_pitch, double *h_vol,
+                             int64_t item_cap) {
+  if (!c) return fail(RA_EINVAL, "null context");
+  if (stream < 0 || stream >= c->p.n_streams) return fail(RA_EINVAL, "stream out of range");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const RaParams &p = c->p;
+  int64_t nfb = c->last_nfb;
+  if (nfb == 0) return 0;
+  std::vector<int32_t> counts(nfb);
+  HIP_TRY(hipMemcpy(counts.data(), c->b.pl_count + static_cast<size_t>(stream) * c->b.frames_cap, nfb * sizeof(int32_t), hipMemcpyDeviceToHost));
+  std::vector<double> pit(static_cast<size_t>(nfb) * p.maxr), vol(static_cast<size_t>(nfb) * p.maxr);
+  size_t base = static_cast<size_t>(stream) * c->b.frames_cap * p.maxr;
+  HIP_TRY(hipMemcpy(pit.data(), c->b.pl_pitch + base, pit.size() * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(vol.data(), c->b.pl_vol + base, vol.size() * sizeof(double), hipMemcpyDeviceToHost));
+  int64_t pos = 0;
+  for (int64_t fb = 0; fb < nfb && fb < frame_cap; ++fb) {
+    h_fire[fb] = ra_fire_sample(p.N, p.H, c->last_f_lo + fb);
+    h_offsets[fb] = pos;
+    for (int i = 0; i < counts[fb]; ++i) {
+      if (pos < item_cap) { h_pitch[pos] = pit[fb * p.maxr + i]; h_vol[pos] = vol[fb * p.maxr + i]; }
+      ++pos;
+    }
+    h_offsets[fb + 1] = pos;
+  }
+  return nfb;
+}
+
+int ra_sqmag(const float *h_windows, int32_t n_windows, int32_t window_size, int32_t window_kind, int32_t device, double *h_sqmag, int32_t *fft_length) {
+  if (!h_windows || !h_sqmag || n_windows < 1) return fail(RA_EINVAL, "bad argument");
+  ra_config cfg;
+  ra_default_config(&cfg);
+  cfg.window_size = window_size;
+  cfg.stride = window_size;
+  cfg.window_kind = window_kind;
+  ra_context *c = nullptr;
+  int r = ra_create(&cfg, 1, device, &c);
+  if (r) return r;
+  int M = c->p.M;
+  if (fft_length) *fft_length = c->p.L;
+  int64_t n = 2 + static_cast<int64_t>(n_windows) * window_size; // PeriodicFFT starts at input sample 2
+  std::vector<float> in(n, 0.f), out(static_cast<size_t>(n) * 2);
+  std::memcpy(in.data() + 2, h_windows, sizeof(float) * n_windows * window_size);
+  double *dbg = nullptr;
+  r = dev_alloc(c, &dbg, static_cast<size_t>(n_windows) * M);
+  if (!r) {
+    c->dbg_sqmag = dbg;
+    r = ra_process_host(c, in.data(), nullptr, n, out.data());
+  }
+  if (!r) {
+    if (c->last_nfb != n_windows) r = fail(RA_EINTERNAL, "ra_sqmag: unexpected frame count");
+    else if (hipMemcpy(h_sqmag, dbg, sizeof(double) * n_windows * M, hipMemcpyDeviceToHost) != hipSuccess) r = fail(RA_EHIP, "copy back failed");
+  }
+  std::string keep = g_last_error;
+  ra_destroy(c);
+  g_last_error = keep;
+  return r;
+}
+
+int64_t ra_resynth_notes(const ra_note *, int32_t, int32_t, int32_t, int32_t, double *, int64_t) {
+  return fail(RA_EINVAL, "ra_resynth_notes: not available in this build");
+}
+
+} // extern "C"

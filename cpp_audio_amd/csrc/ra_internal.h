@@ -1,0 +1,120 @@
+// Internal declarations shared by the host side (ra_capi.hip) and the gfx950 kernels.
+// Data layout in HBM is described in DESIGN.md §3.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/resynth_amd.h"
+
+#define RA_MAX_CHANNELS 256
+#define RA_MAX_FFT 16384
+#define RA_ANALYSIS_THREADS 256
+#define RA_N_FRAMES_PER_BUFFER 16 // audioelement.h:3
+
+// ---- parameters every kernel reads (uniform; passed by value) -------------------------------------
+struct RaParams {
+  int sample_rate, N, H, L, M;       // M = L/2 complex points
+  int log2M;
+  int P, Ppad;                       // channels, padded to a multiple of 64
+  int maxr;                          // pitch-list capacity per frame
+  int n_streams;
+  // step pipeline
+  double min_volume, nearby, max_track;
+  float tolerance, shift_pre, shift_post, harm_pre, harm_post;
+  int use_autotune, autotune_type, n_allowed;
+  double autotune_max_pitch, scale_root;
+  double scale_pitches[8], scale_equi[7];
+  float analysis_volume, input_gain, stereo_spread;
+  // envelope (setAHDSR result, audioelement.h:923-952)
+  int envA, envH, envD, envR;
+  float SMinusOne;
+  int phase_policy;
+  uint64_t seed;
+  double half_tone_ratio;
+  // vocoder
+  int voc_enabled, voc_S, voc_Wm, voc_Lm, voc_Lc, voc_bands;
+  float vol_mod, vol_car, vol_voc;
+};
+
+// ---- analysis -> tracking hand-off: one list per (stream, frame) ----------------------------------
+// pitch/vol/key arrays are [n_streams][frames_cap][maxr]; count is [n_streams][frames_cap]
+
+// ---- tracking -> synthesis hand-off: at most ONE command per (frame, channel) ---------------------
+enum { RA_CMD_NONE = 0, RA_CMD_ON = 1, RA_CMD_OFF = 2, RA_CMD_CHANGE = 3 };
+struct RaCmd {
+  int32_t type;     // RA_CMD_*
+  int32_t ord;      // position in the frame's one-shot order (simple_audio_context.h:74-76 runs them FIFO)
+  float freq;       // Hz, already rounded to float like events.h:19-29
+  float vel;
+  int64_t noteid;
+};
+
+// ---- persistent tracking state, one per stream ----------------------------------------------------
+struct RaPlayed {
+  int64_t noteid;
+  double pitch;
+  int32_t channel;
+  int32_t pad;
+};
+struct RaTrackState {
+  int64_t next_noteid;
+  int64_t dropped_note_on;
+  int32_t n_played;
+  int32_t pad;
+};
+
+// ---- persistent per-channel synth state: struct of arrays [n_streams][field][Ppad] -----------------
+enum {
+  SD_ENV_VALUE, SD_ENV_TOP, SD_CTRL_FROM, SD_CTRL_TO, SD_CTRL_CUR, SD_CTRL_C, SD_CTRL_FRES,
+  SD_OSC_CRE, SD_OSC_CIM, SD_OSC_MRE, SD_OSC_MIM, SD_OSC_ALIAS, SD_OSC_INC,
+  SD_VOL, SD_VOL_TARGET, SD_VOL_FINIT, SD_VOL_K, SD_VOL_Y, SD_GAIN_L, SD_GAIN_R,
+  SD_COUNT
+};
+enum { SI_ENV_STATE, SI_ENV_COUNTER, SI_ENV_RELDELAY, SI_ENV_AHDSTATE, SI_ENV_AHDCOUNTER, SI_ENV_MINCH, SI_ENV_NEXTMINCH, SI_FLAGS, SI_COUNT };
+enum { FL_HAS_FRES = 1, FL_HAS_VOL = 2, FL_HAS_TARGET = 4 };
+enum { ENV_SOON = 0, ENV_PRESSED = 1, ENV_RELEASED = 2, ENV_DONE1 = 3, ENV_DONE2 = 4 }; // audioelement.h:157-163
+
+enum { RA_ERR_OVERFLOW = 1, RA_ERR_BOOKKEEPING = 2 };
+
+// device buffers of one context
+struct RaBuffers {
+  // constant tables
+  double *half_window;      // [N/2]
+  double2 *tw_half;         // [M/2]  e^{-2 pi i k / M}
+  double2 *tw_full;         // [M+1]  e^{-2 pi i k / L}
+  int *bitrev;              // [M]
+  double *loud_pitches;     // [29]
+  float *loud_elv;          // [29] at 60 phon
+  double *allowed;          // [n_allowed]
+  // stream state
+  float *hist;              // [n_streams][N] last N input samples before the current block
+  RaTrackState *track;      // [n_streams]
+  RaPlayed *played;         // [n_streams][P]
+  int64_t *chan_free_at;    // [n_streams][P]
+  int32_t *chan_held;       // [n_streams][P]
+  int32_t *chan_minch;      // [n_streams][P]
+  double *sd;               // [n_streams][SD_COUNT][Ppad]
+  int32_t *si;              // [n_streams][SI_COUNT][Ppad]
+  int32_t *error_flags;     // [1]
+  // per-block scratch (grown on demand)
+  int64_t frames_cap;
+  double *pl_pitch, *pl_vol; // [n_streams][frames_cap][maxr]
+  float *pl_key;
+  int32_t *pl_count;        // [n_streams][frames_cap]
+  RaCmd *cmd;               // [n_streams][frames_cap][Ppad]
+  double *voc_mix;          // [n_streams][n] when the vocoder is enabled
+  int64_t mix_cap;
+  double *dbg_sqmag;        // optional [frames][M] tap of |X|^2 (ra_sqmag), normally null
+};
+
+// launchers (defined next to their kernels)
+void ra_launch_analysis(const RaParams &p, const RaBuffers &b, const float *d_voice, int64_t t0, int64_t n, int64_t f_lo, int64_t n_frames_blk,
+                        hipStream_t st);
+void ra_launch_track(const RaParams &p, const RaBuffers &b, int64_t f_lo, int64_t n_frames_blk, hipStream_t st);
+void ra_launch_synth(const RaParams &p, const RaBuffers &b, int64_t t0, int64_t n, int64_t f_lo, int64_t n_frames_blk, float *d_out,
+                     double *d_out_d, hipStream_t st);
+void ra_launch_roll_history(const RaParams &p, const RaBuffers &b, const float *d_voice, int64_t n, hipStream_t st);
+size_t ra_analysis_lds_bytes(const RaParams &p);
+
+// frame f covers input samples [2 + f H, 2 + f H + N) and fires in iteration N + 1 + f H
+__host__ __device__ inline int64_t ra_fire_sample(int N, int H, int64_t f) { return (int64_t)N + 1 + f * (int64_t)H; }

@@ -1,0 +1,186 @@
+/*
+ * resynth_amd — MI355X (gfx950) implementation of cpp.audio's rt.resynth analysis -> resynthesis hot path.
+ *
+ * C ABI of libresynth_amd.so.  Plain pointers and sizes only; no torch / C++ types cross this boundary.
+ * The reference (OlivierSohn/cpp.audio) has no FFI for this path: its components meet through C++
+ * templates and two type-erased callables.  Each entry point below names the
+ * reference interface it stands in for (paths relative to the reference checkout); INTEGRATION.md
+ * shows the few lines of C++ a maintainer adds on the reference side to bind them.
+ *
+ * Threading: one ra_context is used from one host thread at a time (the reference's audio thread /
+ * offline-job constructor thread, source/rt.resynth.lib.cpp:1185-1235).
+ * Errors: every call returns RA_OK or a negative RA_E* code; ra_last_error() gives the text.  The C++
+ * shims in cpp_audio_amd/host/ turn codes back into the reference's exceptions / bool conventions.
+ */
+#ifndef RESYNTH_AMD_H
+#define RESYNTH_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RA_OK 0
+#define RA_EINVAL -1      /* bad argument / config (reference: std::invalid_argument, lib.cpp:449-481) */
+#define RA_ENODEVICE -2   /* no usable HIP device: there is NO CPU fallback */
+#define RA_EHIP -3        /* a HIP runtime call failed */
+#define RA_EOVERFLOW -4   /* a per-frame list exceeded its capacity (see ra_config.max_pitches_per_frame) */
+#define RA_EINTERNAL -5   /* device-side consistency check failed (decision/synth channel bookkeeping disagree) */
+
+enum { RA_AUTOTUNE_SCALE = 0, RA_AUTOTUNE_CHORD = 1, RA_AUTOTUNE_INTERVALS = 2 };     /* rt.resynth.lib.autotune.cpp:3-8   */
+enum { RA_SCALE_MAJOR = 0, RA_SCALE_MINOR_NATURAL = 1, RA_SCALE_MINOR_HARMONIC = 2 }; /* rt.resynth.lib.autotune.cpp:9-14  */
+enum { RA_CHORD_SINGLE = 0, RA_CHORD_HARMONICS = 1, RA_CHORD_OCTAVES = 2 };           /* rt.resynth.lib.autotune.cpp:16-20 */
+enum { RA_WINDOW_GAUSSIAN4 = 0, RA_WINDOW_HANN = 1, RA_WINDOW_RECT = 2 };             /* periodicfft.cpp:246-249 (+Hann, main.test_fft.cpp:79) */
+enum { RA_PHASE_HASH = 0, RA_PHASE_ZERO = 1 };                                        /* gen.crtp.h:147-155 DefaultStartPhase */
+
+/*
+ * The parameter block of one RtResynth (the std::atomic<> members of source/rt.resynth.lib.cpp:943-999,
+ * same names, same defaults via ra_default_config).  Every stream of a context shares it.
+ * window_size / stride are in frames; ra_even_window_size_frames / ra_window_center_stride_frames
+ * reproduce the reference's seconds -> frames rules (lib.cpp:484-487, 1577-1578).
+ */
+typedef struct ra_config {
+  int32_t sample_rate;
+  int32_t window_size;          /* N, even; FFT length = next power of two >= N (<= 16384) */
+  int32_t stride;               /* H */
+  int32_t n_channels;           /* P = 2 * nVoices, the partial cap (gen.crtp.h:225); <= 256 */
+  int32_t window_kind;          /* RA_WINDOW_*; the reference analyses with RA_WINDOW_GAUSSIAN4 */
+
+  float min_volume;
+  float nearby_distance_tones;
+  float max_track_pitches;
+  float autotune_tolerance_pitches;
+  float pitch_shift_pre_autotune, pitch_shift_post_autotune;
+  float pitch_harmonize_pre_autotune, pitch_harmonize_post_autotune;
+  float stereo_spread;
+
+  float env_attack_seconds, env_hold_seconds, env_decay_seconds, env_release_seconds, env_sustain_level;
+
+  int32_t use_autotune;
+  int32_t autotune_type;
+  int32_t autotune_max_pitch;
+  int32_t autotune_factor;
+  int32_t autotune_scale_mode;
+  int32_t autotune_root_note;   /* 0 = Do .. 11 = Si (include/midi.h:11-24) */
+  int32_t autotune_root_transpose;
+  int32_t autotune_chord_frequencies;
+  uint64_t autotune_bit_chord;
+
+  float vocoder_modulator_window_size_seconds;
+  float vocoder_stride_seconds;
+  int32_t vocoder_count_bands;  /* <= 50 (vocoder.cpp:98) */
+  float vocoder_min_freq, vocoder_max_freq;
+  float voice_volume, carrier_volume, vocoder_volume, analysis_volume;
+
+  float analysis_input_gain;
+
+  /* Declared policy for the reference's two unpinned random draws (start phase gen.crtp.h:152, pan lib.cpp:116):
+   * a counter hash of (seed + stream index, note id). */
+  int32_t phase_policy;
+  uint64_t seed;
+
+  /* capacity of the per-frame pitch list handed from analysis to tracking (the reference's vectors grow
+   * on demand, lib.cpp:1102-1112); exceeding it sets RA_EOVERFLOW instead of truncating silently. */
+  int32_t max_pitches_per_frame; /* default 512 */
+} ra_config;
+
+typedef struct ra_context ra_context;
+
+/* One event as it reached the synth (ImplCRTP::onEvent, include/gen.crtp.h:382-622), for inspection/tests. */
+typedef struct ra_event {
+  int64_t sample;   /* output frame at which it took effect */
+  int32_t type;     /* 0 NoteOn, 1 NoteOff, 2 NoteChange */
+  int32_t channel;
+  int64_t noteid;
+  float frequency, velocity;
+} ra_event;
+
+typedef struct ra_stats {
+  int64_t frames_analysed;      /* analysis frames fired, all streams */
+  int64_t samples_rendered;     /* per stream */
+  int64_t dropped_note_on;      /* RtResynth::countDroppedNoteOns, lib.cpp:549-551, all streams */
+  int32_t error_flags;          /* bit0 pitch-list overflow, bit1 channel bookkeeping mismatch */
+  int32_t reserved;
+} ra_stats;
+
+/* A note for the main.resynth driver: DeducedNote<double> as used by include/resynth.hpp:58-61,84-96. */
+typedef struct ra_note {
+  int32_t start_frame, end_frame; /* in hop units, like the reference (multiplied by stride inside) */
+  double frequency;               /* Hz */
+  double amplitude_db;
+} ra_note;
+
+const char *ra_last_error(void);
+int ra_device_count(void);
+
+/* defaults of source/rt.resynth.lib.cpp:943-999 */
+int ra_default_config(ra_config *cfg);
+/* RtResynth::getEvenWindowSizeFrames (lib.cpp:484-487) and the stride lambda (lib.cpp:1577-1578) */
+int ra_even_window_size_frames(float window_size_seconds, int sample_rate);
+int ra_window_center_stride_frames(float stride_seconds, int sample_rate);
+
+/*
+ * Replaces constructing n_streams RtResynth objects in offline mode (RtResynth(RtResynthOfflineJob&),
+ * lib.cpp:1185-1196: restorePreset + init()).  device = HIP device ordinal.
+ */
+int ra_create(const ra_config *cfg, int32_t n_streams, int32_t device, ra_context **out);
+void ra_destroy(ra_context *ctx);
+/* back to the state right after ra_create (RtResynth::init after teardown, lib.cpp:1305-1307) */
+int ra_reset(ra_context *ctx);
+/* launch on this hipStream_t (NULL = the default stream).  Lets a host framework order us on its own stream. */
+int ra_set_hip_stream(ra_context *ctx, void *hip_stream);
+
+/*
+ * Replaces the body of the offline loop lib.cpp:1204-1234 for all streams at once: for every frame,
+ * input_f (voice sample -> analysis queue, :1208), analyze_until_input_starvation (:1211),
+ * output_f = SimpleAudioOutContext::step (:1215-1217, include/simple_audio_context.h:69-112), write_output (:1220).
+ *
+ * d_voice / d_carrier: DEVICE pointers, [n_streams][n_frames] float32 mono (either may be NULL = silence;
+ * RtResynthOfflineJob::read_voice / read_carrier, rt.resynth.lib.params.cpp:291-313).
+ * d_out: DEVICE pointer, [n_streams][n_frames][2] float32 interleaved (write_output, params.cpp:320-324).
+ * Consecutive calls continue the same streams (block-size independent results).  Asynchronous on the
+ * context's HIP stream; ra_synchronize waits and reports device-side errors.
+ */
+int ra_process_device(ra_context *ctx, const float *d_voice, const float *d_carrier, int64_t n_frames, float *d_out);
+/* same with HOST buffers (does H2D, process, D2H, synchronises) */
+int ra_process_host(ra_context *ctx, const float *h_voice, const float *h_carrier, int64_t n_frames, float *h_out);
+int ra_synchronize(ra_context *ctx);
+
+/*
+ * The reference's block-compute boundary: ComputeFunc = bool(double* buffer, int nFrames)
+ * (include/simple_audio_context.h:24-26), as registered by ImplCRTP::initialize (gen.crtp.h:258-264) and
+ * Vocoder::initialize (vocoder.cpp:760-815).  ra_feed pushes the n input frames those computes will consume
+ * (input_f, lib.cpp:1285-1291); ra_compute then ACCUMULATES (+=) nFrames (1..16) of stream `stream`
+ * into the caller's interleaved double buffer [nFrames][2], exactly like the two registered computes together.
+ * HOST pointers.  Returns 1 where the reference functor returns true, or a negative RA_E* code.
+ */
+int ra_feed(ra_context *ctx, int32_t stream, const float *h_voice, const float *h_carrier, int32_t n_frames);
+int ra_compute(ra_context *ctx, int32_t stream, double *h_buffer, int32_t n_frames);
+
+/* counters and device-side error flags (synchronises) */
+int ra_get_stats(ra_context *ctx, ra_stats *stats);
+/* events of the LAST ra_process_* call for one stream, in the order the reference would have run them; returns count or <0 */
+int64_t ra_get_events(ra_context *ctx, int32_t stream, ra_event *h_events, int64_t cap);
+/* autotuned pitch lists (the output of the stateless half of RtResynth::step, lib.cpp:1676-1708) of the LAST
+ * ra_process_* call for one stream: fire_sample[f], offsets[f..f+1] into pitch/volume; returns frame count or <0 */
+int64_t ra_get_frame_pitches(ra_context *ctx, int32_t stream, int64_t *h_fire_sample, int64_t *h_offsets, int64_t frame_cap,
+                             double *h_pitch, double *h_volume, int64_t item_cap);
+
+/*
+ * Replaces resynth<T>(notes, stride, sampling_rate, path) of include/resynth.hpp:4-100 minus the WAV writer:
+ * renders the mono double signal the reference would have written.  h_out may be NULL to query the length.
+ * Returns the number of frames (>= 0) or a negative RA_E* code.
+ */
+int64_t ra_resynth_notes(const ra_note *notes, int32_t n_notes, int32_t stride, int32_t sample_rate, int32_t device, double *h_out,
+                         int64_t cap);
+
+/* building blocks exposed for tests and for finer-grained integration (HOST pointers, one call = one launch) */
+/* findFrequenciesSqMag (periodicfft.cpp:304-311) on n_windows windows of `window_size` float samples -> [n_windows][L/2] */
+int ra_sqmag(const float *h_windows, int32_t n_windows, int32_t window_size, int32_t window_kind, int32_t device, double *h_sqmag,
+             int32_t *fft_length);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
