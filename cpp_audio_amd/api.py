@@ -62,6 +62,7 @@ EXPORTED_SYMBOLS = [
     "ra_last_error", "ra_device_count", "ra_default_config", "ra_even_window_size_frames", "ra_window_center_stride_frames",
     "ra_create", "ra_destroy", "ra_reset", "ra_set_hip_stream", "ra_process_device", "ra_process_host", "ra_synchronize",
     "ra_feed", "ra_compute", "ra_get_stats", "ra_get_events", "ra_get_frame_pitches", "ra_resynth_notes", "ra_sqmag",
+    "ra_set_profiling", "ra_get_kernel_ms",
 ]
 
 _lib = None
@@ -93,6 +94,8 @@ def lib():
         L.ra_resynth_notes.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]
         L.ra_resynth_notes.restype = C.c_int64
         L.ra_sqmag.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]
+        L.ra_set_profiling.argtypes = [C.c_void_p, C.c_int32]
+        L.ra_get_kernel_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
         L.ra_even_window_size_frames.argtypes = [C.c_float, C.c_int]
         L.ra_window_center_stride_frames.argtypes = [C.c_float, C.c_int]
         _lib = L
@@ -179,6 +182,16 @@ class Context:
         """Accumulates into buf ([n_frames, 2] float64), like the reference's ComputeFunc."""
         assert buf.dtype == np.float64 and buf.flags.c_contiguous
         return _check(lib().ra_compute(self._h, stream, _p(buf), n_frames))
+
+    def set_profiling(self, enable=True):
+        _check(lib().ra_set_profiling(self._h, 1 if enable else 0))
+
+    def kernel_ms(self):
+        """({'analysis','track','synth','history'} -> accumulated ms, number of calls)."""
+        ms = np.zeros(4, np.float64)
+        calls = C.c_int64(0)
+        _check(lib().ra_get_kernel_ms(self._h, _p(ms), C.byref(calls)))
+        return dict(zip(("analysis", "track", "synth", "history"), ms.tolist())), calls.value
 
     def stats(self):
         s = RaStats()

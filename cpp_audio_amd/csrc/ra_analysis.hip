@@ -122,7 +122,7 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   double2 *z = reinterpret_cast<double2 *>(ra_smem);           // [max(M,1)]
   double2 *listA = z + (M > 0 ? M : 1);                        // [2*maxr]
   double2 *listB = listA + 2 * p.maxr;                         // [2*maxr]
-  int *scan = reinterpret_cast<int *>(listB + 2 * p.maxr);     // [T+1]
+  int *scan = reinterpret_cast<int *>(listA);                   // [T+1], aliases listA: consumed (K read) before the lists are written
 
   // ---- 1. load the window (coalesced), weight it, scatter to bit-reversed slots -------------------
   {
@@ -318,7 +318,9 @@ __global__ void ra_roll_history_kernel(RaParams p, RaBuffers b, const float *__r
 
 size_t ra_analysis_lds_bytes(const RaParams &p) {
   size_t m = p.M > 0 ? p.M : 1;
-  return m * sizeof(double2) + 4 * (size_t)p.maxr * sizeof(double2) + (RA_ANALYSIS_THREADS + 1) * sizeof(int);
+  size_t lists = 4 * (size_t)p.maxr * sizeof(double2);
+  size_t scan = (RA_ANALYSIS_THREADS + 1) * sizeof(int);
+  return m * sizeof(double2) + (lists > scan ? lists : scan);
 }
 
 void ra_launch_analysis(const RaParams &p, const RaBuffers &b, const float *d_voice, int64_t t0, int64_t n, int64_t f_lo, int64_t n_frames_blk,

@@ -34,6 +34,12 @@ struct ra_context {
   int64_t st_cap = 0;
   std::vector<float> pending_voice, pending_carrier; // ra_feed -> ra_compute
   double *dbg_sqmag = nullptr;
+  // optional per-kernel timing with HIP events on the launch stream (ra_set_profiling)
+  bool profiling = false;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool ev_pending = false;
+  double kernel_ms[4] = {0, 0, 0, 0};
+  int64_t kernel_calls = 0;
 };
 
 namespace {
@@ -331,6 +337,19 @@ void frames_in_block(const RaParams &p, int64_t t0, int64_t n, int64_t &f_lo, in
   nfb = f_hi >= f_lo ? f_hi - f_lo + 1 : 0;
 }
 
+int resolve_timing(ra_context *c) {
+  if (!c->ev_pending) return RA_OK;
+  HIP_TRY(hipEventSynchronize(c->ev[4]));
+  for (int i = 0; i < 4; ++i) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+    c->kernel_ms[i] += ms;
+  }
+  ++c->kernel_calls;
+  c->ev_pending = false;
+  return RA_OK;
+}
+
 int process_block(ra_context *c, const float *d_voice, const float *d_carrier, int64_t n, float *d_out, double *d_out_d) {
   if (n <= 0) return RA_OK;
   HIP_TRY(hipSetDevice(c->device));
@@ -342,10 +361,16 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
   int r = ensure_scratch(c, nfb, n);
   if (r) return r;
   c->b.dbg_sqmag = c->dbg_sqmag;
+  const bool prof = c->profiling;
+  if (prof) { r = resolve_timing(c); if (r) return r; HIP_TRY(hipEventRecord(c->ev[0], c->stream)); }
   ra_launch_analysis(p, c->b, d_voice, c->t, n, f_lo, nfb, c->stream);
+  if (prof) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
   ra_launch_track(p, c->b, f_lo, nfb, c->stream);
+  if (prof) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
   ra_launch_synth(p, c->b, c->t, n, f_lo, nfb, d_out, d_out_d, c->stream);
+  if (prof) HIP_TRY(hipEventRecord(c->ev[3], c->stream));
   ra_launch_roll_history(p, c->b, d_voice, n, c->stream);
+  if (prof) { HIP_TRY(hipEventRecord(c->ev[4], c->stream)); c->ev_pending = true; }
   HIP_TRY(hipGetLastError());
   c->last_f_lo = f_lo; c->last_nfb = nfb; c->last_n = n; c->last_t0 = c->t;
   c->t += n;
@@ -448,6 +473,7 @@ void ra_destroy(ra_context *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (void *p : c->allocs) (void)hipFree(p);
+  for (int i = 0; i < 5; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   delete c;
 }
 
@@ -462,6 +488,28 @@ int ra_set_hip_stream(ra_context *c, void *hip_stream) {
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->stream = static_cast<hipStream_t>(hip_stream);
+  return RA_OK;
+}
+
+int ra_set_profiling(ra_context *c, int32_t enable) {
+  if (!c) return fail(RA_EINVAL, "null context");
+  HIP_TRY(hipSetDevice(c->device));
+  if (enable && !c->ev[0]) for (int i = 0; i < 5; ++i) HIP_TRY(hipEventCreate(&c->ev[i]));
+  int r = resolve_timing(c);
+  if (r) return r;
+  c->profiling = enable != 0;
+  for (int i = 0; i < 4; ++i) c->kernel_ms[i] = 0;
+  c->kernel_calls = 0;
+  return RA_OK;
+}
+
+int ra_get_kernel_ms(ra_context *c, double *ms4, int64_t *calls) {
+  if (!c || !ms4) return fail(RA_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(c->device));
+  int r = resolve_timing(c);
+  if (r) return r;
+  for (int i = 0; i < 4; ++i) ms4[i] = c->kernel_ms[i];
+  if (calls) *calls = c->kernel_calls;
   return RA_OK;
 }
 
@@ -620,6 +668,7 @@ int ra_sqmag(const float *h_windows, int32_t n_windows, int32_t window_size, int
   cfg.window_size = window_size;
   cfg.stride = window_size;
   cfg.window_kind = window_kind;
+  cfg.carrier_volume = 0.f; // analysis only
   ra_context *c = nullptr;
   int r = ra_create(&cfg, 1, device, &c);
   if (r) return r;

@@ -10,6 +10,14 @@ for p in (_HERE, _ROOT):
         sys.path.insert(0, p)
 
 
+# torch bundles its own HIP runtime under the same SONAME as /opt/rocm's: whichever loads first serves the whole
+# process.  Load torch's first so tests that use both torch tensors and libresynth_amd.so share one runtime.
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 

@@ -1,0 +1,276 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Bars (BASELINE.json north_star): discrete results (analysis frame schedule, events = type/channel/note id/float
+frequency/float velocity, dropped note-ons) identical; audio within 1e-5 RMS per sample per stream (in practice the
+fp64 path reproduces the oracle's float32 output bit for bit on most streams).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RMS_TOL = 1e-5  # BASELINE.json north_star: "within 1e-5 RMS per sample"
+
+
+@pytest.fixture(scope="module")
+def api():
+    from cpp_audio_amd import api
+    assert api.lib().ra_device_count() > 0, "no GPU visible: GPU tests cannot run (there is no CPU fallback)"
+    return api
+
+
+@pytest.fixture(scope="module")
+def sig():
+    from cpp_audio_amd import signals
+    return signals
+
+
+PARITY_KW = dict(analysis_volume=1.0, stereo_spread=0.0, carrier_volume=0.0, seed=1234)
+
+
+def both_configs(api, oracle, **kw):
+    k = dict(PARITY_KW)
+    k.update(kw)
+    gk = dict(k)
+    return api.default_config(**gk), k
+
+
+def rms(a, b):
+    return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
+
+
+def check_streams(api, oracle, x, carrier=None, expect_sound=True, **kw):
+    gcfg, k = both_configs(api, oracle, **kw)
+    S = x.shape[0]
+    with api.Context(gcfg, S, 0) as ctx:
+        out = ctx.process_host(x, carrier)
+        st = ctx.stats()
+        evs = [ctx.events(s) for s in range(S)]
+        fps = [ctx.frame_pitches(s) for s in range(S)]
+    assert st.error_flags == 0
+    dropped_total = 0
+    for s in range(S):
+        ocfg = oracle.default_config(**dict(k, seed=k["seed"] + s))
+        ref, ev, dropped = oracle.run_offline(ocfg, x[s], None if carrier is None else carrier[s])
+        dropped_total += dropped
+        fire, offs, pitch, vol = oracle.run_frames(ocfg, x[s])
+        gfire, goffs, gpitch, gvol = fps[s]
+        assert np.array_equal(fire, gfire), f"stream {s}: frame schedule"
+        assert np.array_equal(offs, goffs), f"stream {s}: pitch list sizes"
+        if len(pitch):
+            assert np.max(np.abs(pitch - gpitch)) < 1e-9 and np.max(np.abs(vol - gvol) / vol) < 1e-9
+        ev = ev[ev["type"] != 3]
+        gev = evs[s]
+        assert len(ev) == len(gev), f"stream {s}: {len(ev)} vs {len(gev)} events"
+        for f in ("sample", "type", "channel", "noteid", "frequency", "velocity"):
+            assert np.array_equal(ev[f], gev[f]), f"stream {s}: event field {f}"
+        if expect_sound:
+            assert np.sqrt(np.mean(ref.astype(np.float64) ** 2)) > 1e-4, "oracle output is silent: the test would be vacuous"
+        e = rms(out[s], ref)
+        assert e <= RMS_TOL, f"stream {s}: rms {e}"
+    assert st.dropped_note_on == dropped_total
+    return out
+
+
+@pytest.mark.parametrize("N,kind", [(2, 0), (16, 0), (800, 0), (1024, 0), (4096, 0), (4096, 1), (4096, 2), (4800, 0), (8192, 0), (16000, 0)])
+def test_sqmag_matches_oracle(api, oracle, N, kind):
+    rng = np.random.default_rng(N + kind)
+    w = rng.standard_normal((3, N)).astype(np.float32)
+    w[2] = 0.0  # a silent window
+    g, L = api.sqmag(w, kind)
+    for i in range(3):
+        r, L2 = oracle.sqmag(w[i].astype(np.float64), kind)
+        assert L == L2
+        scale = max(np.max(r), 1e-300)
+        assert np.max(np.abs(g[i] - r)) <= 1e-13 * scale
+    assert np.all(g[2] == 0)
+
+
+def test_c2_small_partials(api, oracle, sig):
+    # configs[1] shape at a size the oracle finishes in seconds: 6 streams x 2 s, N=4096, H=1024, P=64
+    x = sig.make_streams(6, 96000)
+    check_streams(api, oracle, x)
+
+
+def test_speech_like(api, oracle, sig):
+    x = sig.make_streams(3, 72000, kind="speech")
+    check_streams(api, oracle, x)
+
+
+def test_c1_driver_shape(api, oracle, sig):
+    # configs[0] shape: 44.1 kHz, window 800 -> FFT 1024, stride 400, 16 partials (nVoices = 8, gen.crtp.h:192)
+    x = sig.make_streams(2, 44100, sr=44100)
+    check_streams(api, oracle, x, sample_rate=44100, window_size=800, stride=400, n_channels=16)
+
+
+def test_c4_shape_autotune_128_partials(api, oracle, sig):
+    # configs[3] shape: N=8192, H=2048, P=128, autotune MusicalScale / Major / root C, tolerance 100
+    x = sig.make_streams(2, 96000, base_seed=77)
+    check_streams(api, oracle, x, window_size=8192, stride=2048, n_channels=128, use_autotune=1, autotune_type=0,
+                  autotune_scale_mode=0, autotune_root_note=0)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(use_autotune=1, autotune_type=1, autotune_chord_frequencies=1),       # chord, harmonics
+    dict(use_autotune=1, autotune_type=1, autotune_chord_frequencies=2),       # chord on every octave
+    dict(use_autotune=1, autotune_type=1, autotune_chord_frequencies=0),       # single
+    dict(use_autotune=1, autotune_type=2, autotune_factor=3),                   # fixed-size intervals
+    dict(use_autotune=1, autotune_type=0, autotune_scale_mode=2, autotune_root_note=7, autotune_root_transpose=-3,
+         autotune_tolerance_pitches=0.4),                                       # minor harmonic, tolerance rejects
+    dict(pitch_shift_pre_autotune=2.0, pitch_shift_post_autotune=-7.0),
+    dict(pitch_harmonize_pre_autotune=7.0),
+    dict(pitch_harmonize_pre_autotune=12.0, pitch_harmonize_post_autotune=4.0, use_autotune=1),
+    dict(env_attack_seconds=0.02, env_hold_seconds=0.01, env_decay_seconds=0.05, env_release_seconds=0.1, env_sustain_level=0.6),
+    dict(stereo_spread=1.0),
+    dict(phase_policy=1),
+    dict(analysis_input_gain=0.5, analysis_volume=2.0),
+    dict(min_volume=0.01, nearby_distance_tones=1.5, max_track_pitches=0.3),
+    dict(window_kind=1), dict(window_kind=2),
+])
+def test_parameter_variants(api, oracle, sig, kw):
+    x = sig.make_streams(2, 48000, base_seed=5)
+    check_streams(api, oracle, x, **kw)
+
+
+def test_channel_starvation_drops_note_ons(api, oracle, sig):
+    # P = 4: most note-ons find no free channel (synthesize_sounds, lib.cpp:368-374)
+    x = sig.make_streams(2, 48000)
+    check_streams(api, oracle, x, n_channels=4)
+
+
+def test_low_frequency_long_releases(api, oracle):
+    # 30-60 Hz partials: release = 2.5 periods > stride, channels stay busy for several frames (audioelement.h:216-223)
+    sr, n = 48000, 96000
+    t = np.arange(n) / sr
+    x = np.zeros((2, n), np.float32)
+    x[0] = (0.3 * np.sin(2 * np.pi * 31.0 * t) * (t < 0.9) + 0.2 * np.sin(2 * np.pi * 57.3 * t) * ((t > 0.3) & (t < 1.4))).astype(np.float32)
+    x[1] = (0.3 * np.sin(2 * np.pi * (40 + 15 * t) * t)).astype(np.float32)
+    check_streams(api, oracle, x, n_channels=8)
+
+
+def test_stride_larger_than_window_and_tiny_stride(api, oracle, sig):
+    x = sig.make_streams(1, 30000)
+    check_streams(api, oracle, x, window_size=1024, stride=2500)   # H > N: PeriodicFFT skips H - N samples (periodicfft.cpp:173-175)
+    check_streams(api, oracle, x[:, :6000], window_size=512, stride=7, n_channels=16)
+
+
+def test_silence_and_empty_and_short(api, oracle):
+    cfg = api.default_config(**PARITY_KW)
+    with api.Context(cfg, 3, 0) as ctx:
+        out = ctx.process_host(np.zeros((3, 20000), np.float32))
+        assert np.all(out == 0)
+        assert len(ctx.events(0)) == 0
+        assert ctx.process_host(np.zeros((3, 0), np.float32)).shape == (3, 0, 2)   # empty block
+    # shorter than one window: no analysis frame ever fires
+    x = np.random.default_rng(1).standard_normal((2, 3000)).astype(np.float32) * 0.1
+    check_streams(api, oracle, x, expect_sound=False)
+
+
+def test_white_noise_many_peaks(api, oracle):
+    # ~L/4 local maxima per frame: exercises list capacities
+    x = (np.random.default_rng(3).standard_normal((2, 24000)) * 0.2).astype(np.float32)
+    check_streams(api, oracle, x, n_channels=64)
+    with api.Context(api.default_config(max_pitches_per_frame=8, **PARITY_KW), 2, 0) as ctx:
+        with pytest.raises(api.RaError) as e:
+            ctx.process_host(x)
+        assert e.value.code == -4    # RA_EOVERFLOW instead of silent truncation
+
+
+def test_block_size_invariance_and_reset(api, sig):
+    # consecutive ra_process calls continue the streams: any split of the input gives the same bits
+    x = sig.make_streams(3, 50000)
+    cfg = api.default_config(**PARITY_KW)
+    with api.Context(cfg, 3, 0) as ctx:
+        whole = ctx.process_host(x)
+        ctx.reset()
+        cuts = [0, 1, 17, 4097, 4098, 5000, 5001, 9000, 21111, 21127, 50000]
+        parts = [ctx.process_host(x[:, a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        assert np.array_equal(np.concatenate(parts, axis=1), whole)
+        ctx.reset()
+        assert np.array_equal(ctx.process_host(x), whole)
+
+
+def test_streams_are_independent(api, sig):
+    # a stream's output does not depend on what else is in the batch -> sharding is exact
+    x = sig.make_streams(5, 40000)
+    cfg = api.default_config(**PARITY_KW)
+    with api.Context(cfg, 5, 0) as ctx:
+        full = ctx.process_host(x)
+    from cpp_audio_amd import sharding
+    for world in (2, 3):
+        outs = []
+        for r in range(world):
+            lo, hi = sharding.shard_streams(5, world, r)
+            if hi > lo:
+                with api.Context(sharding.shard_config(cfg, lo), hi - lo, 0) as c2:
+                    outs.append(c2.process_host(x[lo:hi]))
+        assert np.array_equal(np.concatenate(outs, axis=0), full)
+
+
+def test_compute_func_boundary_accumulates(api, oracle, sig):
+    # ra_feed + ra_compute = the reference's ComputeFunc contract: += into a caller-owned interleaved double buffer, 1..16 frames
+    x = sig.make_streams(1, 12000)
+    cfg = api.default_config(**PARITY_KW)
+    ref, _, _ = oracle.run_offline(oracle.default_config(**PARITY_KW), x[0])
+    with api.Context(cfg, 1, 0) as ctx:
+        got = np.zeros((12000, 2), np.float64)
+        pos = 0
+        rng = np.random.default_rng(0)
+        while pos < 12000:
+            m = int(min(12000 - pos, rng.integers(1, 17)))
+            ctx.feed(x[0, pos:pos + m])
+            buf = np.full((m, 2), 0.25, np.float64)   # pre-existing content must be preserved (+=)
+            assert ctx.compute(buf, m) == 1
+            got[pos:pos + m] = buf - 0.25
+            pos += m
+        assert rms(got.astype(np.float32), ref) <= RMS_TOL
+        with pytest.raises(api.RaError):
+            ctx.compute(np.zeros((17, 2)), 17)        # max_n_frames_per_loop = 16
+    with api.Context(cfg, 2, 0) as ctx2:
+        with pytest.raises(api.RaError):
+            ctx2.feed(x[0, :4])
+
+
+def test_argument_validation(api):
+    for kw in (dict(window_size=4095), dict(window_size=0), dict(stride=0), dict(n_channels=0), dict(n_channels=1000),
+               dict(window_size=65536), dict(min_volume=-1.0), dict(vocoder_count_bands=51)):
+        with pytest.raises(api.RaError) as e:
+            api.Context(api.default_config(**kw), 1, 0)
+        assert e.value.code == -1
+    with pytest.raises(api.RaError):
+        api.Context(api.default_config(), 0, 0)
+    with pytest.raises(api.RaError):
+        api.Context(api.default_config(), 1, 99)
+
+
+def test_full_size_properties(api, oracle, sig):
+    # BASELINE configs[1] at full size: 256 streams x 10 s.  The oracle checks a sample of streams end to end;
+    # size-independent properties cover the rest: determinism, stream independence, block-size invariance.
+    import torch
+    import bench
+    S, n = 256, 480000
+    dev = torch.device("cuda", 0)
+    voice = bench.synth_inputs_torch(S, n, 48000, 1234, dev)
+    out = torch.empty(S, n, 2, dtype=torch.float32, device=dev)
+    cfg = api.default_config(**PARITY_KW)
+    with api.Context(cfg, S, 0) as ctx:
+        ctx.set_hip_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.process_device(voice.data_ptr(), 0, n, out.data_ptr())
+        ctx.synchronize()
+        first = out.clone()
+        ctx.reset()
+        half = n // 2 + 123
+        o1 = torch.empty(S, half, 2, dtype=torch.float32, device=dev)
+        o2 = torch.empty(S, n - half, 2, dtype=torch.float32, device=dev)
+        v1 = voice[:, :half].contiguous()
+        v2 = voice[:, half:].contiguous()
+        ctx.process_device(v1.data_ptr(), 0, half, o1.data_ptr())
+        ctx.process_device(v2.data_ptr(), 0, n - half, o2.data_ptr())
+        ctx.synchronize()
+        assert ctx.stats().error_flags == 0
+    assert torch.equal(torch.cat([o1, o2], dim=1), first)
+    assert float(first.abs().max()) < 4.0 and float(first.double().pow(2).mean().sqrt()) > 1e-3
+    hv = voice.cpu().numpy()
+    for s in (0, 101, 255):
+        ref, _, _ = oracle.run_offline(oracle.default_config(**dict(PARITY_KW, seed=1234 + s)), hv[s])
+        assert rms(first[s].cpu().numpy(), ref) <= RMS_TOL
