@@ -187,11 +187,11 @@ class Context:
         _check(lib().ra_set_profiling(self._h, 1 if enable else 0))
 
     def kernel_ms(self):
-        """({'analysis','track','synth','history'} -> accumulated ms, number of calls)."""
-        ms = np.zeros(4, np.float64)
+        """({'analysis','track','vocoder','synth','history'} -> accumulated ms, number of calls)."""
+        ms = np.zeros(5, np.float64)
         calls = C.c_int64(0)
         _check(lib().ra_get_kernel_ms(self._h, _p(ms), C.byref(calls)))
-        return dict(zip(("analysis", "track", "synth", "history"), ms.tolist())), calls.value
+        return dict(zip(("analysis", "track", "vocoder", "synth", "history"), ms.tolist())), calls.value
 
     def stats(self):
         s = RaStats()

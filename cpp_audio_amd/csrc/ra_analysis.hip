@@ -9,7 +9,7 @@
 // The window never leaves the chip: N contiguous floats are read once (coalesced), the real FFT runs
 // as an M = L/2 point complex FFT in LDS (fp64, like the reference), |X|^2 overwrites the same LDS slots,
 // peaks are compacted in bin order and only the short autotuned pitch list goes back to HBM.
-#include "ra_internal.h"
+#include "ra_fft.cuh"
 
 extern __shared__ __align__(16) unsigned char ra_smem[];
 
@@ -148,34 +148,16 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   __syncthreads();
 
   // ---- 2. in-place radix-2 DIT, M points ----------------------------------------------------------
-  for (int len = 2; len <= M; len <<= 1) {
-    const int half = len >> 1, step = M / len;
-    for (int bf = tid; bf < (M >> 1); bf += T) {
-      int grp = bf / half, j = bf - grp * half;
-      int i0 = grp * len + j;
-      double2 w = b.tw_half[j * step];
-      double2 u = z[i0], x = z[i0 + half];
-      double vr = x.x * w.x - x.y * w.y;
-      double vi = x.x * w.y + x.y * w.x;
-      z[i0] = make_double2(u.x + vr, u.y + vi);
-      z[i0 + half] = make_double2(u.x - vr, u.y - vi);
-    }
-    __syncthreads();
-  }
+  ra_fft_dit(z, M, b.tw_half, tid, T, false);
 
   // ---- 3. split into the real spectrum, |X|^2 written over .x of the same slots -------------------
   // X[k] = E[k] + W^k O[k],  E = (Z[k] + conj Z[M-k]) / 2,  O = -i/2 (Z[k] - conj Z[M-k]);  bins 0..M-1 kept
   for (int k = tid; k <= (M >> 1); k += T) {
     int km = (M - k) % M; // partner (k = 0 pairs with itself, k = M/2 too)
     double2 zk = z[k], zm = z[km];
-    auto bin = [&](double2 a, double2 c, int kk) -> double { // a = Z[kk], c = Z[M-kk] (conjugated here)
-      double er = 0.5 * (a.x + c.x), ei = 0.5 * (a.y - c.y);
-      double dr = a.x - c.x, di = a.y + c.y;
-      double o_r = 0.5 * di, o_i = -0.5 * dr;
-      double2 w = b.tw_full[kk];
-      double xr = er + (w.x * o_r - w.y * o_i);
-      double xi = ei + (w.x * o_i + w.y * o_r);
-      return xr * xr + xi * xi;
+    auto bin = [&](double2 a, double2 c, int kk) -> double { // a = Z[kk], c = Z[M-kk] (conjugated inside)
+      double2 x = ra_real_split_bin(a, c, b.tw_full[kk]);
+      return x.x * x.x + x.y * x.y;
     };
     double sk = bin(zk, zm, k);
     double sm = (km != k) ? bin(zm, zk, km) : 0.0;

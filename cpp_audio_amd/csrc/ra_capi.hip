@@ -36,9 +36,9 @@ struct ra_context {
   double *dbg_sqmag = nullptr;
   // optional per-kernel timing with HIP events on the launch stream (ra_set_profiling)
   bool profiling = false;
-  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool ev_pending = false;
-  double kernel_ms[4] = {0, 0, 0, 0};
+  double kernel_ms[5] = {0, 0, 0, 0, 0}; // analysis, track, vocoder, synth, history
   int64_t kernel_calls = 0;
 };
 
@@ -154,6 +154,105 @@ int validate(const ra_config &c, int32_t n_streams) {
   return RA_OK;
 }
 
+// twiddle / bit-reversal tables of a real FFT of length L done as an M = L/2 point complex FFT
+int upload_fft_tables(ra_context *c, int L, double2 **tw_half, double2 **tw_full, int **bitrev) {
+  int M = L / 2, log2M = 0, r;
+  while ((1 << log2M) < M) ++log2M;
+  std::vector<double2> tw(std::max(M / 2, 1));
+  for (int k = 0; k < M / 2; ++k) { double a = -2.0 * M_PI * k / M; tw[k] = make_double2(std::cos(a), std::sin(a)); }
+  if ((r = upload(c, tw_half, tw))) return r;
+  std::vector<double2> tf(M + 1);
+  for (int k = 0; k <= M; ++k) { double a = -2.0 * M_PI * k / L; tf[k] = make_double2(std::cos(a), std::sin(a)); }
+  if ((r = upload(c, tw_full, tf))) return r;
+  std::vector<int> rev(std::max(M, 1), 0);
+  for (int i = 0; i < M; ++i) {
+    int x = 0;
+    for (int bit = 0; bit < log2M; ++bit) if (i & (1 << bit)) x |= 1 << (log2M - 1 - bit);
+    rev[i] = x;
+  }
+  return upload(c, bitrev, rev);
+}
+
+std::vector<double> make_half_window(int kind, int n) {
+  std::vector<double> hw(n);
+  double sigma = n / 4.0, sum = 0;
+  for (int j = 0; j < n; ++j) {
+    double d = j + 0.5;
+    hw[j] = kind == RA_WINDOW_GAUSSIAN4 ? std::exp(-(d * d) / (2.0 * sigma * sigma)) : kind == RA_WINDOW_HANN ? 0.5 * (1.0 + std::cos(M_PI * d / n)) : 1.0;
+    sum += hw[j];
+  }
+  for (auto &v : hw) v /= sum;
+  return hw;
+}
+
+// band of every bin: the single pass of FFTModulator's on_fft_result (vocoder.cpp:137-160); -1 = no band
+std::vector<int> band_of_bins(const std::vector<double> &freqs, int n_bins, double bin_to_Hz) {
+  std::vector<int> band(n_bins, -1);
+  size_t lo = 0, hi = 1, end = freqs.size();
+  int bi = 0;
+  for (int i = 0; i < n_bins; ++i) {
+    double const Hz = bin_to_Hz * i;
+    if (Hz <= freqs[lo]) continue;
+    while (Hz > freqs[hi]) { ++bi; ++hi; ++lo; if (hi == end) break; }
+    if (hi == end) break;
+    band[i] = bi;
+  }
+  return band;
+}
+
+int build_vocoder_tables(ra_context *c) {
+  const ra_config &cfg = c->cfg;
+  RaParams &p = c->p;
+  RaBuffers &b = c->b;
+  int r;
+  // good_stride (vocoder.cpp:84-92) and the modulator window lambda (:107-119)
+  int S = std::max(1, static_cast<int>(0.5f + cfg.vocoder_stride_seconds * cfg.sample_rate));
+  if (0 == S % 2) ++S;
+  int Wm = std::max(1, static_cast<int>(0.5f + cfg.sample_rate * static_cast<double>(cfg.vocoder_modulator_window_size_seconds)));
+  if (1 == Wm % 2) ++Wm;
+  Wm = std::min(1 << 16, Wm);
+  p.voc_S = S;
+  p.voc_Wm = Wm;
+  p.voc_Lm = fft_length_for(Wm);
+  p.voc_Mm = p.voc_Lm / 2;
+  p.voc_Lc = fft_length_for(2 * S);
+  p.voc_Mc = p.voc_Lc / 2;
+  p.voc_bands = cfg.vocoder_count_bands;
+  if (p.voc_Lm > RA_MAX_FFT) return fail(RA_EINVAL, "vocoder modulator window is too large (FFT length > 16384)");
+  if (p.voc_Lc > 4096) return fail(RA_EINVAL, "vocoder stride is too large (carrier FFT length > 4096)");
+  if (!(cfg.vocoder_min_freq > 0.f) || !(cfg.vocoder_max_freq > cfg.vocoder_min_freq)) return fail(RA_EINVAL, "vocoder band limits must satisfy 0 < min < max");
+  // SetupParams::fill_freqs, vocoder.cpp:15-27 (float logs, double exp)
+  std::vector<double> freqs;
+  {
+    auto log_min = std::log(cfg.vocoder_min_freq);
+    auto log_max = std::log(cfg.vocoder_max_freq);
+    for (int i = 0; i <= p.voc_bands; ++i) {
+      double const ratio = static_cast<double>(i) / p.voc_bands;
+      freqs.push_back(std::exp(log_min + ratio * (log_max - log_min)));
+    }
+  }
+  if ((r = upload(c, &b.voc_half_window, make_half_window(RA_WINDOW_GAUSSIAN4, Wm / 2)))) return r;
+  if ((r = upload_fft_tables(c, p.voc_Lm, &b.vm_tw_half, &b.vm_tw_full, &b.vm_bitrev))) return r;
+  if ((r = upload_fft_tables(c, p.voc_Lc, &b.vc_tw_half, &b.vc_tw_full, &b.vc_bitrev))) return r;
+  { // modulator: bins 0..Lm/2-1, bands are contiguous runs of bins
+    std::vector<int> band = band_of_bins(freqs, p.voc_Mm, static_cast<double>(cfg.sample_rate) / p.voc_Lm);
+    std::vector<int> range(2 * p.voc_bands, 0); // [first bin, one past last bin) per band; empty band = [0, 0)
+    for (int bi = 0; bi < p.voc_bands; ++bi) {
+      int s0 = -1, cnt = 0;
+      for (int i = 0; i < p.voc_Mm; ++i) if (band[i] == bi) { if (s0 < 0) s0 = i; ++cnt; }
+      if (s0 >= 0) { range[2 * bi] = s0; range[2 * bi + 1] = s0 + cnt; }
+    }
+    if ((r = upload(c, &b.voc_mod_band_start, range))) return r;
+  }
+  if ((r = upload(c, &b.voc_car_band, band_of_bins(freqs, p.voc_Mc + 1, static_cast<double>(cfg.sample_rate) / p.voc_Lc)))) return r;
+  { // EqualGainXFade::set(S-1, Sinusoidal).get(idx+1) — decision of DESIGN.md §5: new = (1 - cos(pi i / (len+1))) / 2
+    std::vector<double> xf(S);
+    for (int idx = 0; idx < S; ++idx) xf[idx] = 0.5 * (1.0 - std::cos(M_PI * (idx + 1) / ((S - 1) + 1.0)));
+    if ((r = upload(c, &b.voc_xf_new, xf))) return r;
+  }
+  return RA_OK;
+}
+
 int build_tables(ra_context *c) {
   const ra_config &cfg = c->cfg;
   RaParams &p = c->p;
@@ -244,6 +343,7 @@ int build_tables(ra_context *c) {
     p.n_allowed = static_cast<int>(allowed.size());
     if ((r = upload(c, &b.allowed, allowed))) return r;
   }
+  if (p.voc_enabled && (r = build_vocoder_tables(c))) return r;
   return RA_OK;
 }
 
@@ -261,6 +361,12 @@ int alloc_state(ra_context *c) {
   if ((r = dev_alloc(c, &b.sd, S * SD_COUNT * p.Ppad))) return r;
   if ((r = dev_alloc(c, &b.si, S * SI_COUNT * p.Ppad))) return r;
   if ((r = dev_alloc(c, &b.error_flags, 1))) return r;
+  if (p.voc_enabled) {
+    if ((r = dev_alloc(c, &b.voc_mod_hist, S * p.voc_Wm))) return r;
+    if ((r = dev_alloc(c, &b.voc_car_hist, S * 2 * p.voc_S))) return r;
+    if ((r = dev_alloc(c, &b.voc_amp_prev, S * p.voc_bands))) return r;
+    if ((r = dev_alloc(c, &b.voc_sig_prev, S * 4 * p.voc_S))) return r;
+  }
   return RA_OK;
 }
 
@@ -276,6 +382,12 @@ int init_state(ra_context *c) {
   HIP_TRY(hipMemsetAsync(b.chan_held, 0, S * p.P * sizeof(int32_t), c->stream));
   HIP_TRY(hipMemsetAsync(b.chan_minch, 0, S * p.P * sizeof(int32_t), c->stream));
   HIP_TRY(hipMemsetAsync(b.error_flags, 0, sizeof(int32_t), c->stream));
+  if (p.voc_enabled) {
+    HIP_TRY(hipMemsetAsync(b.voc_mod_hist, 0, S * p.voc_Wm * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(b.voc_car_hist, 0, S * 2 * p.voc_S * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(b.voc_amp_prev, 0, S * p.voc_bands * sizeof(double), c->stream));
+    HIP_TRY(hipMemsetAsync(b.voc_sig_prev, 0, S * 4 * p.voc_S * sizeof(double), c->stream));
+  }
   std::vector<double> sd(S * SD_COUNT * p.Ppad, 0.0);
   std::vector<int32_t> si(S * SI_COUNT * p.Ppad, 0);
   for (size_t s = 0; s < S; ++s) {
@@ -317,11 +429,27 @@ int ensure_scratch(ra_context *c, int64_t nfb, int64_t n) {
     if ((r = dev_alloc(c, &b.pl_count, S * F))) return r;
     if ((r = dev_alloc(c, &b.cmd, S * F * p.Ppad, false))) return r;
   }
-  if (p.voc_enabled && n > b.mix_cap) {
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    dev_free(c, b.voc_mix);
-    b.mix_cap = n;
-    if ((r = dev_alloc(c, &b.voc_mix, static_cast<size_t>(p.n_streams) * n, false))) return r;
+  if (p.voc_enabled) {
+    size_t S = p.n_streams;
+    if (n > b.mix_cap) {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      dev_free(c, b.voc_mix);
+      b.mix_cap = n;
+      if ((r = dev_alloc(c, &b.voc_mix, S * n, false))) return r;
+    }
+    RaFrameRange mod = ra_frames_firing(p.voc_Wm, p.voc_S, c->t, n), car = ra_frames_firing(2 * p.voc_S, p.voc_S, c->t, n);
+    if (mod.count > b.voc_mod_cap) {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      dev_free(c, b.voc_amp);
+      b.voc_mod_cap = mod.count;
+      if ((r = dev_alloc(c, &b.voc_amp, S * mod.count * p.voc_bands, false))) return r;
+    }
+    if (car.count > b.voc_car_cap) {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      dev_free(c, b.voc_sig);
+      b.voc_car_cap = car.count;
+      if ((r = dev_alloc(c, &b.voc_sig, S * car.count * 2 * p.voc_S, false))) return r;
+    }
   }
   return RA_OK;
 }
@@ -339,8 +467,8 @@ void frames_in_block(const RaParams &p, int64_t t0, int64_t n, int64_t &f_lo, in
 
 int resolve_timing(ra_context *c) {
   if (!c->ev_pending) return RA_OK;
-  HIP_TRY(hipEventSynchronize(c->ev[4]));
-  for (int i = 0; i < 4; ++i) {
+  HIP_TRY(hipEventSynchronize(c->ev[5]));
+  for (int i = 0; i < 5; ++i) {
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
     c->kernel_ms[i] += ms;
@@ -354,8 +482,6 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
   if (n <= 0) return RA_OK;
   HIP_TRY(hipSetDevice(c->device));
   RaParams &p = c->p;
-  if (p.voc_enabled) return fail(RA_EINVAL, "vocoder volumes are non-zero: vocoder path not available in this build");
-  (void)d_carrier;
   int64_t f_lo, nfb;
   frames_in_block(p, c->t, n, f_lo, nfb);
   int r = ensure_scratch(c, nfb, n);
@@ -367,10 +493,12 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
   if (prof) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
   ra_launch_track(p, c->b, f_lo, nfb, c->stream);
   if (prof) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-  ra_launch_synth(p, c->b, c->t, n, f_lo, nfb, d_out, d_out_d, c->stream);
+  if (p.voc_enabled) ra_launch_vocoder(p, c->b, d_voice, d_carrier, c->t, n, c->stream);
   if (prof) HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+  ra_launch_synth(p, c->b, c->t, n, f_lo, nfb, d_out, d_out_d, c->stream);
+  if (prof) HIP_TRY(hipEventRecord(c->ev[4], c->stream));
   ra_launch_roll_history(p, c->b, d_voice, n, c->stream);
-  if (prof) { HIP_TRY(hipEventRecord(c->ev[4], c->stream)); c->ev_pending = true; }
+  if (prof) { HIP_TRY(hipEventRecord(c->ev[5], c->stream)); c->ev_pending = true; }
   HIP_TRY(hipGetLastError());
   c->last_f_lo = f_lo; c->last_nfb = nfb; c->last_n = n; c->last_t0 = c->t;
   c->t += n;
@@ -473,7 +601,7 @@ void ra_destroy(ra_context *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (void *p : c->allocs) (void)hipFree(p);
-  for (int i = 0; i < 5; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  for (int i = 0; i < 6; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   delete c;
 }
 
@@ -494,21 +622,21 @@ int ra_set_hip_stream(ra_context *c, void *hip_stream) {
 int ra_set_profiling(ra_context *c, int32_t enable) {
   if (!c) return fail(RA_EINVAL, "null context");
   HIP_TRY(hipSetDevice(c->device));
-  if (enable && !c->ev[0]) for (int i = 0; i < 5; ++i) HIP_TRY(hipEventCreate(&c->ev[i]));
+  if (enable && !c->ev[0]) for (int i = 0; i < 6; ++i) HIP_TRY(hipEventCreate(&c->ev[i]));
   int r = resolve_timing(c);
   if (r) return r;
   c->profiling = enable != 0;
-  for (int i = 0; i < 4; ++i) c->kernel_ms[i] = 0;
+  for (int i = 0; i < 5; ++i) c->kernel_ms[i] = 0;
   c->kernel_calls = 0;
   return RA_OK;
 }
 
-int ra_get_kernel_ms(ra_context *c, double *ms4, int64_t *calls) {
-  if (!c || !ms4) return fail(RA_EINVAL, "null argument");
+int ra_get_kernel_ms(ra_context *c, double *ms5, int64_t *calls) {
+  if (!c || !ms5) return fail(RA_EINVAL, "null argument");
   HIP_TRY(hipSetDevice(c->device));
   int r = resolve_timing(c);
   if (r) return r;
-  for (int i = 0; i < 4; ++i) ms4[i] = c->kernel_ms[i];
+  for (int i = 0; i < 5; ++i) ms5[i] = c->kernel_ms[i];
   if (calls) *calls = c->kernel_calls;
   return RA_OK;
 }

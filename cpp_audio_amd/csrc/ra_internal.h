@@ -32,7 +32,7 @@ struct RaParams {
   uint64_t seed;
   double half_tone_ratio;
   // vocoder
-  int voc_enabled, voc_S, voc_Wm, voc_Lm, voc_Lc, voc_bands;
+  int voc_enabled, voc_S, voc_Wm, voc_Lm, voc_Mm, voc_Lc, voc_Mc, voc_bands;
   float vol_mod, vol_car, vol_voc;
 };
 
@@ -105,7 +105,35 @@ struct RaBuffers {
   double *voc_mix;          // [n_streams][n] when the vocoder is enabled
   int64_t mix_cap;
   double *dbg_sqmag;        // optional [frames][M] tap of |X|^2 (ra_sqmag), normally null
+  // ---- vocoder (only allocated when a vocoder volume is non-zero) ----
+  double *voc_half_window;  // [Wm/2] Gaussian 4 sigma
+  double2 *vm_tw_half, *vm_tw_full; int *vm_bitrev;   // modulator FFT, length Lm
+  double2 *vc_tw_half, *vc_tw_full; int *vc_bitrev;   // carrier FFT, length Lc
+  int *voc_mod_band_start;  // [2*bands] modulator bins of band b are [v[2b], v[2b+1])
+  int *voc_car_band;        // [Lc/2+1] band of each carrier bin, -1 = outside every band
+  double *voc_xf_new;       // [S] EqualGainXFade new-signal gain for new_signal_idx = 0..S-1
+  float *voc_mod_hist;      // [n_streams][Wm] last Wm voice samples
+  float *voc_car_hist;      // [n_streams][2S] last 2S carrier samples
+  double *voc_amp_prev;     // [n_streams][bands] band amplitudes of the last modulator frame before this block
+  double *voc_sig_prev;     // [n_streams][2][2S] the two carrier frames before this block (older first)
+  double *voc_amp;          // [n_streams][voc_mod_cap][bands]
+  double *voc_sig;          // [n_streams][voc_car_cap][2S]
+  int64_t voc_mod_cap, voc_car_cap;
 };
+
+// frames of the block [t0, t0+n) for a PeriodicFFT fed from sample 0 with window W and stride S: fire = W - 1 + j S
+struct RaFrameRange { int64_t lo, count; };
+__host__ __device__ inline RaFrameRange ra_frames_firing(int64_t W, int64_t S, int64_t t0, int64_t n) {
+  RaFrameRange r;
+  int64_t a = t0 - (W - 1);
+  r.lo = a <= 0 ? 0 : (a + S - 1) / S;
+  int64_t bnd = t0 + n - 1 - (W - 1);
+  if (bnd < 0) { r.count = 0; return r; }
+  int64_t hi = bnd / S;
+  r.count = hi >= r.lo ? hi - r.lo + 1 : 0;
+  return r;
+}
+void ra_launch_vocoder(const RaParams &p, const RaBuffers &b, const float *d_voice, const float *d_carrier, int64_t t0, int64_t n, hipStream_t st);
 
 // launchers (defined next to their kernels)
 void ra_launch_analysis(const RaParams &p, const RaBuffers &b, const float *d_voice, int64_t t0, int64_t n, int64_t f_lo, int64_t n_frames_blk,

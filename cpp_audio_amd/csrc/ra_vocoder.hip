@@ -1,0 +1,229 @@
+// K4 — FFT band vocoder (reference source/rt.resynth.lib.vocoder.cpp, the live FFTModulator / FFTCarrier pair).
+//
+//  K4a modulator : one workgroup per (stream, modulator frame): Gaussian-windowed |X|^2 of the voice (PeriodicFFT<SqMag>,
+//                  vocoder.cpp:106-163) -> band amplitudes sqrt(sum |X|^2 over the band's bins).
+//  K4b carrier   : one workgroup per (stream, carrier frame): rectangular 2S window of the carrier, real FFT, every bin scaled
+//                  by its band's amplitude (RealFBins_::modulate_bands, vocoder.cpp:453-456), inverse FFT, 1/L (vocoder.cpp:420-475).
+//  K4c mix       : per output frame the 50 % overlap cross-fade of the two latest carrier frames (FFTCarrier::feed, :501-530)
+//                  and the mix vol.mod*m + vol.car*c + vol.voc*y (Vocoder compute lambda, :799-808) into a double buffer that
+//                  K3 adds after the synth channels (compute registration order lib.cpp:1353,1377).
+//  K4d roll      : carries the last frames / samples over to the next block.
+//
+// Frames are independent given "the latest modulator frame fired at or before this carrier frame", so all of a block's
+// frames run concurrently; the sequential per-sample loop of the reference is only an ordering, not a data dependence.
+#include "ra_fft.cuh"
+
+extern __shared__ __align__(16) unsigned char ra_smem_voc[];
+
+namespace {
+
+constexpr int VT = 256;
+
+// ---- K4a ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(VT) ra_voc_modulator_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int64_t t0, int64_t n, int64_t j_lo) {
+  const int tid = threadIdx.x, jb = blockIdx.x, s = blockIdx.y;
+  const int M = p.voc_Mm, W = p.voc_Wm, S = p.voc_S;
+  double2 *z = reinterpret_cast<double2 *>(ra_smem_voc);
+  {
+    const int64_t start = (j_lo + jb) * (int64_t)S;
+    const float *hist = b.voc_mod_hist + (size_t)s * W;
+    const float *vs = voice ? voice + (size_t)s * n : nullptr;
+    const int h = W / 2;
+    auto sample = [&](int i) -> double {
+      if (i >= W) return 0.0;
+      int64_t a = start + i;
+      float v = (a < t0) ? hist[W - (t0 - a)] : (vs ? vs[a - t0] : 0.f);
+      int j = (i >= h) ? (i - h) : (h - 1 - i);
+      return (double)v * b.voc_half_window[j];
+    };
+    for (int k = tid; k < M; k += VT) z[b.vm_bitrev[k]] = make_double2(sample(2 * k), sample(2 * k + 1));
+  }
+  __syncthreads();
+  ra_fft_dit(z, M, b.vm_tw_half, tid, VT, false);
+  for (int k = tid; k <= (M >> 1); k += VT) {
+    int km = (M - k) % M;
+    double2 zk = z[k], zm = z[km];
+    double2 xk = ra_real_split_bin(zk, zm, b.vm_tw_full[k]);
+    double sk = xk.x * xk.x + xk.y * xk.y, sm = 0.0;
+    if (km != k) { double2 xm = ra_real_split_bin(zm, zk, b.vm_tw_full[km]); sm = xm.x * xm.x + xm.y * xm.y; }
+    z[k].x = sk;
+    if (km != k) z[km].x = sm;
+  }
+  __syncthreads();
+  // band amplitudes: bins in ascending order per band, like the reference's single pass (vocoder.cpp:137-160)
+  const int B = p.voc_bands;
+  if (tid < B) {
+    double acc = 0.0;
+    for (int i = b.voc_mod_band_start[2 * tid]; i < b.voc_mod_band_start[2 * tid + 1]; ++i) acc += z[i].x;
+    b.voc_amp[((size_t)s * b.voc_mod_cap + jb) * B + tid] = sqrt(acc);
+  }
+}
+
+// ---- K4b ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(VT) ra_voc_carrier_kernel(RaParams p, RaBuffers b, const float *__restrict__ carrier, int64_t t0, int64_t n, int64_t i_lo,
+                                                          int64_t j_lo, int64_t n_mod) {
+  const int tid = threadIdx.x, ib = blockIdx.x, s = blockIdx.y;
+  const int M = p.voc_Mc, L = p.voc_Lc, S = p.voc_S, W = 2 * p.voc_S, B = p.voc_bands;
+  double2 *z = reinterpret_cast<double2 *>(ra_smem_voc);
+  const int64_t i = i_lo + ib;
+  const int64_t fire = (int64_t)W - 1 + i * S;
+  {
+    const int64_t start = i * (int64_t)S;
+    const float *hist = b.voc_car_hist + (size_t)s * W;
+    const float *cs = carrier ? carrier + (size_t)s * n : nullptr;
+    auto sample = [&](int q) -> double {
+      if (q >= W) return 0.0;
+      int64_t a = start + q;
+      float v = (a < t0) ? hist[W - (t0 - a)] : (cs ? cs[a - t0] : 0.f);
+      return (double)v; // PeriodicFFT::feed(float), apply_rectangular_window (periodicfft.cpp:228)
+    };
+    for (int k = tid; k < M; k += VT) z[b.vc_bitrev[k]] = make_double2(sample(2 * k), sample(2 * k + 1));
+  }
+  __syncthreads();
+  ra_fft_dit(z, M, b.vc_tw_half, tid, VT, false);
+
+  // band amplitudes in force when this frame fires: the latest modulator frame with fire_j <= fire_i (it is fed first, :782-790)
+  const double *amp = nullptr;
+  {
+    int64_t a = fire - ((int64_t)p.voc_Wm - 1);
+    if (a >= 0) {
+      int64_t j = a / S;
+      if (j >= j_lo && j - j_lo < n_mod) amp = b.voc_amp + ((size_t)s * b.voc_mod_cap + (j - j_lo)) * B;
+      else amp = b.voc_amp_prev + (size_t)s * B;
+    }
+  }
+  auto gain = [&](int k) -> double {
+    int band = b.voc_car_band[k];
+    return (band >= 0 && amp) ? amp[band] : 0.0;
+  };
+  // forward split, modulate, and the inverse transform's pre-pass, all on the private slot pair (k, M-k)
+  for (int k = tid; k <= (M >> 1); k += VT) {
+    const int km = M - k; // 1..M ; km == M stands for the Nyquist bin (pairs with k = 0)
+    double2 zk = z[k], zm = z[km % M];
+    double2 Xk = ra_real_split_bin(zk, zm, b.vc_tw_full[k]);
+    double2 Xm = ra_real_split_bin(zm, zk, b.vc_tw_full[km]); // for k = 0 this is X[M] (Nyquist)
+    double gk = gain(k), gm = gain(km);
+    Xk.x *= gk; Xk.y *= gk;
+    Xm.x *= gm; Xm.y *= gm;
+    // z'[k] = (X[k] + conj X[M-k]) + i (X[k] - conj X[M-k]) conj(W^k)
+    auto pre = [&](double2 xa, double2 xb, double2 w) -> double2 { // xa = X[q], xb = X[M-q], w = tw_full[q]
+      double er = xa.x + xb.x, ei = xa.y - xb.y;
+      double dr = xa.x - xb.x, di = xa.y + xb.y;
+      double o_r = dr * w.x + di * w.y;   // (dr + i di) * (w.x - i w.y)
+      double o_i = di * w.x - dr * w.y;
+      return make_double2(er - o_i, ei + o_r);
+    };
+    double2 nk = pre(Xk, Xm, b.vc_tw_full[k]);
+    z[k] = nk;
+    if (k != 0 && km != k) z[km] = pre(Xm, Xk, b.vc_tw_full[km]);
+  }
+  __syncthreads();
+  for (int k = tid; k < M; k += VT) { // bit-reversal permutation (pairs are disjoint)
+    int r = b.vc_bitrev[k];
+    if (k < r) { double2 t = z[k]; z[k] = z[r]; z[r] = t; }
+  }
+  __syncthreads();
+  ra_fft_dit(z, M, b.vc_tw_half, tid, VT, true);
+  const double scale = 1.0 / (double)L;
+  double *dst = b.voc_sig + ((size_t)s * b.voc_car_cap + ib) * W;
+  for (int q = tid; q < W; q += VT) {
+    double2 v = z[q >> 1];
+    dst[q] = ((q & 1) ? v.y : v.x) * scale;
+  }
+}
+
+// ---- K4c ------------------------------------------------------------------------------------------
+__global__ void ra_voc_mix_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, const float *__restrict__ carrier, int64_t t0, int64_t n,
+                                  int64_t i_lo, int64_t n_car) {
+  const int s = blockIdx.y;
+  const int S = p.voc_S, W = 2 * p.voc_S;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t a = t0 + r;
+    double y = 0.0;
+    if (a >= W - 1) {
+      const int64_t i = (a - (W - 1)) / S;
+      const int idx = (int)(a - ((int64_t)W - 1 + i * S));
+      auto sig = [&](int64_t f) -> const double * { // frame f's 2S samples, or null (= zeros) before the first frame
+        if (f < 0) return nullptr;
+        if (f >= i_lo) return b.voc_sig + ((size_t)s * b.voc_car_cap + (f - i_lo)) * W;
+        return b.voc_sig_prev + ((size_t)s * 2 + (f - (i_lo - 2))) * W; // i_lo-2 -> slot 0, i_lo-1 -> slot 1
+      };
+      const double *nw = sig(i), *od = sig(i - 1);
+      const double nm = b.voc_xf_new[idx], om = 1.0 - nm;
+      y = (nw ? nw[idx] : 0.0) * nm + (od ? od[idx + S] : 0.0) * om;
+    }
+    const double m = voice ? (double)voice[(size_t)s * n + r] : 0.0;
+    const double c = carrier ? (double)carrier[(size_t)s * n + r] : 0.0;
+    b.voc_mix[(size_t)s * n + r] = (double)p.vol_mod * m + (double)p.vol_car * c + (double)p.vol_voc * y;
+  }
+}
+
+// ---- K4d ------------------------------------------------------------------------------------------
+// one workgroup per stream; LDS staging so that in-place shifts are safe
+__global__ void ra_voc_roll_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, const float *__restrict__ carrier, int64_t n, int64_t i_lo,
+                                   int64_t n_car, int64_t n_mod) {
+  const int s = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+  const int S = p.voc_S, W = 2 * p.voc_S, Wm = p.voc_Wm, B = p.voc_bands;
+  double *tmp = reinterpret_cast<double *>(ra_smem_voc); // >= max(2*W doubles, Wm floats)
+  // carrier frames: new prev = frames (i_hi - 1, i_hi) where i_hi = i_lo + n_car - 1
+  if (n_car > 0) {
+    double *prev = b.voc_sig_prev + (size_t)s * 2 * W;
+    const double *blk = b.voc_sig + (size_t)s * b.voc_car_cap * W;
+    for (int q = tid; q < 2 * W; q += T) {
+      int slot = q / W, off = q - slot * W;
+      int64_t f = i_lo + n_car - 2 + slot;     // absolute frame wanted in this slot
+      double v;
+      if (f >= i_lo) v = blk[(size_t)(f - i_lo) * W + off];
+      else v = prev[(size_t)(f - (i_lo - 2)) * W + off]; // f == i_lo - 1 -> old slot 1
+      tmp[q] = v;
+    }
+    __syncthreads();
+    for (int q = tid; q < 2 * W; q += T) prev[q] = tmp[q];
+    __syncthreads();
+  }
+  if (n_mod > 0) {
+    const double *src = b.voc_amp + ((size_t)s * b.voc_mod_cap + (n_mod - 1)) * B;
+    for (int q = tid; q < B; q += T) b.voc_amp_prev[(size_t)s * B + q] = src[q];
+  }
+  // sample histories
+  auto roll = [&](float *hist, const float *blk, int len) {
+    float *ft = reinterpret_cast<float *>(tmp);
+    for (int q = tid; q < len; q += T) {
+      int64_t src = (int64_t)q + n;            // index into concat(hist, block)
+      ft[q] = (src < len) ? hist[src] : (blk ? blk[src - len] : 0.f);
+    }
+    __syncthreads();
+    for (int q = tid; q < len; q += T) hist[q] = ft[q];
+    __syncthreads();
+  };
+  roll(b.voc_mod_hist + (size_t)s * Wm, voice ? voice + (size_t)s * n : nullptr, Wm);
+  roll(b.voc_car_hist + (size_t)s * W, carrier ? carrier + (size_t)s * n : nullptr, W);
+}
+
+} // namespace
+
+void ra_launch_vocoder(const RaParams &p, const RaBuffers &b, const float *d_voice, const float *d_carrier, int64_t t0, int64_t n, hipStream_t st) {
+  if (n <= 0) return;
+  const int S = p.voc_S, W = 2 * S;
+  RaFrameRange mod = ra_frames_firing(p.voc_Wm, S, t0, n);
+  RaFrameRange car = ra_frames_firing(W, S, t0, n);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_modulator_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_carrier_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_roll_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  if (mod.count > 0)
+    hipLaunchKernelGGL(ra_voc_modulator_kernel, dim3((unsigned)mod.count, (unsigned)p.n_streams), dim3(VT), (size_t)p.voc_Mm * sizeof(double2), st, p, b, d_voice,
+                       t0, n, mod.lo);
+  if (car.count > 0)
+    hipLaunchKernelGGL(ra_voc_carrier_kernel, dim3((unsigned)car.count, (unsigned)p.n_streams), dim3(VT), (size_t)std::max(p.voc_Mc, 1) * sizeof(double2), st,
+                       p, b, d_carrier, t0, n, car.lo, mod.lo, mod.count);
+  {
+    unsigned gx = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(ra_voc_mix_kernel, dim3(gx, (unsigned)p.n_streams), dim3(256), 0, st, p, b, d_voice, d_carrier, t0, n, car.lo, car.count);
+  }
+  size_t lds = std::max((size_t)2 * W * sizeof(double), (size_t)p.voc_Wm * sizeof(float));
+  hipLaunchKernelGGL(ra_voc_roll_kernel, dim3((unsigned)p.n_streams), dim3(256), lds, st, p, b, d_voice, d_carrier, n, car.lo, car.count, mod.count);
+}

@@ -161,11 +161,11 @@ int ra_compute(ra_context *ctx, int32_t stream, double *h_buffer, int32_t n_fram
 /*
  * Per-kernel device time, measured with HIP events on the context's launch stream — the GPU-side counterpart of the
  * reference's per-stage ThreadCPUTimer gauges (periodicfft.cpp:140-151, lib.cpp:1586-1617, getDurationFft/Extract/Step).
- * ms4 = accumulated milliseconds of {analysis (fft+extract+stateless step), tracking (step), synthesis (compute), history copy}
- * over `calls` ra_process_* calls since profiling was enabled.
+ * ms5 = accumulated milliseconds of {analysis (fft+extract+stateless step), tracking (step), vocoder, synthesis (compute),
+ * history copy} over `calls` ra_process_* calls since profiling was enabled.
  */
 int ra_set_profiling(ra_context *ctx, int32_t enable);
-int ra_get_kernel_ms(ra_context *ctx, double *ms4, int64_t *calls);
+int ra_get_kernel_ms(ra_context *ctx, double *ms5, int64_t *calls);
 
 /* counters and device-side error flags (synchronises) */
 int ra_get_stats(ra_context *ctx, ra_stats *stats);

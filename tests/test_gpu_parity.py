@@ -231,6 +231,53 @@ def test_compute_func_boundary_accumulates(api, oracle, sig):
             ctx2.feed(x[0, :4])
 
 
+VOC_KW = dict(analysis_volume=0.0, voice_volume=0.0, carrier_volume=0.0, vocoder_volume=1.0, vocoder_count_bands=32,
+              vocoder_min_freq=100.0, vocoder_max_freq=20000.0, vocoder_modulator_window_size_seconds=0.10, vocoder_stride_seconds=0.005)
+
+
+def test_c3_vocoder_shape(api, oracle, sig):
+    # configs[2] shape: 32 log bands 100-20000 Hz, modulator window 4800 -> FFT 8192, S = 241, carrier FFT 512, saw carrier
+    n = 48000
+    x = sig.make_streams(3, n, kind="speech")
+    car = np.stack([sig.carrier_stream(n, freq=110.0 * (1 + 0.5 * s)) for s in range(3)])
+    out = check_streams(api, oracle, x, carrier=car, **VOC_KW)
+    assert out.std() > 1e-4
+
+
+@pytest.mark.parametrize("kw", [
+    dict(VOC_KW, vocoder_count_bands=5),                                             # reference default band count
+    dict(VOC_KW, vocoder_count_bands=50, vocoder_stride_seconds=0.011),              # max bands, other stride
+    dict(VOC_KW, voice_volume=0.3, carrier_volume=0.2, vocoder_volume=0.7),          # full mix
+    dict(VOC_KW, analysis_volume=1.0, vocoder_volume=0.5),                           # synth + vocoder summed (lib.cpp:1353,1377)
+    dict(VOC_KW, vocoder_modulator_window_size_seconds=0.02, vocoder_stride_seconds=0.0021, vocoder_min_freq=300.0, vocoder_max_freq=3000.0),
+    dict(analysis_volume=0.0, carrier_volume=0.1),                                    # reference defaults: 0.1 x carrier passes through
+])
+def test_vocoder_variants(api, oracle, sig, kw):
+    n = 30000
+    x = sig.make_streams(2, n, base_seed=21)
+    car = np.stack([sig.carrier_stream(n, freq=98.0), sig.carrier_stream(n, freq=220.0, kind="sine")])
+    check_streams(api, oracle, x, carrier=car, **kw)
+
+
+def test_vocoder_block_size_invariance(api, sig):
+    n = 40000
+    x = sig.make_streams(2, n, kind="speech")
+    car = np.stack([sig.carrier_stream(n), sig.carrier_stream(n, freq=147.0)])
+    cfg = api.default_config(**dict(PARITY_KW, **VOC_KW))
+    with api.Context(cfg, 2, 0) as ctx:
+        whole = ctx.process_host(x, car)
+        ctx.reset()
+        cuts = [0, 1, 240, 241, 482, 483, 5000, 5003, 9600, 9601, 25000, 40000]
+        parts = [ctx.process_host(x[:, a:b], car[:, a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        assert np.array_equal(np.concatenate(parts, axis=1), whole)
+        # voice only / carrier only inputs are legal (RtResynthOfflineJob reads 0 past the end, params.cpp:291-313)
+        ctx.reset()
+        a = ctx.process_host(x, None)
+        ctx.reset()
+        b = ctx.process_host(x, np.zeros_like(car))
+        assert np.array_equal(a, b)
+
+
 def test_argument_validation(api):
     for kw in (dict(window_size=4095), dict(window_size=0), dict(stride=0), dict(n_channels=0), dict(n_channels=1000),
                dict(window_size=65536), dict(min_volume=-1.0), dict(vocoder_count_bands=51)):
