@@ -821,8 +821,81 @@ int ra_sqmag(const float *h_windows, int32_t n_windows, int32_t window_size, int
   return r;
 }
 
-int64_t ra_resynth_notes(const ra_note *, int32_t, int32_t, int32_t, int32_t, double *, int64_t) {
-  return fail(RA_EINVAL, "ra_resynth_notes: not available in this build");
+int64_t ra_resynth_notes(const ra_note *notes, int32_t n_notes, int32_t stride, int32_t sr, int32_t device, double *h_out, int64_t cap) {
+  if (n_notes < 0 || (n_notes > 0 && !notes)) return fail(RA_EINVAL, "bad notes");
+  if (stride < 1 || sr < 1000) return fail(RA_EINVAL, "bad stride / sampling rate");
+  // setAHDSR(AHDSR{1000, LINEAR, 0, 1000, LINEAR, 10000, LINEAR, 0.7f}, sampling_rate), resynth.hpp:87-93
+  RaEnvParams ep;
+  {
+    int min_dt = sr / 1000;
+    ep.A = std::max(1000, min_dt);
+    ep.H = 0;
+    ep.D = std::max(1000, min_dt);
+    ep.R = std::max(10000, min_dt);
+    ep.SMinusOne = std::min(std::max(0.7f, 0.f), 1.f) - 1.f;
+  }
+  // unstride and order by start frame (resynth.hpp:56-70; equal starts keep their input order)
+  struct N { int64_t start, end; double freq, amp; };
+  std::vector<N> byStart(n_notes);
+  for (int i = 0; i < n_notes; ++i) {
+    if (notes[i].end_frame < notes[i].start_frame || notes[i].start_frame < 0) return fail(RA_EINVAL, "note with endFrame < startFrame or negative start");
+    byStart[i] = {static_cast<int64_t>(notes[i].start_frame) * stride, static_cast<int64_t>(notes[i].end_frame) * stride, notes[i].frequency,
+                  notes[i].amplitude_db};
+  }
+  std::stable_sort(byStart.begin(), byStart.end(), [](const N &a, const N &b) { return a.start < b.start; });
+  // replay getAvailableOscillator (resynth.hpp:19-27): an element sounds until the step in which it reaches EnvelopeDone2
+  std::vector<int64_t> slot_end;                 // last step index at which the slot's element is RT-active
+  std::vector<std::vector<RaNoteEv>> per_slot;
+  int64_t max_end = -1, last_start = 0;
+  for (const N &nt : byStart) {
+    double inc = 2 * nt.freq / sr;               // freq_to_angle_increment<double>, sound.functions.h:58-62
+    double period = (inc == 0.) ? 1. : 2. / std::fabs(inc);
+    int next_min_change = static_cast<int>(0.5f + 2.5 * period); // Enveloped::setAngleIncrements, audioelement.h:218-225
+    int64_t delay = stride + nt.end - nt.start;
+    if (delay > 0x7fffffff) return fail(RA_EINVAL, "note too long");
+    int r_eff = std::max(next_min_change, ep.R);
+    int64_t end_step = nt.start + delay + r_eff + 16;
+    size_t slot = 0;
+    for (; slot < slot_end.size(); ++slot) if (slot_end[slot] < nt.start) break;
+    if (slot == slot_end.size()) { slot_end.push_back(0); per_slot.emplace_back(); }
+    slot_end[slot] = end_step;
+    RaNoteEv e;
+    e.start = nt.start; e.inc = inc; e.vol = std::pow(10.0, nt.amp / 20.0); // DbToMag, resynth.hpp:86
+    e.delay = static_cast<int32_t>(delay); e.pad = 0;
+    per_slot[slot].push_back(e);
+    max_end = std::max(max_end, end_step);
+    last_start = nt.start;
+  }
+  // frames the loops of resynth.hpp:77-79,99 write: up to and including the first frame that finds no active element
+  int64_t T = n_notes == 0 ? 1 : std::max(last_start, max_end + 1) + 1;
+  if (!h_out) return T;
+  if (cap < T) return fail(RA_EINVAL, "output buffer too small");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(RA_ENODEVICE, "no HIP device visible (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(RA_EINVAL, "device ordinal out of range");
+  HIP_TRY(hipSetDevice(device));
+  std::vector<RaNoteEv> flat;
+  std::vector<int> begin(per_slot.size() + 1, 0);
+  for (size_t s = 0; s < per_slot.size(); ++s) { begin[s] = static_cast<int>(flat.size()); flat.insert(flat.end(), per_slot[s].begin(), per_slot[s].end()); }
+  begin[per_slot.size()] = static_cast<int>(flat.size());
+  int n_slots = static_cast<int>(per_slot.size());
+  int groups = std::max(1, (n_slots + 63) / 64);
+  RaNoteEv *d_ev = nullptr; int *d_begin = nullptr; double *d_partial = nullptr, *d_out = nullptr;
+  auto cleanup = [&]() { (void)hipFree(d_ev); (void)hipFree(d_begin); (void)hipFree(d_partial); (void)hipFree(d_out); };
+  hipError_t e = hipMalloc(&d_ev, std::max<size_t>(1, flat.size()) * sizeof(RaNoteEv));
+  if (e == hipSuccess) e = hipMalloc(&d_begin, begin.size() * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc(&d_partial, static_cast<size_t>(groups) * T * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&d_out, static_cast<size_t>(T) * sizeof(double));
+  if (e == hipSuccess && !flat.empty()) e = hipMemcpy(d_ev, flat.data(), flat.size() * sizeof(RaNoteEv), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_begin, begin.data(), begin.size() * sizeof(int), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    ra_launch_notes(d_ev, d_begin, n_slots, ep, T, d_partial, d_out, nullptr);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(h_out, d_out, static_cast<size_t>(T) * sizeof(double), hipMemcpyDeviceToHost);
+  cleanup();
+  if (e != hipSuccess) return fail(RA_EHIP, std::string("ra_resynth_notes: ") + hipGetErrorString(e));
+  return T;
 }
 
 } // extern "C"

@@ -1,0 +1,229 @@
+// One synth channel = one audio element of the reference, held in registers by one lane.
+//
+// Restates, in the reference's operation order (fp64), the per-sample chain of
+//   ResynthElement<double> (source/rt.resynth.lib.cpp:6-19) =
+//   StereoPanned (include/audioelement.h:1319-1389) > VolumeAdjusted (:1110-1265) > Enveloped (:181-291)
+//   > AHDSREnvelope (:665-1102) + FreqCtrl_ (:3055-3155) > InterpolatedFreq (:2705-2817) + SineOscillatorAlgo (:2365-2452)
+// (mode 0), and of driver (A)'s Enveloped<VolumeAdjusted<SineOscillatorAlgo<double>>, AHDSREnvelope> (include/resynth.hpp:13-15)
+// (mode 1: no frequency glide, the increment reaches the oscillator directly).
+#pragma once
+#include "ra_internal.h"
+
+struct Chan {
+  // AHDSREnvelope
+  int state, counter, reldelay, ahdstate, ahdcounter, minch, nextminch;
+  double value, top;
+  // InterpolatedFreq
+  double from, to, cur, C, fres;
+  // SineOscillatorAlgo
+  double cre, cim, mre, mim, alias, inc;
+  // BaseVolumeAdjusted
+  double vol, target, finit, k, y;
+  // StereoPanned
+  double gL, gR;
+  int flags;
+};
+
+__device__ inline void chan_init(Chan &c) { // a freshly constructed element
+  c.state = ENV_DONE2; c.counter = 0; c.reldelay = -1; c.ahdstate = -1; c.ahdcounter = 0; c.minch = 0; c.nextminch = 0;
+  c.value = 0; c.top = 0;
+  c.from = c.to = c.cur = c.C = c.fres = 0;
+  c.cre = 1; c.cim = 0; c.mre = 1; c.mim = 0; c.alias = 1; c.inc = 0;
+  c.vol = c.target = c.finit = c.k = c.y = 0;
+  c.gL = c.gR = 1;
+  c.flags = 0;
+}
+
+__device__ inline bool rt_active(const Chan &c) { return c.state != ENV_SOON && c.state != ENV_DONE2; } // audioelement.h:390-395
+
+__device__ inline int env_max_counter(const Chan &c, const RaEnvParams &p) { // :1066-1084
+  switch (c.ahdstate) {
+    case 0: return max(c.minch, p.A);
+    case 1: return p.H;
+    default: return (p.D == 0) ? 0 : max(c.minch, p.D);
+  }
+}
+// onAHDStateChange (:1040-1053) and stepAHD (:1055-1064) call each other; unrolled into a loop
+__device__ inline void env_on_ahd_change(Chan &c, const RaEnvParams &p) {
+  for (;;) {
+    c.ahdcounter = 0;
+    c.minch = c.nextminch;
+    if (c.ahdstate < 0) return;
+    if (env_max_counter(c, p) != 0) return;
+    c.ahdstate = (c.ahdstate == 2) ? -1 : c.ahdstate + 1; // stepAHD with ahdCounter(0) >= maxCounter(0)
+  }
+}
+__device__ inline void env_step_ahd(Chan &c, const RaEnvParams &p) {
+  if (c.ahdcounter < env_max_counter(c, p)) return;
+  c.ahdstate = (c.ahdstate == 2) ? -1 : c.ahdstate + 1;
+  env_on_ahd_change(c, p);
+}
+__device__ inline double itp_linear(double t, double b, double cc, double d) { return cc * t / d + b; }
+
+__device__ inline void env_step(Chan &c, const RaEnvParams &p) { // EnvelopeCRT::step :702-756
+  if (c.reldelay >= 0) {
+    if (c.reldelay == 0) { // startReleased :836-841
+      c.minch = c.nextminch;
+      c.state = ENV_RELEASED;
+      c.top = c.value;
+      c.counter = 0;
+    }
+    --c.reldelay;
+  }
+  ++c.counter;
+  switch (c.state) {
+    case ENV_PRESSED: {
+      if (c.counter < 1) return;
+      if (c.counter == 1) { c.ahdstate = 0; env_on_ahd_change(c, p); } // startPressed :955-958
+      // stepPressed :960-1000
+      if (c.ahdstate >= 0) { env_step_ahd(c, p); ++c.ahdcounter; }
+      if (c.ahdstate < 0) { c.value = 1.0 + (double)p.SMinusOne; }
+      else {
+        double from, tmf;
+        switch (c.ahdstate) {
+          case 0: from = 0; tmf = 1; break;
+          case 1: from = 1; tmf = 0; break;
+          default: from = 1; tmf = (double)p.SMinusOne; break;
+        }
+        c.value = itp_linear((double)c.ahdcounter, from, tmf, (double)env_max_counter(c, p));
+      }
+    } break;
+    case ENV_RELEASED: {
+      int rt = max(c.minch, p.R); // getReleaseTime :1002-1004
+      c.value = itp_linear((double)c.counter, c.top, -c.top, (double)rt);
+      if (c.counter >= rt) { c.state = ENV_DONE1; c.counter = 0; c.value = 0; }
+    } break;
+    case ENV_DONE1:
+      if (c.counter > RA_N_FRAMES_PER_BUFFER) { c.state = ENV_DONE2; c.counter = 0; }
+      c.value = 0;
+      break;
+    default: c.value = 0; break;
+  }
+}
+__device__ inline void env_on_key_pressed(Chan &c, int delay) { c.state = ENV_PRESSED; c.counter = -delay; c.reldelay = -1; c.value = 0; } // :762-767
+__device__ inline void env_on_key_released(Chan &c, int delay) { // :769-781
+  if (c.state != ENV_PRESSED) return;
+  if (c.counter + delay <= 0) c.state = ENV_DONE1; else c.reldelay = delay;
+}
+__device__ inline bool env_can_release_now(const Chan &c, int delay) { // :802-811
+  return c.state == ENV_PRESSED && c.reldelay == -1 && (-c.counter <= delay);
+}
+
+__device__ inline double ctrl_prop(double from, double to) { return (to == from) ? (double)1.f : -log(from / to) / (to - from); } // :2804-2816
+
+__device__ inline double ctrl_step(Chan &c, double dur) { // InterpolatedFreq::step :2764-2788
+  if ((c.flags & FL_HAS_FRES) && c.fres == c.to) return c.to;
+  if (c.cur + (double).5f > dur) c.cur = dur;
+  c.fres = c.from + (c.to - c.from) * (c.cur / dur);
+  c.flags |= FL_HAS_FRES;
+  if (c.cur < dur) {
+    double f = c.from + (c.to - c.from) * (c.cur + (double).5f) / dur;
+    c.cur += c.C * f;
+  }
+  return c.fres;
+}
+
+__device__ inline double alias_mult(double inc) { // freqAliasingMultiplicator :466-483
+  if (inc == 0.) return 1.;
+  double halfN = 1. / inc;
+  if (halfN < 1.) return 0.;
+  if (halfN > 4.) return 1.;
+  return (halfN - 1.) * (1. / 3.);
+}
+
+__device__ inline void osc_set_inc(Chan &c, double f) { // SineOscillatorAlgo::setAngleIncrements :2404-2411
+  if (c.inc == f) return;
+  c.inc = f;
+  double sn, cs;
+  sincos(M_PI * f, &sn, &cs);
+  c.mre = cs;
+  c.mim = sn;
+  c.alias = alias_mult(f);
+}
+
+// FreqCtrl_::angleIncrements :3117-3124 (mode 0) / SineOscillatorAlgo::angleIncrements (mode 1)
+__device__ inline double angle_increments(const Chan &c, int mode) {
+  if (mode == 1) return c.inc;
+  return c.inc != 0. ? c.inc : c.from;
+}
+
+// StereoPanned::step -> BaseVolumeAdjusted::step (:1195-1216) -> Enveloped::step (:197-200) -> FreqCtrl_::step (:3126-3129)
+__device__ inline void chan_step(Chan &c, const RaEnvParams &p, double dur, double max_filter_inc, int mode) {
+  env_step(c, p);
+  if (mode == 0) osc_set_inc(c, ctrl_step(c, dur));
+  { // SineOscillatorAlgo::step :2413-2421 with approx_normalize :2443-2447
+    double re = c.cre * c.mre - c.cim * c.mim;
+    double im = c.cre * c.mim + c.cim * c.mre;
+    double nn = re * re + im * im;
+    double g = 0.5 * (3.0 - nn);
+    c.cre = re * g;
+    c.cim = im * g;
+  }
+  if (!(c.flags & FL_HAS_VOL)) {
+    c.finit = fmin(max_filter_inc, fabs(angle_increments(c, mode)));
+    double a = M_PI * c.finit; c.k = a / (1.0 + a); // one-pole low-pass coefficient (DESIGN.md §5, L0 decision)
+    c.y = c.target;
+  } else if (c.vol != c.target) {
+    double inc = fmin(max_filter_inc, fabs(angle_increments(c, mode)));
+    if (c.finit != inc) { c.finit = inc; double a = M_PI * inc; c.k = a / (1.0 + a); }
+  }
+  c.y = c.y + c.k * (c.target - c.y);
+  c.vol = c.y;
+  c.flags |= FL_HAS_VOL;
+}
+
+// Enveloped::setAngleIncrements :218-225 -> FreqCtrl_::setAngleIncrements :3103-3108 -> InterpolatedFreq::setAngleIncrements :2752-2762
+__device__ inline void chan_set_angle_increments(Chan &c, double a, int mode) {
+  double period = (a == 0.) ? 1. : 2. / fabs(a);
+  c.nextminch = (int)(0.5f + 2.5 * period);
+  if (mode == 1) { osc_set_inc(c, a); return; }
+  c.cur = 0;
+  c.to = a;
+  c.from = (c.flags & FL_HAS_FRES) ? c.fres : a;
+  c.C = ctrl_prop(c.from, c.to);
+}
+
+// forgetPastSignals: envelope :694-700, ctrl :2725-2727, volume :1168-1172
+__device__ inline void chan_forget_past_signals(Chan &c) {
+  c.counter = 0;
+  c.minch = c.nextminch;
+  c.flags = 0;
+}
+
+__device__ inline uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+// declared replacement of the reference's mersenne<> draws (gen.crtp.h:152, lib.cpp:116): see DESIGN.md §5
+__device__ inline float hash_uniform_pm1(uint64_t seed, uint64_t noteid, uint64_t salt) {
+  uint64_t h = splitmix64(seed ^ splitmix64(noteid * 2 + salt));
+  uint32_t r = (uint32_t)(h >> 40);
+  return -1.0f + 2.0f * ((float)r * (1.0f / 16777216.0f));
+}
+
+__device__ inline void load_chan(Chan &c, const double *sd, const int *si, int Ppad, int l) {
+  c.value = sd[SD_ENV_VALUE * Ppad + l]; c.top = sd[SD_ENV_TOP * Ppad + l];
+  c.from = sd[SD_CTRL_FROM * Ppad + l]; c.to = sd[SD_CTRL_TO * Ppad + l]; c.cur = sd[SD_CTRL_CUR * Ppad + l];
+  c.C = sd[SD_CTRL_C * Ppad + l]; c.fres = sd[SD_CTRL_FRES * Ppad + l];
+  c.cre = sd[SD_OSC_CRE * Ppad + l]; c.cim = sd[SD_OSC_CIM * Ppad + l]; c.mre = sd[SD_OSC_MRE * Ppad + l];
+  c.mim = sd[SD_OSC_MIM * Ppad + l]; c.alias = sd[SD_OSC_ALIAS * Ppad + l]; c.inc = sd[SD_OSC_INC * Ppad + l];
+  c.vol = sd[SD_VOL * Ppad + l]; c.target = sd[SD_VOL_TARGET * Ppad + l]; c.finit = sd[SD_VOL_FINIT * Ppad + l];
+  c.k = sd[SD_VOL_K * Ppad + l]; c.y = sd[SD_VOL_Y * Ppad + l]; c.gL = sd[SD_GAIN_L * Ppad + l]; c.gR = sd[SD_GAIN_R * Ppad + l];
+  c.state = si[SI_ENV_STATE * Ppad + l]; c.counter = si[SI_ENV_COUNTER * Ppad + l]; c.reldelay = si[SI_ENV_RELDELAY * Ppad + l];
+  c.ahdstate = si[SI_ENV_AHDSTATE * Ppad + l]; c.ahdcounter = si[SI_ENV_AHDCOUNTER * Ppad + l]; c.minch = si[SI_ENV_MINCH * Ppad + l];
+  c.nextminch = si[SI_ENV_NEXTMINCH * Ppad + l]; c.flags = si[SI_FLAGS * Ppad + l];
+}
+__device__ inline void store_chan(const Chan &c, double *sd, int *si, int Ppad, int l) {
+  sd[SD_ENV_VALUE * Ppad + l] = c.value; sd[SD_ENV_TOP * Ppad + l] = c.top;
+  sd[SD_CTRL_FROM * Ppad + l] = c.from; sd[SD_CTRL_TO * Ppad + l] = c.to; sd[SD_CTRL_CUR * Ppad + l] = c.cur;
+  sd[SD_CTRL_C * Ppad + l] = c.C; sd[SD_CTRL_FRES * Ppad + l] = c.fres;
+  sd[SD_OSC_CRE * Ppad + l] = c.cre; sd[SD_OSC_CIM * Ppad + l] = c.cim; sd[SD_OSC_MRE * Ppad + l] = c.mre;
+  sd[SD_OSC_MIM * Ppad + l] = c.mim; sd[SD_OSC_ALIAS * Ppad + l] = c.alias; sd[SD_OSC_INC * Ppad + l] = c.inc;
+  sd[SD_VOL * Ppad + l] = c.vol; sd[SD_VOL_TARGET * Ppad + l] = c.target; sd[SD_VOL_FINIT * Ppad + l] = c.finit;
+  sd[SD_VOL_K * Ppad + l] = c.k; sd[SD_VOL_Y * Ppad + l] = c.y; sd[SD_GAIN_L * Ppad + l] = c.gL; sd[SD_GAIN_R * Ppad + l] = c.gR;
+  si[SI_ENV_STATE * Ppad + l] = c.state; si[SI_ENV_COUNTER * Ppad + l] = c.counter; si[SI_ENV_RELDELAY * Ppad + l] = c.reldelay;
+  si[SI_ENV_AHDSTATE * Ppad + l] = c.ahdstate; si[SI_ENV_AHDCOUNTER * Ppad + l] = c.ahdcounter; si[SI_ENV_MINCH * Ppad + l] = c.minch;
+  si[SI_ENV_NEXTMINCH * Ppad + l] = c.nextminch; si[SI_FLAGS * Ppad + l] = c.flags;
+}

@@ -133,6 +133,18 @@ __host__ __device__ inline RaFrameRange ra_frames_firing(int64_t W, int64_t S, i
   r.count = hi >= r.lo ? hi - r.lo + 1 : 0;
   return r;
 }
+// the AHDSR stage lengths after setAHDSR (audioelement.h:923-952); uniform for a launch
+struct RaEnvParams { int A, H, D, R; float SMinusOne; };
+// one note of the main.resynth driver, already assigned to a pool slot (resynth.hpp:83-96)
+struct RaNoteEv {
+  int64_t start;   // sample at which the note starts (startFrame * stride)
+  double inc;      // freq_to_angle_increment<double>(frequency, sampling_rate)
+  double vol;      // DbToMag(amplitude)
+  int32_t delay;   // onKeyReleased(stride + endFrame - startFrame)
+  int32_t pad;
+};
+void ra_launch_notes(const RaNoteEv *d_ev, const int *d_slot_begin, int n_slots, RaEnvParams ep, int64_t T, double *d_partial, double *d_out,
+                     hipStream_t st);
 void ra_launch_vocoder(const RaParams &p, const RaBuffers &b, const float *d_voice, const float *d_carrier, int64_t t0, int64_t n, hipStream_t st);
 
 // launchers (defined next to their kernels)

@@ -278,6 +278,31 @@ def test_vocoder_block_size_invariance(api, sig):
         assert np.array_equal(a, b)
 
 
+def _random_notes(rng, n_notes, max_start, sr):
+    start = np.sort(rng.integers(0, max_start, n_notes)).astype(np.int32)
+    start[: n_notes // 8] = start[0]                      # several notes on the same start frame
+    end = (start + rng.integers(0, 40, n_notes)).astype(np.int32)
+    freq = np.exp(rng.uniform(np.log(30.0), np.log(0.45 * sr), n_notes))
+    freq[::17] = freq[0]                                  # repeated frequencies
+    amp = rng.uniform(-50.0, -10.0, n_notes)
+    perm = rng.permutation(n_notes)                       # the driver sorts by start frame itself (resynth.hpp:65-70)
+    return start[perm], end[perm], freq[perm], amp[perm]
+
+
+@pytest.mark.parametrize("n_notes,stride,sr", [(0, 400, 44100), (1, 400, 44100), (40, 400, 44100), (300, 400, 44100), (150, 256, 48000)])
+def test_driver_a_resynth_notes(api, oracle, n_notes, stride, sr):
+    # main.resynth's resynth(): configs[0] uses stride 400 @ 44.1 kHz (main.resynth.cpp:6,77-80)
+    rng = np.random.default_rng(n_notes + stride)
+    start, end, freq, amp = _random_notes(rng, n_notes, 120, sr) if n_notes else (np.zeros(0, np.int32),) * 2 + (np.zeros(0),) * 2
+    ref = oracle.resynth_notes(start, end, freq, amp, stride, sr)
+    got = api.resynth_notes(start, end, freq, amp, stride, sr)
+    assert len(got) == len(ref)
+    if n_notes:
+        assert np.sqrt(np.mean(ref ** 2)) > 1e-4
+    err = np.sqrt(np.mean((got - ref) ** 2))
+    assert err <= 1e-9, err
+
+
 def test_argument_validation(api):
     for kw in (dict(window_size=4095), dict(window_size=0), dict(stride=0), dict(n_channels=0), dict(n_channels=1000),
                dict(window_size=65536), dict(min_volume=-1.0), dict(vocoder_count_bands=51)):
