@@ -41,7 +41,7 @@ class RaConfig(C.Structure):
         ("voice_volume", C.c_float), ("carrier_volume", C.c_float), ("vocoder_volume", C.c_float),
         ("analysis_volume", C.c_float), ("analysis_input_gain", C.c_float),
         ("phase_policy", C.c_int32), ("seed", C.c_uint64),
-        ("max_pitches_per_frame", C.c_int32),
+        ("max_pitches_per_frame", C.c_int32), ("reference_order", C.c_int32),
     ]
 
 

@@ -429,6 +429,14 @@ int ensure_scratch(ra_context *c, int64_t nfb, int64_t n) {
     if ((r = dev_alloc(c, &b.pl_count, S * F))) return r;
     if ((r = dev_alloc(c, &b.cmd, S * F * p.Ppad, false))) return r;
   }
+  if (!c->cfg.reference_order && nfb + 1 > b.seg_cap) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dev_free(c, b.seg_sd); dev_free(c, b.seg_si);
+    size_t S = p.n_streams, G = static_cast<size_t>(nfb + 1);
+    b.seg_cap = nfb + 1;
+    if ((r = dev_alloc(c, &b.seg_sd, S * G * SD_COUNT * p.Ppad, false))) return r;
+    if ((r = dev_alloc(c, &b.seg_si, S * G * SI_COUNT * p.Ppad, false))) return r;
+  }
   if (p.voc_enabled) {
     size_t S = p.n_streams;
     if (n > b.mix_cap) {
@@ -495,7 +503,7 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
   if (prof) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
   if (p.voc_enabled) ra_launch_vocoder(p, c->b, d_voice, d_carrier, c->t, n, c->stream);
   if (prof) HIP_TRY(hipEventRecord(c->ev[3], c->stream));
-  ra_launch_synth(p, c->b, c->t, n, f_lo, nfb, d_out, d_out_d, c->stream);
+  ra_launch_synth(p, c->b, c->t, n, f_lo, nfb, d_out, d_out_d, c->cfg.reference_order, c->stream);
   if (prof) HIP_TRY(hipEventRecord(c->ev[4], c->stream));
   ra_launch_roll_history(p, c->b, d_voice, n, c->stream);
   if (prof) { HIP_TRY(hipEventRecord(c->ev[5], c->stream)); c->ev_pending = true; }

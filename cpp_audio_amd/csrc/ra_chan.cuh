@@ -190,6 +190,121 @@ __device__ inline void chan_forget_past_signals(Chan &c) {
   c.flags = 0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// chan_jump: the state after n calls of "if (rt_active) chan_step" (mode 0), without running them.
+//
+// Between two analysis frames nothing touches a channel, and each of its recurrences has a closed form:
+//   envelope   : integer counters; the value is recomputed from them (bit-exact with stepping)
+//   freq glide : cur' = (1+x) cur + beta  (InterpolatedFreq::step is affine in cur_sample)  -> expm1 / log1p
+//   oscillator : unit phasor; phase += pi * sum(inc_m), and the sum telescopes: inc_m = (cur_{m+1} - cur_m)/C - x/(2C)...
+//   volume     : one-pole towards a constant target with constant k -> (1-k)^n
+// Steps at which a regime changes (stage rotation, release start, glide end, first step of a note, ...) are
+// taken one at a time with chan_step itself, so only regular stretches are jumped.  Differences to stepping are
+// rounding-level (1e-13 relative), far inside the 1e-5 RMS budget; ra_config.reference_order selects the
+// sample-serial kernel instead.
+// ---------------------------------------------------------------------------------------------------
+__device__ inline int env_regular_steps(const Chan &c, const RaEnvParams &p) { // steps that only bump counters (0 = next step is a transition)
+  int lim = 0x7fffffff;
+  if (c.reldelay >= 0) lim = c.reldelay; // the step that finds reldelay == 0 starts the release
+  switch (c.state) {
+    case ENV_PRESSED: {
+      if (c.counter < 1) return 0;
+      if (c.ahdstate < 0) return lim;
+      int a = c.ahdcounter, M = env_max_counter(c, p);
+      return a < M ? min(lim, M - a) : 0;
+    }
+    case ENV_RELEASED: { int rt = max(c.minch, p.R); return max(0, min(lim, rt - 1 - c.counter)); }
+    case ENV_DONE1: return max(0, min(lim, RA_N_FRAMES_PER_BUFFER - c.counter));
+    default: return 0;
+  }
+}
+__device__ inline void env_jump(Chan &c, const RaEnvParams &p, int j) { // j <= env_regular_steps
+  if (c.reldelay >= 0) c.reldelay -= j;
+  c.counter += j;
+  switch (c.state) {
+    case ENV_PRESSED:
+      if (c.ahdstate < 0) c.value = 1.0 + (double)p.SMinusOne;
+      else {
+        c.ahdcounter += j;
+        double from, tmf;
+        switch (c.ahdstate) {
+          case 0: from = 0; tmf = 1; break;
+          case 1: from = 1; tmf = 0; break;
+          default: from = 1; tmf = (double)p.SMinusOne; break;
+        }
+        c.value = itp_linear((double)c.ahdcounter, from, tmf, (double)env_max_counter(c, p));
+      }
+      break;
+    case ENV_RELEASED: c.value = itp_linear((double)c.counter, c.top, -c.top, (double)max(c.minch, p.R)); break;
+    default: c.value = 0; break;
+  }
+}
+
+__device__ inline void osc_rotate(Chan &c, double sum_inc) { // cur *= e^{i pi sum_inc}
+  double r = sum_inc - 2.0 * rint(0.5 * sum_inc); // exact reduction to [-1, 1]
+  double sn, cs;
+  sincos(M_PI * r, &sn, &cs);
+  double re = c.cre * cs - c.cim * sn, im = c.cre * sn + c.cim * cs;
+  double g = 0.5 * (3.0 - (re * re + im * im));
+  c.cre = re * g; c.cim = im * g;
+}
+
+__device__ inline void chan_jump(Chan &c, const RaEnvParams &p, double dur, double max_filter_inc, int64_t n) {
+  while (n > 0 && rt_active(c)) {
+    bool serial = !(c.flags & FL_HAS_VOL);
+    int j = env_regular_steps(c, p);
+    if (j == 0) serial = true;
+    // regime of the frequency control
+    const bool steady = (c.flags & FL_HAS_FRES) && c.fres == c.to;
+    const double f_end = c.from + (c.to - c.from) * (dur / dur);
+    const bool clamped = !steady && (c.flags & FL_HAS_FRES) && c.cur == dur && c.fres == f_end;
+    const bool gliding = !steady && !clamped;
+    if (gliding && (c.to == c.from || c.cur + (double).5f > dur || !(c.flags & FL_HAS_FRES))) serial = true;
+    if (serial) { chan_step(c, p, dur, max_filter_inc, 0); --n; continue; }
+    if ((int64_t)j > n) j = (int)n;
+
+    double sum_inc, fres_last = c.fres, u_j = c.cur;
+    if (!gliding) {
+      sum_inc = (double)j * c.fres; // constant increment (== to when steady)
+    } else {
+      const double x = c.C * (c.to - c.from) / dur;            // alpha - 1
+      const double beta = c.C * c.from + 0.5 * x;
+      const double Lg = log1p(x);
+      const double A = c.cur + beta / x;
+      auto u_at = [&](int m) -> double { return c.cur + expm1((double)m * Lg) * A; };
+      if (u_at(j - 1) + (double).5f > dur) { // the glide ends inside: jump only up to the first clamped step
+        double B = dur - (double).5f - c.cur;
+        double est = log1p(B / A) / Lg;
+        int ms = (est == est && est < 2.0e9 && est >= 0.0) ? (int)est + 1 : 1;
+        if (ms > j) ms = j;
+        if (ms < 1) ms = 1;
+        while (ms > 1 && u_at(ms - 1) + (double).5f > dur) --ms;
+        while (ms < j && !(u_at(ms) + (double).5f > dur)) ++ms;
+        j = ms;
+      }
+      const double u_jm1 = u_at(j - 1);
+      u_j = u_at(j);
+      fres_last = c.from + (c.to - c.from) * (u_jm1 / dur);
+      // inc_m = (u_{m+1} - u_m) / C - (to - from) / (2 dur)   (InterpolatedFreq::step, audioelement.h:2781-2785)
+      sum_inc = (u_j - c.cur) / c.C - (double)j * 0.5 * (c.to - c.from) / dur;
+    }
+    // volume filter: needs a constant coefficient over the stretch
+    if (c.vol != c.target) {
+      double lo = gliding ? fmin(fabs(c.from + (c.to - c.from) * (c.cur / dur)), fabs(fres_last)) : fabs(c.fres);
+      double want = fmin(max_filter_inc, lo);
+      bool ok = (c.finit == want) && (!gliding || lo >= max_filter_inc);
+      if (!ok) { chan_step(c, p, dur, max_filter_inc, 0); --n; continue; }
+      double q = exp((double)j * log1p(-c.k));
+      c.y = c.target + (c.y - c.target) * q;
+      c.vol = c.y;
+    }
+    env_jump(c, p, j);
+    if (gliding) { c.cur = u_j; c.fres = fres_last; osc_set_inc(c, fres_last); }
+    osc_rotate(c, sum_inc);
+    n -= j;
+  }
+}
+
 __device__ inline uint64_t splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;

@@ -104,6 +104,9 @@ struct RaBuffers {
   RaCmd *cmd;               // [n_streams][frames_cap][Ppad]
   double *voc_mix;          // [n_streams][n] when the vocoder is enabled
   int64_t mix_cap;
+  double *seg_sd;           // [n_streams][seg_cap][SD_COUNT][Ppad] channel state at the start of every segment of the block
+  int32_t *seg_si;          // [n_streams][seg_cap][SI_COUNT][Ppad]
+  int64_t seg_cap;
   double *dbg_sqmag;        // optional [frames][M] tap of |X|^2 (ra_sqmag), normally null
   // ---- vocoder (only allocated when a vocoder volume is non-zero) ----
   double *voc_half_window;  // [Wm/2] Gaussian 4 sigma
@@ -152,7 +155,7 @@ void ra_launch_analysis(const RaParams &p, const RaBuffers &b, const float *d_vo
                         hipStream_t st);
 void ra_launch_track(const RaParams &p, const RaBuffers &b, int64_t f_lo, int64_t n_frames_blk, hipStream_t st);
 void ra_launch_synth(const RaParams &p, const RaBuffers &b, int64_t t0, int64_t n, int64_t f_lo, int64_t n_frames_blk, float *d_out,
-                     double *d_out_d, hipStream_t st);
+                     double *d_out_d, int reference_order, hipStream_t st);
 void ra_launch_roll_history(const RaParams &p, const RaBuffers &b, const float *d_voice, int64_t n, hipStream_t st);
 size_t ra_analysis_lds_bytes(const RaParams &p);
 

@@ -1,4 +1,4 @@
-// K2 — tracking: one wavefront per stream, frames in order.
+// K2 — tracking: one wavefront per stream, frames in order, the 64 lanes cooperating inside a frame.
 //
 // Replaces the stateful half of RtResynth::step (reference source/rt.resynth.lib.cpp:1710-1758):
 // track_pitches (rt.resynth.lib.algo.cpp:256-305), order_pitches_by_perceived_loudness (:375-411),
@@ -10,6 +10,12 @@
 // EnvelopeDone1, audioelement.h:732-750), so this kernel keeps a per-channel `free_at` sample index
 // instead of reading synth state, which lets the whole block be tracked before one sample is rendered.
 // K3 cross-checks every acquisition against the real envelope (RA_ERR_BOOKKEEPING).
+//
+// Only the two-pointer matching of track_pitches is inherently sequential (one lane, tens of steps).  Everything
+// else maps to lanes: the loudness order and the pitch order are rank sorts (stable: ties keep index order, the
+// declared resolution of the reference's std::sort), event numbering and channel hand-out are ballot prefix counts
+// (the k-th note-on candidate in loudness order gets the k-th free channel in channel order — what the reference's
+// sequential first-free search yields, since channels only get taken inside one frame).
 #include "ra_internal.h"
 
 extern __shared__ __align__(16) unsigned char ra_smem_trk[];
@@ -17,8 +23,8 @@ extern __shared__ __align__(16) unsigned char ra_smem_trk[];
 namespace {
 
 // Enveloped::setAngleIncrements, audioelement.h:218-225 with sound.functions.h:69-76
-__device__ inline int min_change_for(float freq, int sample_rate, float mult) {
-  float inc_f = 2 * (freq * mult) / sample_rate; // freq_to_angle_increment<float>, sound.functions.h:58-62
+__device__ inline int min_change_for(float freq, int sample_rate) {
+  float inc_f = 2 * (freq * 1.f) / sample_rate; // freq_to_angle_increment<float>, sound.functions.h:58-62
   double a = (double)inc_f;
   double period = (a == 0.) ? 1. : 2. / fabs(a);
   return (int)(0.5f + 2.5 * period);
@@ -28,21 +34,33 @@ __global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, i
   const int s = blockIdx.x;
   const int lane = threadIdx.x;
   const int P = p.P, maxr = p.maxr;
+  const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-  double *pitch = reinterpret_cast<double *>(ra_smem_trk);       // [maxr]
-  double *vol = pitch + maxr;                                    // [maxr]
-  double *pl_pitch = vol + maxr;                                 // [P] played: current pitch
-  int64_t *pl_noteid = reinterpret_cast<int64_t *>(pl_pitch + P); // [P]
-  int64_t *free_at = pl_noteid + P;                              // [P]
-  int64_t *cnote = free_at + P;                                  // [P] staged commands: note id
-  float *key = reinterpret_cast<float *>(cnote + P);             // [maxr]
-  int *ord = reinterpret_cast<int *>(key + maxr);                // [maxr]
-  int *pc = ord + maxr;                                          // [maxr]  pitch_changes (-1 = none)
-  int *pl_chan = pc + maxr;                                      // [P]
-  int *cont = pl_chan + P;                                       // [P]
-  int *held = cont + P;                                          // [P]
-  int *minch = held + P;                                         // [P]
-  int *ctype = minch + P;                                        // [P] staged commands
+  // per pitch-list item
+  double *pitch = reinterpret_cast<double *>(ra_smem_trk);        // [maxr]
+  double *vol = pitch + maxr;                                     // [maxr]
+  // per played note / channel (8-byte)
+  double *pl_pitch = vol + maxr;                                  // [P]
+  double *tmp_pitch = pl_pitch + P;                               // [P]
+  int64_t *pl_noteid = reinterpret_cast<int64_t *>(tmp_pitch + P); // [P]
+  int64_t *tmp_noteid = pl_noteid + P;                            // [P]
+  int64_t *free_at = tmp_noteid + P;                              // [P]
+  int64_t *cnote = free_at + P;                                   // [P] staged commands: note id
+  // per item (4-byte)
+  float *key = reinterpret_cast<float *>(cnote + P);              // [maxr]
+  float *nf = key + maxr;                                         // [maxr] new frequency (float, events.h:19-29)
+  float *nv = nf + maxr;                                          // [maxr] new velocity
+  int *nmc = reinterpret_cast<int *>(nv + maxr);                  // [maxr] min change duration of the new frequency
+  int *ord = nmc + maxr;                                          // [maxr]
+  int *pc = ord + maxr;                                           // [maxr] pitch_changes (-1 = none)
+  // per played / channel (4-byte)
+  int *pl_chan = pc + maxr;                                       // [P]
+  int *tmp_chan = pl_chan + P;
+  int *cont = tmp_chan + P;
+  int *held = cont + P;
+  int *minch = held + P;
+  int *free_list = minch + P;
+  int *ctype = free_list + P;
   int *cord = ctype + P;
   float *cfreq = reinterpret_cast<float *>(cord + P);
   float *cvel = cfreq + P;
@@ -66,87 +84,122 @@ __global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, i
     const int64_t k_f = ra_fire_sample(p.N, p.H, f_lo + fb);
     const size_t lbase = ((size_t)s * b.frames_cap + fb) * maxr;
     const int A = b.pl_count[(size_t)s * b.frames_cap + fb];
-    for (int i = lane; i < A; i += 64) { pitch[i] = b.pl_pitch[lbase + i]; vol[i] = b.pl_vol[lbase + i]; key[i] = b.pl_key[lbase + i]; }
-    for (int i = lane; i < P; i += 64) ctype[i] = RA_CMD_NONE;
+
+    // ---- phase 0: load the frame's list; per item the event payload (lib.cpp:319-324, midi.h:254-264) ----
+    for (int i = lane; i < A; i += 64) {
+      double pt = b.pl_pitch[lbase + i], v = b.pl_vol[lbase + i];
+      pitch[i] = pt; vol[i] = v; key[i] = b.pl_key[lbase + i];
+      float f = (float)((double)440.f * pow(p.half_tone_ratio, pt - 69.0));
+      nf[i] = f;
+      nv[i] = (float)((double)p.analysis_volume * v / (double)0.1f);
+      nmc[i] = min_change_for(f, p.sample_rate);
+      pc[i] = -1;
+    }
+    for (int i = lane; i < P; i += 64) { ctype[i] = RA_CMD_NONE; if (i < n_played) cont[i] = 0; }
     __syncthreads();
 
+    // ---- phase 1: track_pitches, algo.cpp:256-305 (sequential two-pointer scan) ----
     if (lane == 0) {
-      // track_pitches, algo.cpp:256-305
-      for (int i = 0; i < A; ++i) pc[i] = -1;
-      for (int j = 0; j < n_played; ++j) cont[j] = 0;
-      {
-        int it = 0;
-        for (int idx = 0; idx < A; ++idx) {
-          double np = pitch[idx];
-          for (; it != n_played; ++it) {
-            if (pl_pitch[it] < np - p.max_track) continue;
-            if (pl_pitch[it] <= np + p.max_track) { pc[idx] = it; cont[it] = 1; ++it; }
-            break;
-          }
+      int it = 0;
+      for (int idx = 0; idx < A; ++idx) {
+        double np = pitch[idx];
+        for (; it != n_played; ++it) {
+          if (pl_pitch[it] < np - p.max_track) continue;
+          if (pl_pitch[it] <= np + p.max_track) { pc[idx] = it; cont[it] = 1; ++it; }
+          break;
         }
-      }
-      // order by key, descending, equal keys by ascending index (insertion sort = stable)
-      for (int i = 0; i < A; ++i) {
-        float k = key[i];
-        int j = i - 1;
-        while (j >= 0 && key[ord[j]] < k) { ord[j + 1] = ord[j]; --j; }
-        ord[j + 1] = i;
-      }
-      int n_ev = 0;
-      // note-offs, lib.cpp:296-313
-      for (int j = 0; j < n_played; ++j) {
-        if (!cont[j]) {
-          int c = pl_chan[j];
-          ctype[c] = RA_CMD_OFF; cord[c] = n_ev++; cfreq[c] = 0.f; cvel[c] = 0.f; cnote[c] = pl_noteid[j];
-          held[c] = 0;
-          int r_eff = max(minch[c], R_env);     // getReleaseTime, audioelement.h:1002-1004 (latched at startReleased :836-841)
-          free_at[c] = k_f + r_eff + 17;        // Done1 after r_eff steps, Done2 17 steps later (:738-750)
-        }
-      }
-      // note-changes and note-ons in loudness order, lib.cpp:316-376
-      int n_new = n_played;
-      for (int oi = 0; oi < A; ++oi) {
-        int idx = ord[oi];
-        double new_pitch = pitch[idx];
-        float new_freq = (float)((double)440.f * pow(p.half_tone_ratio, new_pitch - 69.0)); // midi.h:254-264
-        float volume = (float)((double)p.analysis_volume * vol[idx] / (double)0.1f);       // lib.cpp:324
-        int pci = pc[idx];
-        if (pci >= 0) {
-          int c = pl_chan[pci];
-          ctype[c] = RA_CMD_CHANGE; cord[c] = n_ev++; cfreq[c] = new_freq; cvel[c] = volume; cnote[c] = pl_noteid[pci];
-          minch[c] = min_change_for(new_freq, p.sample_rate, 1.f);
-          pl_pitch[pci] = new_pitch;
-        } else {
-          if (volume <= 0) continue;
-          ++st.next_noteid;
-          int c = -1;
-          for (int q = 0; q < P; ++q) if (!held[q] && free_at[q] <= k_f) { c = q; break; } // tryAcquire in channel order, gen.crtp.h:397-405
-          if (c < 0) { ++st.dropped_note_on; continue; }
-          ctype[c] = RA_CMD_ON; cord[c] = n_ev++; cfreq[c] = new_freq; cvel[c] = volume; cnote[c] = st.next_noteid;
-          held[c] = 1;
-          minch[c] = min_change_for(new_freq, p.sample_rate, 1.f);
-          pl_pitch[n_new] = new_pitch; pl_noteid[n_new] = st.next_noteid; pl_chan[n_new] = c; cont[n_new] = 1;
-          ++n_new;
-        }
-      }
-      // remove_dead_notes (stable) + sort_by_current_pitch (stable insertion), algo.cpp:415-440
-      int w = 0;
-      for (int j = 0; j < n_new; ++j) {
-        if (cont[j]) {
-          if (w != j) { pl_pitch[w] = pl_pitch[j]; pl_noteid[w] = pl_noteid[j]; pl_chan[w] = pl_chan[j]; }
-          ++w;
-        }
-      }
-      n_played = w;
-      for (int i = 1; i < n_played; ++i) {
-        double kp = pl_pitch[i]; int64_t kn = pl_noteid[i]; int kc = pl_chan[i];
-        int j = i - 1;
-        while (j >= 0 && kp < pl_pitch[j]) { pl_pitch[j + 1] = pl_pitch[j]; pl_noteid[j + 1] = pl_noteid[j]; pl_chan[j + 1] = pl_chan[j]; --j; }
-        pl_pitch[j + 1] = kp; pl_noteid[j + 1] = kn; pl_chan[j + 1] = kc;
       }
     }
+    // ---- phase 2: loudness order = stable rank sort by key, descending ----
+    for (int i = lane; i < A; i += 64) {
+      float k = key[i];
+      int r = 0;
+      for (int j = 0; j < A; ++j) { float kj = key[j]; r += (kj > k || (kj == k && j < i)) ? 1 : 0; }
+      ord[r] = i;
+    }
     __syncthreads();
-    n_played = __shfl(n_played, 0);
+
+    // ---- phase 3: note-offs for played notes that were not continued, lib.cpp:296-313 ----
+    int n_off = 0;
+    for (int j0 = 0; j0 < n_played; j0 += 64) {
+      int j = j0 + lane;
+      bool is = j < n_played && !cont[j];
+      unsigned long long m = __ballot(is);
+      if (is) {
+        int c = pl_chan[j];
+        ctype[c] = RA_CMD_OFF; cord[c] = n_off + __popcll(m & lower); cfreq[c] = 0.f; cvel[c] = 0.f; cnote[c] = pl_noteid[j];
+        held[c] = 0;
+        int r_eff = max(minch[c], R_env);     // getReleaseTime, audioelement.h:1002-1004 (latched at startReleased :836-841)
+        free_at[c] = k_f + r_eff + 17;        // Done1 after r_eff steps, Done2 17 steps later (:738-750)
+      }
+      n_off += __popcll(m);
+    }
+    __syncthreads();
+
+    // ---- phase 4: channels a note-on may take now, in channel order (tryAcquire loop, gen.crtp.h:397-405) ----
+    int n_free = 0;
+    for (int q0 = 0; q0 < P; q0 += 64) {
+      int q = q0 + lane;
+      bool is = q < P && !held[q] && free_at[q] <= k_f;
+      unsigned long long m = __ballot(is);
+      if (is) free_list[n_free + __popcll(m & lower)] = q;
+      n_free += __popcll(m);
+    }
+    __syncthreads();
+
+    // ---- phase 5: note-changes and note-ons in loudness order, lib.cpp:316-376 ----
+    int ev_base = n_off, cand_base = 0, succ_base = 0;
+    for (int o0 = 0; o0 < A; o0 += 64) {
+      int oi = o0 + lane;
+      bool valid = oi < A;
+      int idx = valid ? ord[oi] : 0;
+      int pci = valid ? pc[idx] : -1;
+      bool tracked = valid && pci >= 0;
+      bool cand = valid && !tracked && !(nv[idx] <= 0);     // `if (volume <= 0) continue;`
+      unsigned long long cm = __ballot(cand);
+      int crank = cand_base + __popcll(cm & lower);
+      bool succ = cand && crank < n_free;                   // else onDroppedNote (gen.crtp.h:407-409)
+      unsigned long long em = __ballot(tracked || succ);
+      int evi = ev_base + __popcll(em & lower);
+      unsigned long long sm = __ballot(succ);
+      int srank = succ_base + __popcll(sm & lower);
+      if (tracked) {
+        int c = pl_chan[pci];
+        ctype[c] = RA_CMD_CHANGE; cord[c] = evi; cfreq[c] = nf[idx]; cvel[c] = nv[idx]; cnote[c] = pl_noteid[pci];
+        minch[c] = nmc[idx];
+        pl_pitch[pci] = pitch[idx];
+      } else if (succ) {
+        int c = free_list[crank];
+        int64_t noteid = st.next_noteid + crank + 1;        // ++next_noteid for every attempted note-on, lib.cpp:350
+        ctype[c] = RA_CMD_ON; cord[c] = evi; cfreq[c] = nf[idx]; cvel[c] = nv[idx]; cnote[c] = noteid;
+        held[c] = 1;
+        minch[c] = nmc[idx];
+        int slot = n_played + srank;
+        pl_pitch[slot] = pitch[idx]; pl_noteid[slot] = noteid; pl_chan[slot] = c; cont[slot] = 1;
+      }
+      cand_base += __popcll(cm); ev_base += __popcll(em); succ_base += __popcll(sm);
+    }
+    st.next_noteid += cand_base;
+    st.dropped_note_on += cand_base - succ_base;
+    const int n_new = n_played + succ_base;
+    __syncthreads();
+
+    // ---- phase 6: remove_dead_notes + sort_by_current_pitch (both stable), algo.cpp:415-440 ----
+    int kept = 0;
+    for (int j0 = 0; j0 < n_new; j0 += 64) {
+      int j = j0 + lane;
+      bool is = j < n_new && cont[j];
+      if (is) {
+        double pj = pl_pitch[j];
+        int r = 0;
+        for (int i = 0; i < n_new; ++i) { double pi = pl_pitch[i]; r += (cont[i] && (pi < pj || (pi == pj && i < j))) ? 1 : 0; }
+        tmp_pitch[r] = pj; tmp_noteid[r] = pl_noteid[j]; tmp_chan[r] = pl_chan[j];
+      }
+      kept += __popcll(__ballot(is));
+    }
+    __syncthreads();
+    n_played = kept;
+    for (int i = lane; i < n_played; i += 64) { pl_pitch[i] = tmp_pitch[i]; pl_noteid[i] = tmp_noteid[i]; pl_chan[i] = tmp_chan[i]; }
 
     RaCmd *out = b.cmd + ((size_t)s * b.frames_cap + fb) * p.Ppad;
     for (int i = lane; i < p.Ppad; i += 64) {
@@ -174,6 +227,6 @@ __global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, i
 
 void ra_launch_track(const RaParams &p, const RaBuffers &b, int64_t f_lo, int64_t n_frames_blk, hipStream_t st) {
   if (n_frames_blk <= 0) return;
-  size_t lds = (size_t)p.maxr * (8 + 8 + 4 + 4 + 4) + (size_t)p.P * (8 + 8 + 8 + 4 * 8 + 8) + 64;
+  size_t lds = (size_t)p.maxr * (8 + 8 + 6 * 4) + (size_t)p.P * (6 * 8 + 10 * 4) + 64;
   hipLaunchKernelGGL(ra_track_kernel, dim3((unsigned)p.n_streams), dim3(64), lds, st, p, b, f_lo, n_frames_blk);
 }

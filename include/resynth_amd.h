@@ -83,6 +83,11 @@ typedef struct ra_config {
   /* capacity of the per-frame pitch list handed from analysis to tracking (the reference's vectors grow
    * on demand, lib.cpp:1102-1112); exceeding it sets RA_EOVERFLOW instead of truncating silently. */
   int32_t max_pitches_per_frame; /* default 512 */
+
+  /* 0 (default): synthesis runs hop-parallel — per-hop channel states come from closed-form jumps, differing from
+   * sample-by-sample stepping at rounding level (~1e-13).  1: one sample-serial launch per stream that follows the
+   * reference's operation order exactly (slow; for bit-level comparisons). */
+  int32_t reference_order;
 } ra_config;
 
 typedef struct ra_context ra_context;

@@ -28,10 +28,13 @@ def sig():
 PARITY_KW = dict(analysis_volume=1.0, stereo_spread=0.0, carrier_volume=0.0, seed=1234)
 
 
+GPU_ONLY_KEYS = ("reference_order", "max_pitches_per_frame")
+
+
 def both_configs(api, oracle, **kw):
-    k = dict(PARITY_KW)
-    k.update(kw)
-    gk = dict(k)
+    gk = dict(PARITY_KW)
+    gk.update(kw)
+    k = {a: v for a, v in gk.items() if a not in GPU_ONLY_KEYS}
     return api.default_config(**gk), k
 
 
@@ -86,10 +89,29 @@ def test_sqmag_matches_oracle(api, oracle, N, kind):
     assert np.all(g[2] == 0)
 
 
-def test_c2_small_partials(api, oracle, sig):
+@pytest.mark.parametrize("reference_order", [0, 1])
+def test_c2_small_partials(api, oracle, sig, reference_order):
     # configs[1] shape at a size the oracle finishes in seconds: 6 streams x 2 s, N=4096, H=1024, P=64
     x = sig.make_streams(6, 96000)
-    check_streams(api, oracle, x)
+    out = check_streams(api, oracle, x, reference_order=reference_order)
+    if reference_order:
+        # the sample-serial kernel follows the oracle's operation order; only libm (sincos/log/pow) ulps differ, so the
+        # float32 outputs agree bit for bit on all but a handful of samples that sit on a rounding boundary
+        ref = np.stack([oracle.run_offline(oracle.default_config(**dict(PARITY_KW, seed=1234 + s)), x[s])[0] for s in range(6)])
+        assert np.mean(out == ref) > 0.9999
+        assert np.max(np.abs(out.astype(np.float64) - ref)) < 1e-7
+
+
+def test_hop_parallel_vs_reference_order(api, sig):
+    # default (closed-form hop jumps + parallel render) against the sample-serial kernel: rounding-level agreement
+    x = np.concatenate([sig.make_streams(3, 120000), sig.make_streams(2, 120000, kind="speech")])
+    outs = []
+    for ro in (0, 1):
+        with api.Context(api.default_config(reference_order=ro, **PARITY_KW), 5, 0) as ctx:
+            outs.append(ctx.process_host(x).astype(np.float64))
+            assert ctx.stats().error_flags == 0
+    assert np.max(np.abs(outs[0] - outs[1])) < 1e-6
+    assert rms(outs[0], outs[1]) < 1e-8
 
 
 def test_speech_like(api, oracle, sig):
@@ -176,18 +198,23 @@ def test_white_noise_many_peaks(api, oracle):
         assert e.value.code == -4    # RA_EOVERFLOW instead of silent truncation
 
 
-def test_block_size_invariance_and_reset(api, sig):
-    # consecutive ra_process calls continue the streams: any split of the input gives the same bits
+@pytest.mark.parametrize("reference_order", [0, 1])
+def test_block_size_invariance_and_reset(api, sig, reference_order):
+    # consecutive ra_process calls continue the streams: any split of the input gives the same result
+    # (same bits in reference order; rounding-level differences when hop states come from closed-form jumps)
     x = sig.make_streams(3, 50000)
-    cfg = api.default_config(**PARITY_KW)
+    cfg = api.default_config(reference_order=reference_order, **PARITY_KW)
     with api.Context(cfg, 3, 0) as ctx:
         whole = ctx.process_host(x)
         ctx.reset()
         cuts = [0, 1, 17, 4097, 4098, 5000, 5001, 9000, 21111, 21127, 50000]
-        parts = [ctx.process_host(x[:, a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
-        assert np.array_equal(np.concatenate(parts, axis=1), whole)
+        parts = np.concatenate([ctx.process_host(x[:, a:b]) for a, b in zip(cuts[:-1], cuts[1:])], axis=1)
+        if reference_order:
+            assert np.array_equal(parts, whole)
+        else:
+            assert np.max(np.abs(parts.astype(np.float64) - whole)) < 1e-6
         ctx.reset()
-        assert np.array_equal(ctx.process_host(x), whole)
+        assert np.array_equal(ctx.process_host(x), whole)   # same call pattern -> same bits
 
 
 def test_streams_are_independent(api, sig):
@@ -340,7 +367,7 @@ def test_full_size_properties(api, oracle, sig):
         ctx.process_device(v2.data_ptr(), 0, n - half, o2.data_ptr())
         ctx.synchronize()
         assert ctx.stats().error_flags == 0
-    assert torch.equal(torch.cat([o1, o2], dim=1), first)
+    assert float((torch.cat([o1, o2], dim=1).double() - first.double()).abs().max()) < 1e-6
     assert float(first.abs().max()) < 4.0 and float(first.double().pow(2).mean().sqrt()) > 1e-3
     hv = voice.cpu().numpy()
     for s in (0, 101, 255):
