@@ -58,15 +58,18 @@ __device__ inline SynConst syn_const(const RaParams &p, int s) {
 }
 
 // samples [t, seg_end) of stream s: step every active channel, mix, write.  Workgroup-uniform control flow.
+template <bool FAST>
 __device__ inline void render_range(Chan &c, const SynLds &L, const SynConst &k, const RaParams &p, int s, int l, int64_t t, int64_t seg_end, int64_t t0,
                                     int64_t n, const double *__restrict__ mix, float *__restrict__ out, double *__restrict__ out_d) {
   const int Ppad = p.Ppad, stride1 = Ppad + 1;
+  const double inv_dur = 1.0 / k.dur;
   while (t < seg_end) {
     const int m = (int)min((int64_t)RA_N_FRAMES_PER_BUFFER, seg_end - t);
     for (int i = 0; i < m; ++i) {
       double v = 0.0;
       if (rt_active(c)) { // ImplCRTP::compute, gen.crtp.h:352-371
-        chan_step(c, k.ep, k.dur, k.max_filter_inc, 0);
+        if (FAST) chan_step_fast(c, k.ep, k.dur, inv_dur, k.max_filter_inc);
+        else chan_step(c, k.ep, k.dur, k.max_filter_inc, 0);
         if (rt_active(c)) v = c.vol * ((c.alias * c.cim) * c.value); // :1135 over :231 over :2424
       }
       L.tile[i * stride1 + l] = c.gL * v;        // StereoPanned::imag(0), :1382-1384
@@ -86,6 +89,125 @@ __device__ inline void render_range(Chan &c, const SynLds &L, const SynConst &k,
         const int64_t rel = (t - t0) + fr;
         if (mix) acc += mix[rel];  // the vocoder compute runs after the synth compute (lib.cpp:1353,1377)
         if (out) out[((size_t)s * n + rel) * 2 + ch] = (float)acc; // simple_audio_context.h:105-109
+        if (out_d) out_d[((size_t)s * n + rel) * 2 + ch] = acc;
+      }
+    }
+    __syncthreads();
+    t += m;
+  }
+}
+
+// ---- regime-based renderer (hop-parallel path) ------------------------------------------------------------------------
+// Between two transitions (envelope stage change, glide end, first step of a note) a channel's step is a handful of
+// multiply-adds with per-stretch constants.  Each lane caches those constants; the wave takes the general step only on
+// samples where one of its lanes is at a transition (~1 % of samples), which keeps the common path free of the state
+// machine's branches, divisions and sincos (213 -> ~50 VALU instructions per sample).
+struct Regime {
+  double dv;                        // envelope value increment per step
+  double base, slope, alpha, beta;  // glide: inc = base + slope * cur ; cur' = alpha * cur + beta  (steady: slope 0, alpha 1, beta 0)
+  int steps_left;                   // envelope steps before its next transition
+  int pending;                      // steps taken since the envelope counters were last brought up to date
+  bool active, gliding, irregular;  // irregular: the next step must be the general one
+  bool hi;                          // the glide passes above fs/8: the anti-aliasing gain follows the increment
+};
+
+__device__ inline void regime_setup(const Chan &c, const SynConst &k, double inv_dur, Regime &r) {
+  r.pending = 0;
+  r.active = rt_active(c);
+  r.dv = 0; r.base = c.inc; r.slope = 0; r.alpha = 1; r.beta = 0; r.steps_left = 0x7fffffff; r.gliding = false; r.irregular = false; r.hi = false;
+  if (!r.active) return;
+  r.steps_left = env_regular_steps(c, k.ep);
+  switch (c.state) {
+    case ENV_PRESSED:
+      if (c.ahdstate >= 0) {
+        double tmf = c.ahdstate == 0 ? 1.0 : c.ahdstate == 1 ? 0.0 : (double)k.ep.SMinusOne;
+        r.dv = tmf / (double)env_max_counter(c, k.ep);
+      }
+      break;
+    case ENV_RELEASED: r.dv = -c.top / (double)max(c.minch, k.ep.R); break;
+    default: break;
+  }
+  if (!(c.flags & FL_HAS_VOL) || !(c.flags & FL_HAS_FRES)) { r.irregular = true; return; }
+  const bool steady = c.fres == c.to;
+  const double f_end = c.from + (c.to - c.from) * (k.dur / k.dur);
+  const bool clamped = !steady && c.cur == k.dur && c.fres == f_end;
+  double lo;
+  if (steady || clamped) { r.base = c.fres; lo = fabs(c.fres); }
+  else {
+    if (c.to == c.from) { r.irregular = true; return; }
+    r.gliding = true;
+    r.slope = (c.to - c.from) * inv_dur;
+    r.base = c.from;
+    r.alpha = 1.0 + c.C * r.slope;
+    r.beta = c.C * (c.from + 0.5 * r.slope);
+    lo = fmin(fabs(c.from + r.slope * c.cur), fabs(f_end));
+    r.hi = fmax(fabs(c.from), fabs(c.to)) > 0.25 || c.from <= 0. || c.to <= 0.;
+  }
+  if (c.vol != c.target) { // the volume filter's coefficient must stay constant over the stretch (cf. chan_jump)
+    double want = fmin(k.max_filter_inc, lo);
+    if (!(c.finit == want && (!r.gliding || lo >= k.max_filter_inc))) r.irregular = true;
+  }
+}
+
+__device__ inline void render_range_fast(Chan &c, const SynLds &L, const SynConst &k, const RaParams &p, int s, int l, int64_t t, int64_t seg_end,
+                                         int64_t t0, int64_t n, const double *__restrict__ mix, float *__restrict__ out, double *__restrict__ out_d) {
+  const int Ppad = p.Ppad, stride1 = Ppad + 1;
+  const double inv_dur = 1.0 / k.dur;
+  Regime r;
+  regime_setup(c, k, inv_dur, r);
+  while (t < seg_end) {
+    const int m = (int)min((int64_t)RA_N_FRAMES_PER_BUFFER, seg_end - t);
+    for (int i = 0; i < m; ++i) {
+      double v = 0.0;
+      const bool irr = r.active && (r.irregular || r.steps_left == 0 || (r.gliding && c.cur + 0.5 > k.dur));
+      if (__any(irr)) {
+        if (irr) {
+          if (r.pending) env_jump(c, k.ep, r.pending);
+          chan_step_fast(c, k.ep, k.dur, inv_dur, k.max_filter_inc);
+          if (rt_active(c)) v = c.vol * ((c.alias * c.cim) * c.value);
+          regime_setup(c, k, inv_dur, r);
+        }
+      }
+      if (!irr && r.active) {
+        const double f = fma(r.slope, c.cur, r.base);
+        if (r.gliding) {
+          c.fres = f;
+          c.cur = fma(r.alpha, c.cur, r.beta);
+          const double d = M_PI * (f - c.inc);
+          const double d2 = d * d;
+          const double sd = d * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
+          const double cd = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
+          const double mr = fma(c.mre, cd, -(c.mim * sd)), mi = fma(c.mre, sd, c.mim * cd);
+          c.mre = mr; c.mim = mi; c.inc = f;
+          if (r.hi) c.alias = alias_mult(f);
+        }
+        const double re = fma(c.cre, c.mre, -(c.cim * c.mim));
+        const double im = fma(c.cre, c.mim, c.cim * c.mre);
+        const double g = 0.5 * (3.0 - fma(re, re, im * im));
+        c.cre = re * g; c.cim = im * g;
+        c.y = fma(c.k, c.target - c.y, c.y);
+        c.vol = c.y;
+        c.value += r.dv;
+        ++r.pending; --r.steps_left;
+        v = c.vol * ((c.alias * c.cim) * c.value);
+      }
+      L.tile[i * stride1 + l] = c.gL * v;
+      L.tile[(16 + i) * stride1 + l] = c.gR * v;
+    }
+    __syncthreads();
+    if (l < 64) {
+      const int fr = l & 15, ch = (l >> 4) & 1, half = l >> 5;
+      double acc = 0.0;
+      if (fr < m) {
+        const double *row = L.tile + (ch * 16 + fr) * stride1;
+        const int c0 = half * (Ppad >> 1), c1 = c0 + (Ppad >> 1);
+        for (int q = c0; q < c1; ++q) acc += row[q];
+      }
+      acc += __shfl_down(acc, 32);
+      if (l < 32 && fr < m) {
+        const int64_t rel = (t - t0) + fr;
+        if (mix) acc += mix[rel];
+        if (out) out[((size_t)s * n + rel) * 2 + ch] = (float)acc;
         if (out_d) out_d[((size_t)s * n + rel) * 2 + ch] = acc;
       }
     }
@@ -172,7 +294,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_serial_kernel(RaPara
   int64_t t = t0;
   for (int64_t fb = 0; fb <= n_frames_blk; ++fb) {
     const int64_t seg_end = (fb < n_frames_blk) ? ra_fire_sample(p.N, p.H, f_lo + fb) : t0 + n;
-    render_range(c, L, k, p, s, l, t, seg_end, t0, n, mix, out, out_d);
+    render_range<false>(c, L, k, p, s, l, t, seg_end, t0, n, mix, out, out_d);
     t = seg_end;
     if (fb == n_frames_blk) break;
     const RaCmd cmd = b.cmd[((size_t)s * b.frames_cap + fb) * Ppad + l];
@@ -217,7 +339,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_render_kernel(RaPara
   load_chan(c, b.seg_sd + seg * SD_COUNT * Ppad, b.seg_si + seg * SI_COUNT * Ppad, Ppad, l);
   const SynConst k = syn_const(p, s);
   const double *mix = (p.voc_enabled && b.voc_mix) ? b.voc_mix + (size_t)s * n : nullptr;
-  render_range(c, L, k, p, s, l, seg_begin, seg_end, t0, n, mix, out, out_d);
+  render_range_fast(c, L, k, p, s, l, seg_begin, seg_end, t0, n, mix, out, out_d);
 }
 
 } // namespace
