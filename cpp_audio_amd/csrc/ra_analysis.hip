@@ -210,39 +210,74 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   }
   __syncthreads();
 
-  // ---- 5. the sequential part of the pipeline (tens of items): one lane ---------------------------
-  if (tid == 0) {
-    const int K = scan[T];
-    const int cap = 2 * p.maxr;
-    int err = 0;
-    // aggregate_pitches + reduce_pitches (algo.cpp:124-184, PonderateByVolume / SumVolumes)
-    int R = 0;
-    bool have = false;
-    double mn = 0, mx = 0, sumV = 0, sumPV = 0;
-    auto close_interval = [&]() {
-      if (!(sumV < p.min_volume)) {
-        if (R < cap) listA[R++] = make_double2(sumPV / sumV, sumV); else err = 1;
-      }
-    };
-    for (int i = 0; i < K; ++i) {
-      double pt = z[i].y, v = z[(M >> 1) + i].y;
-      if (have) {
-        double hi = fmax(fmax(mn, mx), pt), lo = fmin(fmin(mn, mx), pt);
-        if (hi - lo > p.nearby) { close_interval(); have = false; }
-      }
-      if (!have) { mn = mx = pt; sumV = 0; sumPV = 0; have = true; }
-      else { mn = fmin(mn, pt); mx = fmax(mx, pt); }
-      sumV += v;
-      sumPV += pt * v;
+  // ---- 5. aggregate_pitches + reduce_pitches (algo.cpp:124-184, PonderateByVolume / SumVolumes) -------------------
+  // Pitches ascend, so an interval opened at peak i0 runs up to the first peak j with pitch[j] - pitch[i0] > nearby:
+  //  5a every peak finds that j by binary search (nxt, kept in the now unused .x half of its slot)
+  //  5b one lane follows the nxt chain from peak 0 to list the interval starts (tens to a few hundred hops)
+  //  5c each interval is summed by one thread in index order (the reference's summation order) and kept if its volume
+  //     reaches min_volume; kept intervals are compacted in order with a block scan
+  const int K = scan[T];
+  const int Mh = M >> 1;
+  __syncthreads();
+  for (int i = tid; i < K; i += T) {
+    const double pi0 = z[i].y;
+    int lo = i + 1, hi = K;
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      if (z[mid].y - pi0 > p.nearby) hi = mid; else lo = mid + 1;
     }
-    if (have) close_interval();
+    z[i].x = (double)lo;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int R = 0;
+    for (int i = 0; i < K; i = (int)z[i].x) z[Mh + R++].x = (double)i;
+    z[Mh + R].x = (double)K;   // R <= K <= Mh - 1, so slot Mh + R exists
+    scan[T] = R;
+  }
+  __syncthreads();
+  const int R = scan[T];
+  const int chunkR = (R + T - 1) / T;
+  const int r0 = min(R, tid * chunkR), r1 = min(R, r0 + chunkR);
+  auto interval = [&](int r, double &sumV, double &sumPV) {
+    const int i0 = (int)z[Mh + r].x, i1 = (int)z[Mh + r + 1].x;
+    sumV = 0; sumPV = 0;
+    for (int i = i0; i < i1; ++i) { double pt = z[i].y, v = z[Mh + i].y; sumV += v; sumPV += pt * v; }
+  };
+  {
+    int kept = 0;
+    for (int r = r0; r < r1; ++r) { double sv, spv; interval(r, sv, spv); kept += !(sv < p.min_volume) ? 1 : 0; }
+    scan[tid] = kept;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int i = 0; i < T; ++i) { int v = scan[i]; scan[i] = acc; acc += v; }
+    scan[T] = acc;
+  }
+  __syncthreads();
+  const int cap = 2 * p.maxr;
+  int pos = scan[tid];
+  const int Rk = scan[T];
+  __syncthreads(); // scan aliases listA: everyone has its offset before the list is written
+  for (int r = r0; r < r1; ++r) {
+    double sv, spv;
+    interval(r, sv, spv);
+    if (!(sv < p.min_volume)) { if (pos < cap) listA[pos] = make_double2(spv / sv, sv); ++pos; }
+  }
+  __syncthreads();
 
+  // ---- 6. shift / harmonize / autotune on the reduced list (tens of items): one lane ------------------------------
+  int *pub = reinterpret_cast<int *>(z); // [0] = A, [1] = which list holds the result   (z is free now)
+  if (tid == 0) {
+    int err = Rk > cap ? 1 : 0;
+    int Rn = min(Rk, cap);
     double2 *cur = listA, *oth = listB;
-    shift_list(cur, R, p.shift_pre);
-    R = harmonize_list(cur, oth, R, cap, p.harm_pre, &err);
+    shift_list(cur, Rn, p.shift_pre);
+    Rn = harmonize_list(cur, oth, Rn, cap, p.harm_pre, &err);
     // autotune_pitches, algo.cpp:191-229
     int A = 0;
-    for (int i = 0; i < R; ++i) {
+    for (int i = 0; i < Rn; ++i) {
       double2 pv = cur[i];
       double t;
       bool has;
@@ -262,15 +297,22 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
     A = harmonize_list(cur, oth, A, cap, p.harm_post, &err);
     if (A > p.maxr) { err = 1; A = p.maxr; }
     if (err) atomicOr(b.error_flags, RA_ERR_OVERFLOW);
-
-    size_t base = ((size_t)s * b.frames_cap + fb) * p.maxr;
-    for (int i = 0; i < A; ++i) {
-      b.pl_pitch[base + i] = cur[i].x;
-      b.pl_vol[base + i] = cur[i].y;
-      // order_pitches_by_perceived_loudness key, lib.cpp:1717-1727 (a float vector, algo.cpp:380-395)
-      b.pl_key[base + i] = (float)(cur[i].y / (double)equal_loudness_db(b.loud_pitches, b.loud_elv, cur[i].x));
-    }
+    pub[0] = A;
+    pub[1] = (cur == listA) ? 0 : 1;
     b.pl_count[(size_t)s * b.frames_cap + fb] = A;
+  }
+  __syncthreads();
+  {
+    const int A = pub[0];
+    const double2 *cur = pub[1] ? listB : listA;
+    const size_t base = ((size_t)s * b.frames_cap + fb) * p.maxr;
+    for (int i = tid; i < A; i += T) {
+      double2 pv = cur[i];
+      b.pl_pitch[base + i] = pv.x;
+      b.pl_vol[base + i] = pv.y;
+      // order_pitches_by_perceived_loudness key, lib.cpp:1717-1727 (a float vector, algo.cpp:380-395)
+      b.pl_key[base + i] = (float)(pv.y / (double)equal_loudness_db(b.loud_pitches, b.loud_elv, pv.x));
+    }
   }
 }
 

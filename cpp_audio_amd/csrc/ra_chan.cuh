@@ -300,16 +300,43 @@ __device__ inline void env_jump(Chan &c, const RaEnvParams &p, int j) { // j <= 
   }
 }
 
+// small-argument elementary functions (the glide's per-step growth x = ln(to/from)/dur is ~1e-5): short series instead of
+// libm calls keep the latency-bound propagate kernel short; outside their range they defer to libm
+__device__ inline double expm1_small(double z) {
+  if (!(fabs(z) < 0.25)) return expm1(z);
+  double r = 1.0; // z (1 + z/2 (1 + z/3 (... (1 + z/14))))   truncation < 0.25^15/15! ~ 1e-21
+#pragma unroll
+  for (int k = 14; k >= 2; --k) r = fma(z * (1.0 / k), r, 1.0);
+  return z * r;
+}
+__device__ inline double log1p_small(double x) {
+  if (!(fabs(x) < 0.1)) return log1p(x);
+  const double s = x / (2.0 + x), s2 = s * s; // log1p(x) = 2 atanh(x / (2 + x))
+  double q = 1.0 / 13.0;
+  q = fma(q, s2, 1.0 / 11.0); q = fma(q, s2, 1.0 / 9.0); q = fma(q, s2, 1.0 / 7.0); q = fma(q, s2, 1.0 / 5.0); q = fma(q, s2, 1.0 / 3.0);
+  q = fma(q, s2, 1.0);
+  return 2.0 * s * q;
+}
+
 __device__ inline void osc_rotate(Chan &c, double sum_inc) { // cur *= e^{i pi sum_inc}
   double r = sum_inc - 2.0 * rint(0.5 * sum_inc); // exact reduction to [-1, 1]
   double sn, cs;
-  sincos(M_PI * r, &sn, &cs);
+  sincospi(r, &sn, &cs);
   double re = c.cre * cs - c.cim * sn, im = c.cre * sn + c.cim * cs;
   double g = 0.5 * (3.0 - (re * re + im * im));
   c.cre = re * g; c.cim = im * g;
 }
+__device__ inline void osc_set_inc_jump(Chan &c, double f) { // osc_set_inc with the exact-pi sincospi
+  if (c.inc == f) return;
+  c.inc = f;
+  double sn, cs;
+  sincospi(f, &sn, &cs);
+  c.mre = cs; c.mim = sn;
+  c.alias = (f > 0. && f <= 0.25) ? 1.0 : alias_mult(f);
+}
 
 __device__ inline void chan_jump(Chan &c, const RaEnvParams &p, double dur, double max_filter_inc, int64_t n) {
+  const double inv_dur = 1.0 / dur;
   while (n > 0 && rt_active(c)) {
     bool serial = !(c.flags & FL_HAS_VOL);
     int j = env_regular_steps(c, p);
@@ -319,47 +346,50 @@ __device__ inline void chan_jump(Chan &c, const RaEnvParams &p, double dur, doub
     const double f_end = c.from + (c.to - c.from) * (dur / dur);
     const bool clamped = !steady && (c.flags & FL_HAS_FRES) && c.cur == dur && c.fres == f_end;
     const bool gliding = !steady && !clamped;
-    if (gliding && (c.to == c.from || c.cur + (double).5f > dur || !(c.flags & FL_HAS_FRES))) serial = true;
-    if (serial) { chan_step(c, p, dur, max_filter_inc, 0); --n; continue; }
+    if (gliding && (c.to == c.from || c.cur + 0.5 > dur || !(c.flags & FL_HAS_FRES))) serial = true;
+    if (serial) { chan_step_fast(c, p, dur, inv_dur, max_filter_inc); --n; continue; }
     if ((int64_t)j > n) j = (int)n;
 
     double sum_inc, fres_last = c.fres, u_j = c.cur;
     if (!gliding) {
       sum_inc = (double)j * c.fres; // constant increment (== to when steady)
     } else {
-      const double x = c.C * (c.to - c.from) / dur;            // alpha - 1
+      const double slope = (c.to - c.from) * inv_dur;
+      const double x = c.C * slope;                            // alpha - 1
       const double beta = c.C * c.from + 0.5 * x;
-      const double Lg = log1p(x);
+      const double Lg = log1p_small(x);
       const double A = c.cur + beta / x;
-      auto u_at = [&](int m) -> double { return c.cur + expm1((double)m * Lg) * A; };
-      if (u_at(j - 1) + (double).5f > dur) { // the glide ends inside: jump only up to the first clamped step
-        double B = dur - (double).5f - c.cur;
-        double est = log1p(B / A) / Lg;
+      const double lim = dur - 0.5;                            // a step with cur > lim clamps
+      // E_m = alpha^m - 1 ; u_m = cur + E_m A
+      double Ej = expm1_small((double)j * Lg);
+      double Ejm1 = (Ej - x) / (1.0 + x);
+      if (c.cur + Ejm1 * A > lim) { // the glide ends inside: jump only up to the first clamped step
+        double est = log1p_small((lim - c.cur) / A) / Lg;
         int ms = (est == est && est < 2.0e9 && est >= 0.0) ? (int)est + 1 : 1;
-        if (ms > j) ms = j;
-        if (ms < 1) ms = 1;
-        while (ms > 1 && u_at(ms - 1) + (double).5f > dur) --ms;
-        while (ms < j && !(u_at(ms) + (double).5f > dur)) ++ms;
-        j = ms;
+        ms = max(1, min(ms, j));
+        double Em = expm1_small((double)ms * Lg), Emm1 = (Em - x) / (1.0 + x);
+        while (ms > 1 && c.cur + Emm1 * A > lim) { --ms; Em = Emm1; Emm1 = (Em - x) / (1.0 + x); }
+        while (ms < j && !(c.cur + Em * A > lim)) { ++ms; Emm1 = Em; Em = fma(Em, x, Em + x); }
+        j = ms; Ej = Em; Ejm1 = Emm1;
       }
-      const double u_jm1 = u_at(j - 1);
-      u_j = u_at(j);
-      fres_last = c.from + (c.to - c.from) * (u_jm1 / dur);
+      const double u_jm1 = c.cur + Ejm1 * A;
+      u_j = c.cur + Ej * A;
+      fres_last = c.from + slope * u_jm1;
       // inc_m = (u_{m+1} - u_m) / C - (to - from) / (2 dur)   (InterpolatedFreq::step, audioelement.h:2781-2785)
-      sum_inc = (u_j - c.cur) / c.C - (double)j * 0.5 * (c.to - c.from) / dur;
+      sum_inc = (u_j - c.cur) / c.C - (double)j * 0.5 * slope;
     }
     // volume filter: needs a constant coefficient over the stretch
     if (c.vol != c.target) {
-      double lo = gliding ? fmin(fabs(c.from + (c.to - c.from) * (c.cur / dur)), fabs(fres_last)) : fabs(c.fres);
+      double lo = gliding ? fmin(fabs(c.from + (c.to - c.from) * (c.cur * inv_dur)), fabs(fres_last)) : fabs(c.fres);
       double want = fmin(max_filter_inc, lo);
       bool ok = (c.finit == want) && (!gliding || lo >= max_filter_inc);
-      if (!ok) { chan_step(c, p, dur, max_filter_inc, 0); --n; continue; }
-      double q = exp((double)j * log1p(-c.k));
+      if (!ok) { chan_step_fast(c, p, dur, inv_dur, max_filter_inc); --n; continue; }
+      double q = exp((double)j * log1p_small(-c.k));
       c.y = c.target + (c.y - c.target) * q;
       c.vol = c.y;
     }
     env_jump(c, p, j);
-    if (gliding) { c.cur = u_j; c.fres = fres_last; osc_set_inc(c, fres_last); }
+    if (gliding) { c.cur = u_j; c.fres = fres_last; osc_set_inc_jump(c, fres_last); }
     osc_rotate(c, sum_inc);
     n -= j;
   }
