@@ -155,8 +155,9 @@ __device__ inline void render_range_fast(Chan &c, const SynLds &L, const SynCons
   const double inv_dur = 1.0 / k.dur;
   Regime r;
   regime_setup(c, k, inv_dur, r);
+  constexpr int TD = 8; // tile depth: 16 rows x (Ppad + 1) doubles of LDS per workgroup -> up to 4 waves per SIMD stay resident
   while (t < seg_end) {
-    const int m = (int)min((int64_t)RA_N_FRAMES_PER_BUFFER, seg_end - t);
+    const int m = (int)min((int64_t)TD, seg_end - t);
     for (int i = 0; i < m; ++i) {
       double v = 0.0;
       const bool irr = r.active && (r.irregular || r.steps_left == 0 || (r.gliding && c.cur + 0.5 > k.dur));
@@ -192,19 +193,20 @@ __device__ inline void render_range_fast(Chan &c, const SynLds &L, const SynCons
         v = c.vol * ((c.alias * c.cim) * c.value);
       }
       L.tile[i * stride1 + l] = c.gL * v;
-      L.tile[(16 + i) * stride1 + l] = c.gR * v;
+      L.tile[(TD + i) * stride1 + l] = c.gR * v;
     }
     __syncthreads();
-    if (l < 64) {
-      const int fr = l & 15, ch = (l >> 4) & 1, half = l >> 5;
+    if (l < 64) { // 16 outputs (8 frames x 2) x 4 channel quarters
+      const int fr = l & (TD - 1), ch = (l >> 3) & 1, quarter = l >> 4;
       double acc = 0.0;
       if (fr < m) {
-        const double *row = L.tile + (ch * 16 + fr) * stride1;
-        const int c0 = half * (Ppad >> 1), c1 = c0 + (Ppad >> 1);
+        const double *row = L.tile + (ch * TD + fr) * stride1;
+        const int c0 = quarter * (Ppad >> 2), c1 = c0 + (Ppad >> 2);
         for (int q = c0; q < c1; ++q) acc += row[q];
       }
       acc += __shfl_down(acc, 32);
-      if (l < 32 && fr < m) {
+      acc += __shfl_down(acc, 16);
+      if (l < 16 && fr < m) {
         const int64_t rel = (t - t0) + fr;
         if (mix) acc += mix[rel];
         if (out) out[((size_t)s * n + rel) * 2 + ch] = (float)acc;
@@ -353,6 +355,7 @@ void ra_launch_synth(const RaParams &p, const RaBuffers &b, int64_t t0, int64_t 
     return;
   }
   hipLaunchKernelGGL(ra_synth_propagate_kernel, dim3((unsigned)p.n_streams), dim3((unsigned)p.Ppad), lds, st, p, b, t0, n, f_lo, n_frames_blk);
-  hipLaunchKernelGGL(ra_synth_render_kernel, dim3((unsigned)(n_frames_blk + 1), (unsigned)p.n_streams), dim3((unsigned)p.Ppad), lds, st, p, b, t0, n, f_lo,
-                     n_frames_blk, d_out, d_out_d);
+  const size_t lds_render = (size_t)16 * (p.Ppad + 1) * sizeof(double); // the 8-frame output tile only
+  hipLaunchKernelGGL(ra_synth_render_kernel, dim3((unsigned)(n_frames_blk + 1), (unsigned)p.n_streams), dim3((unsigned)p.Ppad), lds_render, st, p, b, t0, n,
+                     f_lo, n_frames_blk, d_out, d_out_d);
 }
