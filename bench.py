@@ -163,7 +163,7 @@ def main():
 
     result = None
     if rank == 0:
-        synth_ms = kms["synth"] / max(calls, 1)
+        synth_ms = (kms["propagate"] + kms["render"]) / max(calls, 1)
         dom = max(kms, key=kms.get)
         dom_ms = kms[dom] / max(calls, 1)
         algo_bytes = ALGO_BYTES_PER_FRAME * frames_per_step_gpu
@@ -179,7 +179,8 @@ def main():
                        "streams_per_gpu": S, "frames_per_stream_per_step": n, "sharding": f"streams x{world}, no collective"},
             "x_realtime_per_stream": value / (sr * S * world),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": {"analysis": "ra_analysis_kernel", "track": "ra_track_kernel", "synth": "ra_synth_kernel",
+                         "traffic": None, "kernel": {"analysis": "ra_analysis_kernel", "track": "ra_track_kernel", "vocoder": "ra_voc_*_kernel",
+                                                     "propagate": "ra_synth_propagate_kernel", "render": "ra_synth_render_kernel",
                                                      "history": "ra_roll_history_kernel"}[dom],
                          "kernel_ms_per_launch": dom_ms, "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "path is fp64-VALU / serial-latency bound (SURVEY.md §8d): see valu"},

@@ -62,7 +62,7 @@ EXPORTED_SYMBOLS = [
     "ra_last_error", "ra_device_count", "ra_default_config", "ra_even_window_size_frames", "ra_window_center_stride_frames",
     "ra_create", "ra_destroy", "ra_reset", "ra_set_hip_stream", "ra_process_device", "ra_process_host", "ra_synchronize",
     "ra_feed", "ra_compute", "ra_get_stats", "ra_get_events", "ra_get_frame_pitches", "ra_resynth_notes", "ra_sqmag",
-    "ra_set_profiling", "ra_get_kernel_ms",
+    "ra_set_profiling", "ra_get_kernel_ms", "ra_render_note",
 ]
 
 _lib = None
@@ -187,11 +187,11 @@ class Context:
         _check(lib().ra_set_profiling(self._h, 1 if enable else 0))
 
     def kernel_ms(self):
-        """({'analysis','track','vocoder','synth','history'} -> accumulated ms, number of calls)."""
-        ms = np.zeros(5, np.float64)
+        """({'analysis','track','vocoder','propagate','render','history'} -> accumulated ms, number of calls)."""
+        ms = np.zeros(6, np.float64)
         calls = C.c_int64(0)
         _check(lib().ra_get_kernel_ms(self._h, _p(ms), C.byref(calls)))
-        return dict(zip(("analysis", "track", "vocoder", "synth", "history"), ms.tolist())), calls.value
+        return dict(zip(("analysis", "track", "vocoder", "propagate", "render", "history"), ms.tolist())), calls.value
 
     def stats(self):
         s = RaStats()

@@ -36,9 +36,9 @@ struct ra_context {
   double *dbg_sqmag = nullptr;
   // optional per-kernel timing with HIP events on the launch stream (ra_set_profiling)
   bool profiling = false;
-  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool ev_pending = false;
-  double kernel_ms[5] = {0, 0, 0, 0, 0}; // analysis, track, vocoder, synth, history
+  double kernel_ms[6] = {0, 0, 0, 0, 0, 0}; // analysis, track, vocoder, propagate, render, history
   int64_t kernel_calls = 0;
 };
 
@@ -475,8 +475,8 @@ void frames_in_block(const RaParams &p, int64_t t0, int64_t n, int64_t &f_lo, in
 
 int resolve_timing(ra_context *c) {
   if (!c->ev_pending) return RA_OK;
-  HIP_TRY(hipEventSynchronize(c->ev[5]));
-  for (int i = 0; i < 5; ++i) {
+  HIP_TRY(hipEventSynchronize(c->ev[6]));
+  for (int i = 0; i < 6; ++i) {
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
     c->kernel_ms[i] += ms;
@@ -503,10 +503,10 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
   if (prof) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
   if (p.voc_enabled) ra_launch_vocoder(p, c->b, d_voice, d_carrier, c->t, n, c->stream);
   if (prof) HIP_TRY(hipEventRecord(c->ev[3], c->stream));
-  ra_launch_synth(p, c->b, c->t, n, f_lo, nfb, d_out, d_out_d, c->cfg.reference_order, c->stream);
-  if (prof) HIP_TRY(hipEventRecord(c->ev[4], c->stream));
+  ra_launch_synth(p, c->b, c->t, n, f_lo, nfb, d_out, d_out_d, c->cfg.reference_order, prof ? c->ev[4] : nullptr, c->stream);
+  if (prof) HIP_TRY(hipEventRecord(c->ev[5], c->stream));
   ra_launch_roll_history(p, c->b, d_voice, n, c->stream);
-  if (prof) { HIP_TRY(hipEventRecord(c->ev[5], c->stream)); c->ev_pending = true; }
+  if (prof) { HIP_TRY(hipEventRecord(c->ev[6], c->stream)); c->ev_pending = true; }
   HIP_TRY(hipGetLastError());
   c->last_f_lo = f_lo; c->last_nfb = nfb; c->last_n = n; c->last_t0 = c->t;
   c->t += n;
@@ -609,7 +609,7 @@ void ra_destroy(ra_context *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (void *p : c->allocs) (void)hipFree(p);
-  for (int i = 0; i < 6; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  for (int i = 0; i < 7; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   delete c;
 }
 
@@ -630,21 +630,21 @@ int ra_set_hip_stream(ra_context *c, void *hip_stream) {
 int ra_set_profiling(ra_context *c, int32_t enable) {
   if (!c) return fail(RA_EINVAL, "null context");
   HIP_TRY(hipSetDevice(c->device));
-  if (enable && !c->ev[0]) for (int i = 0; i < 6; ++i) HIP_TRY(hipEventCreate(&c->ev[i]));
+  if (enable && !c->ev[0]) for (int i = 0; i < 7; ++i) HIP_TRY(hipEventCreate(&c->ev[i]));
   int r = resolve_timing(c);
   if (r) return r;
   c->profiling = enable != 0;
-  for (int i = 0; i < 5; ++i) c->kernel_ms[i] = 0;
+  for (int i = 0; i < 6; ++i) c->kernel_ms[i] = 0;
   c->kernel_calls = 0;
   return RA_OK;
 }
 
-int ra_get_kernel_ms(ra_context *c, double *ms5, int64_t *calls) {
-  if (!c || !ms5) return fail(RA_EINVAL, "null argument");
+int ra_get_kernel_ms(ra_context *c, double *ms6, int64_t *calls) {
+  if (!c || !ms6) return fail(RA_EINVAL, "null argument");
   HIP_TRY(hipSetDevice(c->device));
   int r = resolve_timing(c);
   if (r) return r;
-  for (int i = 0; i < 5; ++i) ms5[i] = c->kernel_ms[i];
+  for (int i = 0; i < 6; ++i) ms6[i] = c->kernel_ms[i];
   if (calls) *calls = c->kernel_calls;
   return RA_OK;
 }
@@ -829,6 +829,58 @@ int ra_sqmag(const float *h_windows, int32_t n_windows, int32_t window_size, int
   return r;
 }
 
+// One note on one driver-(A) element, starting from a given oscillator phasor.  This is what the element duck-type shim
+// (cpp_audio_amd/host/resynth_amd.hpp: AmdElement) renders when the reference's manual loop first steps an element after
+// forgetPastSignals / setAngleIncrements / setVolumeTarget / setAHDSR / onKeyPressed(0) / onKeyReleased(delay)
+// (include/resynth.hpp:83-96).  Returns the number of frames during which the element is RT-active.
+int64_t ra_render_note(double angle_increment, double volume, const ra_ahdsr *env, int32_t release_delay, int32_t next_min_change_before,
+                       int32_t sample_rate, int32_t device, double *phase_re_im, double *h_out, int64_t cap) {
+  if (!env || !phase_re_im) return fail(RA_EINVAL, "null argument");
+  if (release_delay < 1 || sample_rate < 1000) return fail(RA_EINVAL, "bad release delay / sampling rate");
+  (void)next_min_change_before; // forgetPastSignals latches the previous note's value, but every stage re-latches before using it
+  RaEnvParams ep;
+  { // setAHDSR, audioelement.h:923-952
+    int min_dt = sample_rate / 1000;
+    bool hasDecay = env->sustain < 0.999999;
+    ep.SMinusOne = hasDecay ? std::min(std::max(env->sustain, 0.f), 1.f) - 1.f : 0.f;
+    ep.A = std::max(env->attack, min_dt);
+    ep.H = std::max(env->hold, 0);
+    ep.D = hasDecay ? std::max(env->decay, min_dt) : 0;
+    ep.R = std::max(env->release, min_dt);
+  }
+  double period = (angle_increment == 0.) ? 1. : 2. / std::fabs(angle_increment);
+  int next_min_change = static_cast<int>(0.5f + 2.5 * period);
+  int r_eff = std::max(next_min_change, ep.R);
+  int64_t T = static_cast<int64_t>(release_delay) + r_eff + 17; // steps 0 .. delay + r_eff + 16 run with the element RT-active
+  if (!h_out) return T;
+  if (cap < T) return fail(RA_EINVAL, "output buffer too small");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(RA_ENODEVICE, "no HIP device visible (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(RA_EINVAL, "device ordinal out of range");
+  HIP_TRY(hipSetDevice(device));
+  RaNoteEv e;
+  e.start = 0; e.inc = angle_increment; e.vol = volume; e.delay = release_delay; e.pad = 0;
+  int begin[2] = {0, 1};
+  double2 ph = make_double2(phase_re_im[0], phase_re_im[1]);
+  RaNoteEv *d_ev = nullptr; int *d_begin = nullptr; double *d_partial = nullptr, *d_out = nullptr; double2 *d_ph = nullptr;
+  auto cleanup = [&]() { (void)hipFree(d_ev); (void)hipFree(d_begin); (void)hipFree(d_partial); (void)hipFree(d_out); (void)hipFree(d_ph); };
+  hipError_t er = hipMalloc(&d_ev, sizeof(RaNoteEv));
+  if (er == hipSuccess) er = hipMalloc(&d_begin, sizeof(begin));
+  if (er == hipSuccess) er = hipMalloc(&d_partial, static_cast<size_t>(T) * sizeof(double));
+  if (er == hipSuccess) er = hipMalloc(&d_out, static_cast<size_t>(T) * sizeof(double));
+  if (er == hipSuccess) er = hipMalloc(&d_ph, sizeof(double2));
+  if (er == hipSuccess) er = hipMemcpy(d_ev, &e, sizeof(e), hipMemcpyHostToDevice);
+  if (er == hipSuccess) er = hipMemcpy(d_begin, begin, sizeof(begin), hipMemcpyHostToDevice);
+  if (er == hipSuccess) er = hipMemcpy(d_ph, &ph, sizeof(ph), hipMemcpyHostToDevice);
+  if (er == hipSuccess) { ra_launch_notes(d_ev, d_begin, 1, ep, T, d_partial, d_out, d_ph, nullptr); er = hipGetLastError(); }
+  if (er == hipSuccess) er = hipMemcpy(h_out, d_out, static_cast<size_t>(T) * sizeof(double), hipMemcpyDeviceToHost);
+  if (er == hipSuccess) er = hipMemcpy(&ph, d_ph, sizeof(ph), hipMemcpyDeviceToHost);
+  cleanup();
+  if (er != hipSuccess) return fail(RA_EHIP, std::string("ra_render_note: ") + hipGetErrorString(er));
+  phase_re_im[0] = ph.x; phase_re_im[1] = ph.y;
+  return T;
+}
+
 int64_t ra_resynth_notes(const ra_note *notes, int32_t n_notes, int32_t stride, int32_t sr, int32_t device, double *h_out, int64_t cap) {
   if (n_notes < 0 || (n_notes > 0 && !notes)) return fail(RA_EINVAL, "bad notes");
   if (stride < 1 || sr < 1000) return fail(RA_EINVAL, "bad stride / sampling rate");
@@ -897,7 +949,7 @@ int64_t ra_resynth_notes(const ra_note *notes, int32_t n_notes, int32_t stride, 
   if (e == hipSuccess && !flat.empty()) e = hipMemcpy(d_ev, flat.data(), flat.size() * sizeof(RaNoteEv), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(d_begin, begin.data(), begin.size() * sizeof(int), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    ra_launch_notes(d_ev, d_begin, n_slots, ep, T, d_partial, d_out, nullptr);
+    ra_launch_notes(d_ev, d_begin, n_slots, ep, T, d_partial, d_out, nullptr, nullptr);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpy(h_out, d_out, static_cast<size_t>(T) * sizeof(double), hipMemcpyDeviceToHost);

@@ -147,7 +147,7 @@ struct RaNoteEv {
   int32_t pad;
 };
 void ra_launch_notes(const RaNoteEv *d_ev, const int *d_slot_begin, int n_slots, RaEnvParams ep, int64_t T, double *d_partial, double *d_out,
-                     hipStream_t st);
+                     double2 *d_phase_io, hipStream_t st);
 void ra_launch_vocoder(const RaParams &p, const RaBuffers &b, const float *d_voice, const float *d_carrier, int64_t t0, int64_t n, hipStream_t st);
 
 // launchers (defined next to their kernels)
@@ -155,7 +155,7 @@ void ra_launch_analysis(const RaParams &p, const RaBuffers &b, const float *d_vo
                         hipStream_t st);
 void ra_launch_track(const RaParams &p, const RaBuffers &b, int64_t f_lo, int64_t n_frames_blk, hipStream_t st);
 void ra_launch_synth(const RaParams &p, const RaBuffers &b, int64_t t0, int64_t n, int64_t f_lo, int64_t n_frames_blk, float *d_out,
-                     double *d_out_d, int reference_order, hipStream_t st);
+                     double *d_out_d, int reference_order, hipEvent_t mid, hipStream_t st);
 void ra_launch_roll_history(const RaParams &p, const RaBuffers &b, const float *d_voice, int64_t n, hipStream_t st);
 size_t ra_analysis_lds_bytes(const RaParams &p);
 

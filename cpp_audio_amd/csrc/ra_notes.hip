@@ -10,8 +10,9 @@
 
 namespace {
 
+// phase_io (optional, [n_slots]): oscillator phasor each slot starts from / ends with (default: a fresh element, 1 + 0i)
 __global__ void __launch_bounds__(64) ra_notes_kernel(const RaNoteEv *__restrict__ ev, const int *__restrict__ slot_begin, int n_slots, RaEnvParams ep,
-                                                      int64_t T, double *__restrict__ partial) {
+                                                      int64_t T, double *__restrict__ partial, double2 *__restrict__ phase_io) {
   __shared__ double tile[16][65];
   const int l = threadIdx.x, g = blockIdx.x;
   const int slot = g * 64 + l;
@@ -19,6 +20,7 @@ __global__ void __launch_bounds__(64) ra_notes_kernel(const RaNoteEv *__restrict
   if (slot < n_slots) { next = slot_begin[slot]; end = slot_begin[slot + 1]; }
   Chan c;
   chan_init(c);
+  if (phase_io && slot < n_slots) { c.cre = phase_io[slot].x; c.cim = phase_io[slot].y; }
   const double max_filter_inc = 1.7976931348623157e308; // BaseVolumeAdjusted::max_filter_increment default, audioelement.h:1225
   double *dst = partial + (size_t)g * T;
   for (int64_t t = 0; t < T; t += 16) {
@@ -55,6 +57,7 @@ __global__ void __launch_bounds__(64) ra_notes_kernel(const RaNoteEv *__restrict
     }
     __syncthreads();
   }
+  if (phase_io && slot < n_slots) phase_io[slot] = make_double2(c.cre, c.cim);
 }
 
 __global__ void ra_notes_sum_kernel(const double *__restrict__ partial, int groups, int64_t T, double *__restrict__ out) {
@@ -67,11 +70,12 @@ __global__ void ra_notes_sum_kernel(const double *__restrict__ partial, int grou
 
 } // namespace
 
-void ra_launch_notes(const RaNoteEv *d_ev, const int *d_slot_begin, int n_slots, RaEnvParams ep, int64_t T, double *d_partial, double *d_out, hipStream_t st) {
+void ra_launch_notes(const RaNoteEv *d_ev, const int *d_slot_begin, int n_slots, RaEnvParams ep, int64_t T, double *d_partial, double *d_out,
+                     double2 *d_phase_io, hipStream_t st) {
   if (T <= 0) return;
   int groups = (n_slots + 63) / 64;
   if (groups < 1) groups = 1;
-  hipLaunchKernelGGL(ra_notes_kernel, dim3((unsigned)groups), dim3(64), 0, st, d_ev, d_slot_begin, n_slots, ep, T, d_partial);
+  hipLaunchKernelGGL(ra_notes_kernel, dim3((unsigned)groups), dim3(64), 0, st, d_ev, d_slot_begin, n_slots, ep, T, d_partial, d_phase_io);
   unsigned gx = (unsigned)std::min<int64_t>((T + 255) / 256, 8192);
   hipLaunchKernelGGL(ra_notes_sum_kernel, dim3(gx), dim3(256), 0, st, d_partial, groups, T, d_out);
 }

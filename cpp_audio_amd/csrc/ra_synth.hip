@@ -347,14 +347,16 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_render_kernel(RaPara
 } // namespace
 
 void ra_launch_synth(const RaParams &p, const RaBuffers &b, int64_t t0, int64_t n, int64_t f_lo, int64_t n_frames_blk, float *d_out,
-                     double *d_out_d, int reference_order, hipStream_t st) {
+                     double *d_out_d, int reference_order, hipEvent_t mid, hipStream_t st) {
   if (n <= 0) return;
   size_t lds = syn_lds_bytes(p.Ppad);
   if (reference_order) {
+    if (mid) (void)hipEventRecord(mid, st);
     hipLaunchKernelGGL(ra_synth_serial_kernel, dim3((unsigned)p.n_streams), dim3((unsigned)p.Ppad), lds, st, p, b, t0, n, f_lo, n_frames_blk, d_out, d_out_d);
     return;
   }
   hipLaunchKernelGGL(ra_synth_propagate_kernel, dim3((unsigned)p.n_streams), dim3((unsigned)p.Ppad), lds, st, p, b, t0, n, f_lo, n_frames_blk);
+  if (mid) (void)hipEventRecord(mid, st);
   const size_t lds_render = (size_t)16 * (p.Ppad + 1) * sizeof(double); // the 8-frame output tile only
   hipLaunchKernelGGL(ra_synth_render_kernel, dim3((unsigned)(n_frames_blk + 1), (unsigned)p.n_streams), dim3((unsigned)p.Ppad), lds_render, st, p, b, t0, n,
                      f_lo, n_frames_blk, d_out, d_out_d);

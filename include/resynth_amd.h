@@ -166,11 +166,11 @@ int ra_compute(ra_context *ctx, int32_t stream, double *h_buffer, int32_t n_fram
 /*
  * Per-kernel device time, measured with HIP events on the context's launch stream — the GPU-side counterpart of the
  * reference's per-stage ThreadCPUTimer gauges (periodicfft.cpp:140-151, lib.cpp:1586-1617, getDurationFft/Extract/Step).
- * ms5 = accumulated milliseconds of {analysis (fft+extract+stateless step), tracking (step), vocoder, synthesis (compute),
- * history copy} over `calls` ra_process_* calls since profiling was enabled.
+ * ms6 = accumulated milliseconds of {analysis (fft+extract+stateless step), tracking (step), vocoder, synthesis state
+ * propagation, synthesis render (compute), history copy} over `calls` ra_process_* calls since profiling was enabled.
  */
 int ra_set_profiling(ra_context *ctx, int32_t enable);
-int ra_get_kernel_ms(ra_context *ctx, double *ms5, int64_t *calls);
+int ra_get_kernel_ms(ra_context *ctx, double *ms6, int64_t *calls);
 
 /* counters and device-side error flags (synchronises) */
 int ra_get_stats(ra_context *ctx, ra_stats *stats);
@@ -188,6 +188,23 @@ int64_t ra_get_frame_pitches(ra_context *ctx, int32_t stream, int64_t *h_fire_sa
  */
 int64_t ra_resynth_notes(const ra_note *notes, int32_t n_notes, int32_t stride, int32_t sample_rate, int32_t device, double *h_out,
                          int64_t cap);
+
+/* audioelement::AHDSR (include/audioelement.h:314-335) in frames; every interpolation is itp::LINEAR on this path */
+typedef struct ra_ahdsr {
+  int32_t attack, hold, decay, release;
+  float sustain;
+} ra_ahdsr;
+
+/*
+ * One note of one driver-(A) element — Enveloped<VolumeAdjusted<SineOscillatorAlgo<double>>, AHDSREnvelope> (resynth.hpp:13-15) —
+ * i.e. the samples its step()/imag() pairs yield after forgetPastSignals(); setAngleIncrements(angle_increment);
+ * setVolumeTarget(volume); setAHDSR(*env, sample_rate); onKeyPressed(0); onKeyReleased(release_delay)  (resynth.hpp:83-96),
+ * until getEnvelope().isEnvelopeRTActive() turns false.  phase_re_im[2]: the oscillator phasor carried by the (reused)
+ * element, in: before the note, out: after it (a new element starts at {1, 0}, audioelement.h:2438).
+ * h_out may be NULL to query the length.  Returns the number of frames or a negative RA_E* code.
+ */
+int64_t ra_render_note(double angle_increment, double volume, const ra_ahdsr *env, int32_t release_delay, int32_t next_min_change_before,
+                       int32_t sample_rate, int32_t device, double *phase_re_im, double *h_out, int64_t cap);
 
 /* building blocks exposed for tests and for finer-grained integration (HOST pointers, one call = one launch) */
 /* findFrequenciesSqMag (periodicfft.cpp:304-311) on n_windows windows of `window_size` float samples -> [n_windows][L/2] */
