@@ -51,6 +51,24 @@ def host_cores():
     return int(env) if env else cores
 
 
+def measured_traffic(kernel, S, n, N, H, P):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r*/traffic.json, separate --pmc runs of
+    FETCH_SIZE and WRITE_SIZE, gfx950 x2 read correction) — PMC counters cannot be read from inside this process.  None unless a
+    profile of exactly this workload shape exists."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
+        try:
+            doc = json.load(open(path))
+            w = doc["workload"]
+            if (w["streams"], w["frames_per_stream"], w["window"], w["stride"], w["partials"]) != (S, n, N, H, P):
+                continue
+            k = doc["kernels"][kernel]
+            return (2.0 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0
+        except Exception:
+            continue
+    return None
+
+
 def synth_inputs_torch(n_streams, n_frames, sr, seed, device):
     """Seeded synthetic streams of the SURVEY.md §8(d) recipe, generated on the GPU (float32, peak 0.5)."""
     import math
@@ -169,6 +187,9 @@ def main():
         algo_bytes = ALGO_BYTES_PER_FRAME * frames_per_step_gpu
         achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         flops = algo_flops_per_frame(N, H, P)
+        KNAME = {"analysis": "ra_analysis_kernel", "track": "ra_track_kernel", "vocoder": "ra_voc_*_kernel",
+                 "propagate": "ra_synth_propagate_kernel", "render": "ra_synth_render_kernel", "history": "ra_roll_history_kernel"}
+        traffic = measured_traffic(KNAME[dom], S, n, N, H, P)
         result = {
             "metric": "audio frames/sec (48 kHz, 4096-pt FFT, 64 partials) per GPU; CPU ref x",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -179,9 +200,7 @@ def main():
                        "streams_per_gpu": S, "frames_per_stream_per_step": n, "sharding": f"streams x{world}, no collective"},
             "x_realtime_per_stream": value / (sr * S * world),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": {"analysis": "ra_analysis_kernel", "track": "ra_track_kernel", "vocoder": "ra_voc_*_kernel",
-                                                     "propagate": "ra_synth_propagate_kernel", "render": "ra_synth_render_kernel",
-                                                     "history": "ra_roll_history_kernel"}[dom],
+                         "traffic": traffic, "kernel": KNAME[dom],
                          "kernel_ms_per_launch": dom_ms, "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "path is fp64-VALU / serial-latency bound (SURVEY.md §8d): see valu"},
             "valu": {"algorithmic_flop_per_frame": flops, "achieved_tflops_fp64": flops * frames_per_step_gpu / (synth_ms * 1e-3 + 1e-30) / 1e12
