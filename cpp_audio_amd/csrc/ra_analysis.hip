@@ -112,9 +112,9 @@ __device__ inline float equal_loudness_db(const double *arr, const float *elv, d
 }
 
 __global__ void __launch_bounds__(RA_ANALYSIS_THREADS)
-ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int64_t t0, int64_t n, int64_t f_lo) {
+ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int64_t t0, int64_t n, int64_t f_lo, int fb0, int nfb_total) {
   const int tid = threadIdx.x;
-  const int fb = blockIdx.x;
+  const int fb = fb0 + blockIdx.x; // frame index inside the block [t0, t0 + n): this launch covers frames fb0 .. fb0 + gridDim.x - 1
   const int s = blockIdx.y;
   const int64_t f = f_lo + fb;
   const int M = p.M, N = p.N, T = RA_ANALYSIS_THREADS;
@@ -167,7 +167,7 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   }
   __syncthreads();
   if (b.dbg_sqmag) {
-    double *dst = b.dbg_sqmag + ((size_t)s * gridDim.x + fb) * M;
+    double *dst = b.dbg_sqmag + ((size_t)s * nfb_total + fb) * M;
     for (int k = tid; k < M; k += T) dst[k] = z[k].x;
   }
 
@@ -347,17 +347,17 @@ size_t ra_analysis_lds_bytes(const RaParams &p) {
   return m * sizeof(double2) + (lists > scan ? lists : scan);
 }
 
-void ra_launch_analysis(const RaParams &p, const RaBuffers &b, const float *d_voice, int64_t t0, int64_t n, int64_t f_lo, int64_t n_frames_blk,
-                        hipStream_t st) {
-  if (n_frames_blk <= 0) return;
-  dim3 grid((unsigned)n_frames_blk, (unsigned)p.n_streams);
+void ra_launch_analysis(const RaParams &p, const RaBuffers &b, const float *d_voice, int64_t t0, int64_t n, int64_t f_lo, int64_t fb0, int64_t nfb_chunk,
+                        int64_t nfb_total, hipStream_t st) {
+  if (nfb_chunk <= 0) return;
+  dim3 grid((unsigned)nfb_chunk, (unsigned)p.n_streams);
   size_t lds = ra_analysis_lds_bytes(p);
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void *>(ra_analysis_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(ra_analysis_kernel, grid, dim3(RA_ANALYSIS_THREADS), lds, st, p, b, d_voice, t0, n, f_lo);
+  hipLaunchKernelGGL(ra_analysis_kernel, grid, dim3(RA_ANALYSIS_THREADS), lds, st, p, b, d_voice, t0, n, f_lo, (int)fb0, (int)nfb_total);
 }
 
 void ra_launch_roll_history(const RaParams &p, const RaBuffers &b, const float *d_voice, int64_t n, hipStream_t st) {

@@ -36,10 +36,16 @@ struct ra_context {
   double *dbg_sqmag = nullptr;
   // optional per-kernel timing with HIP events on the launch stream (ra_set_profiling)
   bool profiling = false;
-  hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  bool ev_pending = false;
+  struct Timed { int stage; hipEvent_t a, b; };
+  std::vector<Timed> timed;          // launches of the calls not yet resolved
+  std::vector<hipEvent_t> ev_pool;   // recycled timing events
   double kernel_ms[6] = {0, 0, 0, 0, 0, 0}; // analysis, track, vocoder, propagate, render, history
   int64_t kernel_calls = 0;
+  // chunk pipeline: analysis / tracking / propagation / render streams and the events chaining them
+  bool pipe_ready = false;
+  hipStream_t pipe_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_voc = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_chunk[3][12] = {};
 };
 
 namespace {
@@ -69,6 +75,7 @@ int upload(ra_context *c, T **ptr, const std::vector<T> &v) {
   return RA_OK;
 }
 
+constexpr int kMaxChunks = 12;
 int fft_length_for(int n) { int l = 1; while (l < n) l <<= 1; return l; }
 
 // ---- host-side constants (own restatement of the reference's small pure functions; not the oracle) --------------
@@ -414,7 +421,7 @@ int init_state(ra_context *c) {
   return RA_OK;
 }
 
-int ensure_scratch(ra_context *c, int64_t nfb, int64_t n) {
+int ensure_scratch(ra_context *c, int64_t nfb, int64_t n, int n_chunks) {
   RaParams &p = c->p;
   RaBuffers &b = c->b;
   int r;
@@ -429,11 +436,11 @@ int ensure_scratch(ra_context *c, int64_t nfb, int64_t n) {
     if ((r = dev_alloc(c, &b.pl_count, S * F))) return r;
     if ((r = dev_alloc(c, &b.cmd, S * F * p.Ppad, false))) return r;
   }
-  if (!c->cfg.reference_order && nfb + 1 > b.seg_cap) {
+  if (!c->cfg.reference_order && nfb + n_chunks > b.seg_cap) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     dev_free(c, b.seg_sd); dev_free(c, b.seg_si);
-    size_t S = p.n_streams, G = static_cast<size_t>(nfb + 1);
-    b.seg_cap = nfb + 1;
+    size_t S = p.n_streams, G = static_cast<size_t>(nfb + kMaxChunks);
+    b.seg_cap = nfb + kMaxChunks;
     if ((r = dev_alloc(c, &b.seg_sd, S * G * SD_COUNT * p.Ppad, false))) return r;
     if ((r = dev_alloc(c, &b.seg_si, S * G * SI_COUNT * p.Ppad, false))) return r;
   }
@@ -473,42 +480,111 @@ void frames_in_block(const RaParams &p, int64_t t0, int64_t n, int64_t &f_lo, in
   nfb = f_hi >= f_lo ? f_hi - f_lo + 1 : 0;
 }
 
+// ---- per-launch timing with HIP events on the stream each kernel is launched on -------------------------------------
+enum { ST_ANALYSIS = 0, ST_TRACK, ST_VOCODER, ST_PROPAGATE, ST_RENDER, ST_HISTORY, ST_COUNT };
+
 int resolve_timing(ra_context *c) {
-  if (!c->ev_pending) return RA_OK;
-  HIP_TRY(hipEventSynchronize(c->ev[6]));
-  for (int i = 0; i < 6; ++i) {
+  for (auto &t : c->timed) {
+    HIP_TRY(hipEventSynchronize(t.b));
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
-    c->kernel_ms[i] += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b));
+    c->kernel_ms[t.stage] += ms;
+    c->ev_pool.push_back(t.a);
+    c->ev_pool.push_back(t.b);
   }
-  ++c->kernel_calls;
-  c->ev_pending = false;
+  if (!c->timed.empty()) ++c->kernel_calls;
+  c->timed.clear();
   return RA_OK;
 }
 
+template <typename F>
+int timed_launch(ra_context *c, int stage, hipStream_t st, F &&launch) {
+  if (!c->profiling) { launch(); return RA_OK; }
+  hipEvent_t ev[2];
+  for (auto &e : ev) {
+    if (c->ev_pool.empty()) { HIP_TRY(hipEventCreate(&e)); }
+    else { e = c->ev_pool.back(); c->ev_pool.pop_back(); }
+  }
+  HIP_TRY(hipEventRecord(ev[0], st));
+  launch();
+  HIP_TRY(hipEventRecord(ev[1], st));
+  c->timed.push_back({stage, ev[0], ev[1]});
+  return RA_OK;
+}
+
+// The block is cut into time chunks; analysis, tracking, propagation and render of successive chunks run on four HIP
+// streams chained by events.  Tracking and propagation are dependency chains over frames that occupy a few hundred
+// wavefronts; cutting the block lets the throughput kernels (analysis of later chunks, render of earlier ones) fill the
+// rest of the chip meanwhile.  Results do not depend on the cut (each chunk continues the carried state exactly).
 int process_block(ra_context *c, const float *d_voice, const float *d_carrier, int64_t n, float *d_out, double *d_out_d) {
   if (n <= 0) return RA_OK;
   HIP_TRY(hipSetDevice(c->device));
   RaParams &p = c->p;
+  const int64_t t0 = c->t;
   int64_t f_lo, nfb;
-  frames_in_block(p, c->t, n, f_lo, nfb);
-  int r = ensure_scratch(c, nfb, n);
+  frames_in_block(p, t0, n, f_lo, nfb);
+  int n_chunks = 1;
+  if (!c->cfg.reference_order && nfb >= 64) n_chunks = static_cast<int>(std::min<int64_t>(kMaxChunks, nfb / 48));
+  int r = ensure_scratch(c, nfb, n, n_chunks);
   if (r) return r;
   c->b.dbg_sqmag = c->dbg_sqmag;
-  const bool prof = c->profiling;
-  if (prof) { r = resolve_timing(c); if (r) return r; HIP_TRY(hipEventRecord(c->ev[0], c->stream)); }
-  ra_launch_analysis(p, c->b, d_voice, c->t, n, f_lo, nfb, c->stream);
-  if (prof) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-  ra_launch_track(p, c->b, f_lo, nfb, c->stream);
-  if (prof) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-  if (p.voc_enabled) ra_launch_vocoder(p, c->b, d_voice, d_carrier, c->t, n, c->stream);
-  if (prof) HIP_TRY(hipEventRecord(c->ev[3], c->stream));
-  ra_launch_synth(p, c->b, c->t, n, f_lo, nfb, d_out, d_out_d, c->cfg.reference_order, prof ? c->ev[4] : nullptr, c->stream);
-  if (prof) HIP_TRY(hipEventRecord(c->ev[5], c->stream));
-  ra_launch_roll_history(p, c->b, d_voice, n, c->stream);
-  if (prof) { HIP_TRY(hipEventRecord(c->ev[6], c->stream)); c->ev_pending = true; }
+  if (c->profiling && (r = resolve_timing(c))) return r;
+  const RaBuffers &b = c->b;
+  hipStream_t user = c->stream;
+
+  if (n_chunks == 1) { // everything in order on the caller's stream
+    RaSpan sp{t0, n, t0, t0 + n, f_lo, 0, nfb, 0};
+    timed_launch(c, ST_ANALYSIS, user, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, 0, nfb, nfb, user); });
+    timed_launch(c, ST_TRACK, user, [&] { ra_launch_track(p, b, f_lo, 0, nfb, user); });
+    if (p.voc_enabled) timed_launch(c, ST_VOCODER, user, [&] { ra_launch_vocoder(p, b, d_voice, d_carrier, t0, n, user); });
+    if (c->cfg.reference_order) timed_launch(c, ST_RENDER, user, [&] { ra_launch_synth_serial(p, b, sp, d_out, d_out_d, user); });
+    else {
+      timed_launch(c, ST_PROPAGATE, user, [&] { ra_launch_synth_propagate(p, b, sp, user); });
+      timed_launch(c, ST_RENDER, user, [&] { ra_launch_synth_render(p, b, sp, d_out, d_out_d, user); });
+    }
+  } else {
+    if (!c->pipe_ready) {
+      for (int i = 1; i < 4; ++i) HIP_TRY(hipStreamCreateWithFlags(&c->pipe_stream[i], hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&c->ev_voc, hipEventDisableTiming));
+      for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+      for (int i = 0; i < kMaxChunks; ++i)
+        for (int k = 0; k < 3; ++k) HIP_TRY(hipEventCreateWithFlags(&c->ev_chunk[k][i], hipEventDisableTiming));
+      c->pipe_ready = true;
+    }
+    // ROCm multiplexes HIP streams onto 4 hardware queues by default: the analysis launches ride on the caller's stream so that
+    // tracking, propagation and render each keep a queue of their own (on a shared queue propagate(i+1) would wait for render(i))
+    hipStream_t sA = user, sT = c->pipe_stream[1], sP = c->pipe_stream[2], sR = c->pipe_stream[3];
+    HIP_TRY(hipEventRecord(c->ev_fork, user));
+    for (int i = 1; i < 4; ++i) HIP_TRY(hipStreamWaitEvent(c->pipe_stream[i], c->ev_fork, 0));
+    if (p.voc_enabled) { // independent of the analysis chain: runs beside it, only the render waits for the mix
+      timed_launch(c, ST_VOCODER, sR, [&] { ra_launch_vocoder(p, b, d_voice, d_carrier, t0, n, sR); });
+    }
+    for (int i = 0; i < n_chunks; ++i) {
+      const int64_t fb0 = nfb * i / n_chunks, fb1 = nfb * (i + 1) / n_chunks;
+      RaSpan sp;
+      sp.t0 = t0; sp.n = n; sp.f_lo = f_lo; sp.fb0 = fb0; sp.nfb = fb1 - fb0; sp.seg0 = fb0 + i;
+      sp.ct0 = (i == 0) ? t0 : ra_fire_sample(p.N, p.H, f_lo + fb0);
+      sp.ct1 = (i == n_chunks - 1) ? t0 + n : ra_fire_sample(p.N, p.H, f_lo + fb1);
+      timed_launch(c, ST_ANALYSIS, sA, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, fb0, sp.nfb, nfb, sA); });
+      HIP_TRY(hipEventRecord(c->ev_chunk[0][i], sA));
+      HIP_TRY(hipStreamWaitEvent(sT, c->ev_chunk[0][i], 0));
+      timed_launch(c, ST_TRACK, sT, [&] { ra_launch_track(p, b, f_lo, fb0, sp.nfb, sT); });
+      HIP_TRY(hipEventRecord(c->ev_chunk[1][i], sT));
+      HIP_TRY(hipStreamWaitEvent(sP, c->ev_chunk[1][i], 0));
+      timed_launch(c, ST_PROPAGATE, sP, [&] { ra_launch_synth_propagate(p, b, sp, sP); });
+      HIP_TRY(hipEventRecord(c->ev_chunk[2][i], sP));
+      HIP_TRY(hipStreamWaitEvent(sR, c->ev_chunk[2][i], 0));
+      timed_launch(c, ST_RENDER, sR, [&] { ra_launch_synth_render(p, b, sp, d_out, d_out_d, sR); });
+    }
+    for (int i = 1; i < 4; ++i) {
+      HIP_TRY(hipEventRecord(c->ev_join[i], c->pipe_stream[i]));
+      HIP_TRY(hipStreamWaitEvent(user, c->ev_join[i], 0));
+    }
+  }
+  timed_launch(c, ST_HISTORY, user, [&] { ra_launch_roll_history(p, b, d_voice, n, user); });
   HIP_TRY(hipGetLastError());
-  c->last_f_lo = f_lo; c->last_nfb = nfb; c->last_n = n; c->last_t0 = c->t;
+  c->last_f_lo = f_lo; c->last_nfb = nfb; c->last_n = n; c->last_t0 = t0;
   c->t += n;
   c->frames_fired += nfb;
   return RA_OK;
@@ -609,7 +685,14 @@ void ra_destroy(ra_context *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (void *p : c->allocs) (void)hipFree(p);
-  for (int i = 0; i < 7; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+  for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+  if (c->pipe_ready) {
+    for (int i = 1; i < 4; ++i) { (void)hipStreamSynchronize(c->pipe_stream[i]); (void)hipStreamDestroy(c->pipe_stream[i]); }
+    (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_voc);
+    for (auto e : c->ev_join) (void)hipEventDestroy(e);
+    for (auto &row : c->ev_chunk) for (auto e : row) if (e) (void)hipEventDestroy(e);
+  }
   delete c;
 }
 
@@ -630,7 +713,6 @@ int ra_set_hip_stream(ra_context *c, void *hip_stream) {
 int ra_set_profiling(ra_context *c, int32_t enable) {
   if (!c) return fail(RA_EINVAL, "null context");
   HIP_TRY(hipSetDevice(c->device));
-  if (enable && !c->ev[0]) for (int i = 0; i < 7; ++i) HIP_TRY(hipEventCreate(&c->ev[i]));
   int r = resolve_timing(c);
   if (r) return r;
   c->profiling = enable != 0;

@@ -150,12 +150,22 @@ void ra_launch_notes(const RaNoteEv *d_ev, const int *d_slot_begin, int n_slots,
                      double2 *d_phase_io, hipStream_t st);
 void ra_launch_vocoder(const RaParams &p, const RaBuffers &b, const float *d_voice, const float *d_carrier, int64_t t0, int64_t n, hipStream_t st);
 
+// one time-chunk of a ra_process_* block: the block gives I/O indexing and the history split, the chunk the work range
+struct RaSpan {
+  int64_t t0, n;      // the block: absolute index of its first sample, length
+  int64_t ct0, ct1;   // this chunk's sample range [ct0, ct1)
+  int64_t f_lo;       // first analysis frame firing in the block
+  int64_t fb0, nfb;   // this chunk's frames: block-relative index of the first one, count (scratch is indexed block-relative)
+  int64_t seg0;       // first slot of this chunk's nfb + 1 segments in seg_sd / seg_si
+};
+
 // launchers (defined next to their kernels)
-void ra_launch_analysis(const RaParams &p, const RaBuffers &b, const float *d_voice, int64_t t0, int64_t n, int64_t f_lo, int64_t n_frames_blk,
-                        hipStream_t st);
-void ra_launch_track(const RaParams &p, const RaBuffers &b, int64_t f_lo, int64_t n_frames_blk, hipStream_t st);
-void ra_launch_synth(const RaParams &p, const RaBuffers &b, int64_t t0, int64_t n, int64_t f_lo, int64_t n_frames_blk, float *d_out,
-                     double *d_out_d, int reference_order, hipEvent_t mid, hipStream_t st);
+void ra_launch_analysis(const RaParams &p, const RaBuffers &b, const float *d_voice, int64_t t0, int64_t n, int64_t f_lo, int64_t fb0, int64_t nfb_chunk,
+                        int64_t nfb_total, hipStream_t st);
+void ra_launch_track(const RaParams &p, const RaBuffers &b, int64_t f_lo, int64_t fb0, int64_t n_frames_blk, hipStream_t st);
+void ra_launch_synth_serial(const RaParams &p, const RaBuffers &b, const RaSpan &sp, float *d_out, double *d_out_d, hipStream_t st);
+void ra_launch_synth_propagate(const RaParams &p, const RaBuffers &b, const RaSpan &sp, hipStream_t st);
+void ra_launch_synth_render(const RaParams &p, const RaBuffers &b, const RaSpan &sp, float *d_out, double *d_out_d, hipStream_t st);
 void ra_launch_roll_history(const RaParams &p, const RaBuffers &b, const float *d_voice, int64_t n, hipStream_t st);
 size_t ra_analysis_lds_bytes(const RaParams &p);
 

@@ -283,8 +283,7 @@ __device__ inline void apply_frame_events(Chan &c, const RaCmd &cmd, const SynLd
 }
 
 // ---- reference-order kernel: one workgroup per stream, samples strictly in order ----------------------------------
-__global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_serial_kernel(RaParams p, RaBuffers b, int64_t t0, int64_t n, int64_t f_lo, int64_t n_frames_blk,
-                                                                          float *__restrict__ out, double *__restrict__ out_d) {
+__global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_serial_kernel(RaParams p, RaBuffers b, RaSpan sp, float *__restrict__ out, double *__restrict__ out_d) {
   const int s = blockIdx.x, l = threadIdx.x, Ppad = p.Ppad;
   SynLds L = carve(ra_smem_syn, Ppad);
   double *sd = b.sd + (size_t)s * SD_COUNT * Ppad;
@@ -292,21 +291,22 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_serial_kernel(RaPara
   Chan c;
   load_chan(c, sd, si, Ppad, l);
   const SynConst k = syn_const(p, s);
-  const double *mix = (p.voc_enabled && b.voc_mix) ? b.voc_mix + (size_t)s * n : nullptr;
-  int64_t t = t0;
-  for (int64_t fb = 0; fb <= n_frames_blk; ++fb) {
-    const int64_t seg_end = (fb < n_frames_blk) ? ra_fire_sample(p.N, p.H, f_lo + fb) : t0 + n;
-    render_range<false>(c, L, k, p, s, l, t, seg_end, t0, n, mix, out, out_d);
+  const double *mix = (p.voc_enabled && b.voc_mix) ? b.voc_mix + (size_t)s * sp.n : nullptr;
+  int64_t t = sp.ct0;
+  for (int64_t i = 0; i <= sp.nfb; ++i) {
+    const int64_t seg_end = (i < sp.nfb) ? ra_fire_sample(p.N, p.H, sp.f_lo + sp.fb0 + i) : sp.ct1;
+    render_range<false>(c, L, k, p, s, l, t, seg_end, sp.t0, sp.n, mix, out, out_d);
     t = seg_end;
-    if (fb == n_frames_blk) break;
-    const RaCmd cmd = b.cmd[((size_t)s * b.frames_cap + fb) * Ppad + l];
+    if (i == sp.nfb) break;
+    const RaCmd cmd = b.cmd[((size_t)s * b.frames_cap + sp.fb0 + i) * Ppad + l];
     apply_frame_events(c, cmd, L, k, p, b, l);
   }
   store_chan(c, sd, si, Ppad, l);
 }
 
-// ---- K3a: state at the start of every segment (segment i = samples between frame i-1 and frame i of the block) ----
-__global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_propagate_kernel(RaParams p, RaBuffers b, int64_t t0, int64_t n, int64_t f_lo, int64_t n_frames_blk) {
+// ---- K3a: state at the start of every segment (segment i of a chunk = samples between its frames i-1 and i) -----------
+__global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_propagate_kernel(RaParams p, RaBuffers b, RaSpan sp) {
+  __builtin_amdgcn_s_setprio(3); // a dependency chain a few hundred waves wide: let it win issue arbitration against the throughput kernels it runs beside
   const int s = blockIdx.x, l = threadIdx.x, Ppad = p.Ppad;
   SynLds L = carve(ra_smem_syn, Ppad);
   double *sd = b.sd + (size_t)s * SD_COUNT * Ppad;
@@ -314,50 +314,47 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_propagate_kernel(RaP
   Chan c;
   load_chan(c, sd, si, Ppad, l);
   const SynConst k = syn_const(p, s);
-  int64_t t = t0;
-  for (int64_t fb = 0; fb <= n_frames_blk; ++fb) {
-    const int64_t seg_end = (fb < n_frames_blk) ? ra_fire_sample(p.N, p.H, f_lo + fb) : t0 + n;
-    const size_t seg = (size_t)s * b.seg_cap + fb;
+  int64_t t = sp.ct0;
+  for (int64_t i = 0; i <= sp.nfb; ++i) {
+    const int64_t seg_end = (i < sp.nfb) ? ra_fire_sample(p.N, p.H, sp.f_lo + sp.fb0 + i) : sp.ct1;
+    const size_t seg = (size_t)s * b.seg_cap + sp.seg0 + i;
     store_chan(c, b.seg_sd + seg * SD_COUNT * Ppad, b.seg_si + seg * SI_COUNT * Ppad, Ppad, l);
     chan_jump(c, k.ep, k.dur, k.max_filter_inc, seg_end - t);
     t = seg_end;
-    if (fb == n_frames_blk) break;
-    const RaCmd cmd = b.cmd[((size_t)s * b.frames_cap + fb) * Ppad + l];
+    if (i == sp.nfb) break;
+    const RaCmd cmd = b.cmd[((size_t)s * b.frames_cap + sp.fb0 + i) * Ppad + l];
     apply_frame_events(c, cmd, L, k, p, b, l);
   }
   store_chan(c, sd, si, Ppad, l);
 }
 
 // ---- K3b: render one segment ----------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_render_kernel(RaParams p, RaBuffers b, int64_t t0, int64_t n, int64_t f_lo, int64_t n_frames_blk,
-                                                                          float *__restrict__ out, double *__restrict__ out_d) {
-  const int fb = blockIdx.x, s = blockIdx.y, l = threadIdx.x, Ppad = p.Ppad;
-  const int64_t seg_begin = (fb == 0) ? t0 : ra_fire_sample(p.N, p.H, f_lo + fb - 1);
-  const int64_t seg_end = (fb < n_frames_blk) ? ra_fire_sample(p.N, p.H, f_lo + fb) : t0 + n;
+__global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_render_kernel(RaParams p, RaBuffers b, RaSpan sp, float *__restrict__ out, double *__restrict__ out_d) {
+  const int i = blockIdx.x, s = blockIdx.y, l = threadIdx.x, Ppad = p.Ppad;
+  const int64_t seg_begin = (i == 0) ? sp.ct0 : ra_fire_sample(p.N, p.H, sp.f_lo + sp.fb0 + i - 1);
+  const int64_t seg_end = (i < sp.nfb) ? ra_fire_sample(p.N, p.H, sp.f_lo + sp.fb0 + i) : sp.ct1;
   if (seg_end <= seg_begin) return;
   SynLds L = carve(ra_smem_syn, Ppad);
-  const size_t seg = (size_t)s * b.seg_cap + fb;
+  const size_t seg = (size_t)s * b.seg_cap + sp.seg0 + i;
   Chan c;
   load_chan(c, b.seg_sd + seg * SD_COUNT * Ppad, b.seg_si + seg * SI_COUNT * Ppad, Ppad, l);
   const SynConst k = syn_const(p, s);
-  const double *mix = (p.voc_enabled && b.voc_mix) ? b.voc_mix + (size_t)s * n : nullptr;
-  render_range_fast(c, L, k, p, s, l, seg_begin, seg_end, t0, n, mix, out, out_d);
+  const double *mix = (p.voc_enabled && b.voc_mix) ? b.voc_mix + (size_t)s * sp.n : nullptr;
+  render_range_fast(c, L, k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
 }
 
 } // namespace
 
-void ra_launch_synth(const RaParams &p, const RaBuffers &b, int64_t t0, int64_t n, int64_t f_lo, int64_t n_frames_blk, float *d_out,
-                     double *d_out_d, int reference_order, hipEvent_t mid, hipStream_t st) {
-  if (n <= 0) return;
-  size_t lds = syn_lds_bytes(p.Ppad);
-  if (reference_order) {
-    if (mid) (void)hipEventRecord(mid, st);
-    hipLaunchKernelGGL(ra_synth_serial_kernel, dim3((unsigned)p.n_streams), dim3((unsigned)p.Ppad), lds, st, p, b, t0, n, f_lo, n_frames_blk, d_out, d_out_d);
-    return;
-  }
-  hipLaunchKernelGGL(ra_synth_propagate_kernel, dim3((unsigned)p.n_streams), dim3((unsigned)p.Ppad), lds, st, p, b, t0, n, f_lo, n_frames_blk);
-  if (mid) (void)hipEventRecord(mid, st);
+void ra_launch_synth_serial(const RaParams &p, const RaBuffers &b, const RaSpan &sp, float *d_out, double *d_out_d, hipStream_t st) {
+  if (sp.ct1 <= sp.ct0) return;
+  hipLaunchKernelGGL(ra_synth_serial_kernel, dim3((unsigned)p.n_streams), dim3((unsigned)p.Ppad), syn_lds_bytes(p.Ppad), st, p, b, sp, d_out, d_out_d);
+}
+void ra_launch_synth_propagate(const RaParams &p, const RaBuffers &b, const RaSpan &sp, hipStream_t st) {
+  if (sp.ct1 <= sp.ct0) return;
+  hipLaunchKernelGGL(ra_synth_propagate_kernel, dim3((unsigned)p.n_streams), dim3((unsigned)p.Ppad), syn_lds_bytes(p.Ppad), st, p, b, sp);
+}
+void ra_launch_synth_render(const RaParams &p, const RaBuffers &b, const RaSpan &sp, float *d_out, double *d_out_d, hipStream_t st) {
+  if (sp.ct1 <= sp.ct0) return;
   const size_t lds_render = (size_t)16 * (p.Ppad + 1) * sizeof(double); // the 8-frame output tile only
-  hipLaunchKernelGGL(ra_synth_render_kernel, dim3((unsigned)(n_frames_blk + 1), (unsigned)p.n_streams), dim3((unsigned)p.Ppad), lds_render, st, p, b, t0, n,
-                     f_lo, n_frames_blk, d_out, d_out_d);
+  hipLaunchKernelGGL(ra_synth_render_kernel, dim3((unsigned)(sp.nfb + 1), (unsigned)p.n_streams), dim3((unsigned)p.Ppad), lds_render, st, p, b, sp, d_out, d_out_d);
 }

@@ -30,7 +30,8 @@ __device__ inline int min_change_for(float freq, int sample_rate) {
   return (int)(0.5f + 2.5 * period);
 }
 
-__global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, int64_t f_lo, int64_t n_frames_blk) {
+__global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, int64_t f_lo, int64_t fb0, int64_t n_frames_blk) {
+  __builtin_amdgcn_s_setprio(3); // latency-bound chain: win issue arbitration against the throughput kernels running beside it
   const int s = blockIdx.x;
   const int lane = threadIdx.x;
   const int P = p.P, maxr = p.maxr;
@@ -80,7 +81,7 @@ __global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, i
 
   const int R_env = p.envR;
 
-  for (int64_t fb = 0; fb < n_frames_blk; ++fb) {
+  for (int64_t fb = fb0; fb < fb0 + n_frames_blk; ++fb) { // frames fb0 .. of the block; scratch is indexed by fb
     const int64_t k_f = ra_fire_sample(p.N, p.H, f_lo + fb);
     const size_t lbase = ((size_t)s * b.frames_cap + fb) * maxr;
     const int A = b.pl_count[(size_t)s * b.frames_cap + fb];
@@ -225,8 +226,8 @@ __global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, i
 
 } // namespace
 
-void ra_launch_track(const RaParams &p, const RaBuffers &b, int64_t f_lo, int64_t n_frames_blk, hipStream_t st) {
+void ra_launch_track(const RaParams &p, const RaBuffers &b, int64_t f_lo, int64_t fb0, int64_t n_frames_blk, hipStream_t st) {
   if (n_frames_blk <= 0) return;
   size_t lds = (size_t)p.maxr * (8 + 8 + 6 * 4) + (size_t)p.P * (6 * 8 + 10 * 4) + 64;
-  hipLaunchKernelGGL(ra_track_kernel, dim3((unsigned)p.n_streams), dim3(64), lds, st, p, b, f_lo, n_frames_blk);
+  hipLaunchKernelGGL(ra_track_kernel, dim3((unsigned)p.n_streams), dim3(64), lds, st, p, b, f_lo, fb0, n_frames_blk);
 }
