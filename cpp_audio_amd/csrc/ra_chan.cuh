@@ -21,6 +21,7 @@ struct Chan {
   double vol, target, finit, k, y;
   // StereoPanned
   double gL, gR;
+  double theta; // phase-domain oscillator (propagate kernel): angle in rad/pi, cur = e^{i pi theta}
   int flags;
 };
 
@@ -31,6 +32,7 @@ __device__ inline void chan_init(Chan &c) { // a freshly constructed element
   c.cre = 1; c.cim = 0; c.mre = 1; c.mim = 0; c.alias = 1; c.inc = 0;
   c.vol = c.target = c.finit = c.k = c.y = 0;
   c.gL = c.gR = 1;
+  c.theta = 0;
   c.flags = 0;
 }
 
@@ -395,6 +397,115 @@ __device__ inline void chan_jump(Chan &c, const RaEnvParams &p, double dur, doub
   }
 }
 
+// ---- phase-domain propagation ---------------------------------------------------------------------------------------------
+// The propagate kernel is a dependency chain over hops; it carries the oscillator as its angle theta (cur = e^{i pi theta}), so
+// a step is "theta += inc" and a jump "theta += sum(inc)": no trigonometry on the chain.  The render kernel rebuilds the phasor,
+// the per-sample rotation and the anti-aliasing gain from (theta, inc) when it loads a hop's start state.
+__device__ inline void chan_step_phase(Chan &c, const RaEnvParams &p, double dur, double inv_dur, double max_filter_inc) {
+  env_step(c, p);
+  {
+    double f;
+    if ((c.flags & FL_HAS_FRES) && c.fres == c.to) f = c.to;
+    else {
+      if (c.cur + 0.5 > dur) c.cur = dur;
+      const double slope = (c.to - c.from) * inv_dur;
+      c.fres = (c.cur == dur) ? c.from + (c.to - c.from) * (dur / dur) : c.from + slope * c.cur;
+      c.flags |= FL_HAS_FRES;
+      if (c.cur < dur) c.cur += c.C * (c.from + slope * (c.cur + 0.5));
+      f = c.fres;
+    }
+    c.inc = f;
+  }
+  c.theta += c.inc;
+  if (!(c.flags & FL_HAS_VOL)) {
+    c.finit = fmin(max_filter_inc, fabs(angle_increments(c, 0)));
+    double a = M_PI * c.finit; c.k = a / (1.0 + a);
+    c.y = c.target;
+  } else if (c.vol != c.target) {
+    double inc = fmin(max_filter_inc, fabs(angle_increments(c, 0)));
+    if (c.finit != inc) { c.finit = inc; double a = M_PI * inc; c.k = a / (1.0 + a); }
+  }
+  c.y = c.y + c.k * (c.target - c.y);
+  c.vol = c.y;
+  c.flags |= FL_HAS_VOL;
+}
+
+// chan_jump in the phase domain; a glide that ends inside the stretch is taken in one go (glide part, clamp step, constant tail)
+__device__ inline void chan_jump_phase(Chan &c, const RaEnvParams &p, double dur, double max_filter_inc, int64_t n) {
+  const double inv_dur = 1.0 / dur;
+  double k_cached = -1.0, lk = 0.0;
+  while (n > 0 && rt_active(c)) {
+    bool serial = !(c.flags & FL_HAS_VOL);
+    int j = env_regular_steps(c, p);
+    if (j == 0) serial = true;
+    const bool steady = (c.flags & FL_HAS_FRES) && c.fres == c.to;
+    const double f_end = c.from + (c.to - c.from) * (dur / dur);
+    const bool clamped = !steady && (c.flags & FL_HAS_FRES) && c.cur == dur && c.fres == f_end;
+    const bool gliding = !steady && !clamped;
+    if (gliding && (c.to == c.from || c.cur + 0.5 > dur || !(c.flags & FL_HAS_FRES))) serial = true;
+    if (serial) { chan_step_phase(c, p, dur, inv_dur, max_filter_inc); --n; continue; }
+    if ((int64_t)j > n) j = (int)n;
+
+    double sum_inc, new_cur = c.cur, new_fres = c.fres;
+    if (!gliding) {
+      sum_inc = (double)j * c.fres;
+    } else {
+      const double slope = (c.to - c.from) * inv_dur;
+      const double x = c.C * slope;                            // alpha - 1
+      const double beta = c.C * c.from + 0.5 * x;
+      const double Lg = log1p_small(x);
+      const double A = c.cur + beta / x;
+      const double lim = dur - 0.5;                            // a step that finds cur > lim clamps
+      const double inv_1px = 1.0 / (1.0 + x);
+      double Ej = expm1_small((double)j * Lg);                 // E_m = alpha^m - 1 ; u_m = cur + E_m A
+      double Ejm1 = (Ej - x) * inv_1px;
+      if (c.cur + Ejm1 * A > lim) { // the glide ends inside the stretch
+        double est = log1p_small((lim - c.cur) / A) / Lg;
+        int ms = (est == est && est < 2.0e9 && est >= 0.0) ? (int)est + 1 : 1;
+        ms = max(1, min(ms, j));
+        double Em = expm1_small((double)ms * Lg), Emm1 = (Em - x) * inv_1px;
+        while (ms > 1 && c.cur + Emm1 * A > lim) { --ms; Em = Emm1; Emm1 = (Em - x) * inv_1px; }
+        while (ms < j && !(c.cur + Em * A > lim)) { ++ms; Emm1 = Em; Em = fma(Em, x, Em + x); }
+        // steps 0 .. ms-1 glide; if ms < j step ms clamps and every later step keeps f_end
+        const double u_ms = c.cur + Em * A;
+        sum_inc = (u_ms - c.cur) / c.C - (double)ms * 0.5 * slope;
+        if (ms < j) { sum_inc += (double)(j - ms) * f_end; new_cur = dur; new_fres = f_end; }
+        else { new_cur = u_ms; new_fres = c.from + slope * (c.cur + Emm1 * A); }
+      } else {
+        new_cur = c.cur + Ej * A;
+        new_fres = c.from + slope * (c.cur + Ejm1 * A);
+        // inc_m = (u_{m+1} - u_m) / C - (to - from) / (2 dur)   (InterpolatedFreq::step, audioelement.h:2781-2785)
+        sum_inc = (new_cur - c.cur) / c.C - (double)j * 0.5 * slope;
+      }
+    }
+    if (c.vol != c.target) { // volume filter: needs a constant coefficient over the stretch
+      double lo = gliding ? fmin(fabs(c.from + (c.to - c.from) * (c.cur * inv_dur)), fabs(new_fres)) : fabs(c.fres);
+      double want = fmin(max_filter_inc, lo);
+      bool ok = (c.finit == want) && (!gliding || lo >= max_filter_inc);
+      if (!ok) { chan_step_phase(c, p, dur, inv_dur, max_filter_inc); --n; continue; }
+      if (c.k != k_cached) { k_cached = c.k; lk = log1p_small(-c.k); }
+      double q = exp((double)j * lk);
+      c.y = c.target + (c.y - c.target) * q;
+      c.vol = c.y;
+    }
+    env_jump(c, p, j);
+    if (gliding) { c.cur = new_cur; c.fres = new_fres; c.inc = new_fres; }
+    c.theta += sum_inc;
+    n -= j;
+  }
+  c.theta -= 2.0 * rint(0.5 * c.theta); // keep the angle in [-1, 1]
+}
+
+// hop start in the render kernel: phasor, per-sample rotation and anti-aliasing gain from (theta, inc)
+__device__ inline void chan_from_phase(Chan &c) {
+  double sn, cs;
+  sincospi(c.theta, &sn, &cs);
+  c.cre = cs; c.cim = sn;
+  sincospi(c.inc, &sn, &cs);
+  c.mre = cs; c.mim = sn;
+  c.alias = (c.inc > 0. && c.inc <= 0.25) ? 1.0 : alias_mult(c.inc);
+}
+
 __device__ inline uint64_t splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -416,6 +527,7 @@ __device__ inline void load_chan(Chan &c, const double *sd, const int *si, int P
   c.mim = sd[SD_OSC_MIM * Ppad + l]; c.alias = sd[SD_OSC_ALIAS * Ppad + l]; c.inc = sd[SD_OSC_INC * Ppad + l];
   c.vol = sd[SD_VOL * Ppad + l]; c.target = sd[SD_VOL_TARGET * Ppad + l]; c.finit = sd[SD_VOL_FINIT * Ppad + l];
   c.k = sd[SD_VOL_K * Ppad + l]; c.y = sd[SD_VOL_Y * Ppad + l]; c.gL = sd[SD_GAIN_L * Ppad + l]; c.gR = sd[SD_GAIN_R * Ppad + l];
+  c.theta = sd[SD_THETA * Ppad + l];
   c.state = si[SI_ENV_STATE * Ppad + l]; c.counter = si[SI_ENV_COUNTER * Ppad + l]; c.reldelay = si[SI_ENV_RELDELAY * Ppad + l];
   c.ahdstate = si[SI_ENV_AHDSTATE * Ppad + l]; c.ahdcounter = si[SI_ENV_AHDCOUNTER * Ppad + l]; c.minch = si[SI_ENV_MINCH * Ppad + l];
   c.nextminch = si[SI_ENV_NEXTMINCH * Ppad + l]; c.flags = si[SI_FLAGS * Ppad + l];
@@ -428,6 +540,7 @@ __device__ inline void store_chan(const Chan &c, double *sd, int *si, int Ppad, 
   sd[SD_OSC_MIM * Ppad + l] = c.mim; sd[SD_OSC_ALIAS * Ppad + l] = c.alias; sd[SD_OSC_INC * Ppad + l] = c.inc;
   sd[SD_VOL * Ppad + l] = c.vol; sd[SD_VOL_TARGET * Ppad + l] = c.target; sd[SD_VOL_FINIT * Ppad + l] = c.finit;
   sd[SD_VOL_K * Ppad + l] = c.k; sd[SD_VOL_Y * Ppad + l] = c.y; sd[SD_GAIN_L * Ppad + l] = c.gL; sd[SD_GAIN_R * Ppad + l] = c.gR;
+  sd[SD_THETA * Ppad + l] = c.theta;
   si[SI_ENV_STATE * Ppad + l] = c.state; si[SI_ENV_COUNTER * Ppad + l] = c.counter; si[SI_ENV_RELDELAY * Ppad + l] = c.reldelay;
   si[SI_ENV_AHDSTATE * Ppad + l] = c.ahdstate; si[SI_ENV_AHDCOUNTER * Ppad + l] = c.ahdcounter; si[SI_ENV_MINCH * Ppad + l] = c.minch;
   si[SI_ENV_NEXTMINCH * Ppad + l] = c.nextminch; si[SI_FLAGS * Ppad + l] = c.flags;

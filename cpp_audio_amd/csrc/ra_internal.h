@@ -68,6 +68,7 @@ enum {
   SD_ENV_VALUE, SD_ENV_TOP, SD_CTRL_FROM, SD_CTRL_TO, SD_CTRL_CUR, SD_CTRL_C, SD_CTRL_FRES,
   SD_OSC_CRE, SD_OSC_CIM, SD_OSC_MRE, SD_OSC_MIM, SD_OSC_ALIAS, SD_OSC_INC,
   SD_VOL, SD_VOL_TARGET, SD_VOL_FINIT, SD_VOL_K, SD_VOL_Y, SD_GAIN_L, SD_GAIN_R,
+  SD_THETA, // oscillator angle in rad/pi: authoritative in hop-parallel mode (cre/cim are derived from it), unused in reference order
   SD_COUNT
 };
 enum { SI_ENV_STATE, SI_ENV_COUNTER, SI_ENV_RELDELAY, SI_ENV_AHDSTATE, SI_ENV_AHDCOUNTER, SI_ENV_MINCH, SI_ENV_NEXTMINCH, SI_FLAGS, SI_COUNT };

@@ -219,6 +219,8 @@ __device__ inline void render_range_fast(Chan &c, const SynLds &L, const SynCons
 }
 
 // the one-shots of one analysis frame, in the order the reference queued them.  Workgroup-uniform control flow.
+// PHASE: the oscillator is carried as its angle theta (propagate kernel) instead of the phasor (cre, cim).
+template <bool PHASE>
 __device__ inline void apply_frame_events(Chan &c, const RaCmd &cmd, const SynLds &L, const SynConst &k, const RaParams &p, const RaBuffers &b, int l) {
   const int Ppad = p.Ppad;
   for (int i = l; i < 2 * Ppad; i += Ppad) L.ev_lane[i] = -1;
@@ -235,7 +237,7 @@ __device__ inline void apply_frame_events(Chan &c, const RaCmd &cmd, const SynLd
     L.ev_lane[cmd.ord] = l;
   }
   L.x_inc[l] = angle_increments(c, 0);
-  L.x_cre[l] = c.cre;
+  L.x_cre[l] = PHASE ? c.theta : c.cre;
   L.x_cim[l] = c.cim;
   L.x_act[l] = rt_active(c) ? 1 : 0;
   __syncthreads();
@@ -268,15 +270,19 @@ __device__ inline void apply_frame_events(Chan &c, const RaCmd &cmd, const SynLd
         if (!L.x_act[q]) continue;
         if (L.x_inc[q] == ai) { src = q; break; }
       }
-      if (src >= 0) { c.cre = L.x_cre[src]; c.cim = L.x_cim[src]; }
-      else {
+      if (src >= 0) { // synchronizeAngles :2397-2399
+        if (PHASE) c.theta = L.x_cre[src]; else { c.cre = L.x_cre[src]; c.cim = L.x_cim[src]; }
+      } else {
         float a = (p.phase_policy == RA_PHASE_HASH) ? hash_uniform_pm1(k.seed, (uint64_t)cmd.noteid, 0) : 0.f;
-        double sn, cs;
-        sincos(M_PI * (double)a, &sn, &cs);  // setStartAngle :2401-2403
-        c.cre = cs; c.cim = sn;
+        if (PHASE) c.theta = (double)a;      // setStartAngle :2401-2403: cur = polar(pi a)
+        else {
+          double sn, cs;
+          sincos(M_PI * (double)a, &sn, &cs);
+          c.cre = cs; c.cim = sn;
+        }
       }
       env_on_key_pressed(c, 0);
-      L.x_cre[l] = c.cre; L.x_cim[l] = c.cim; L.x_act[l] = 1; L.x_inc[l] = ai;
+      L.x_cre[l] = PHASE ? c.theta : c.cre; L.x_cim[l] = c.cim; L.x_act[l] = 1; L.x_inc[l] = ai;
     }
     __syncthreads();
   }
@@ -299,7 +305,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_serial_kernel(RaPara
     t = seg_end;
     if (i == sp.nfb) break;
     const RaCmd cmd = b.cmd[((size_t)s * b.frames_cap + sp.fb0 + i) * Ppad + l];
-    apply_frame_events(c, cmd, L, k, p, b, l);
+    apply_frame_events<false>(c, cmd, L, k, p, b, l);
   }
   store_chan(c, sd, si, Ppad, l);
 }
@@ -319,11 +325,11 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_propagate_kernel(RaP
     const int64_t seg_end = (i < sp.nfb) ? ra_fire_sample(p.N, p.H, sp.f_lo + sp.fb0 + i) : sp.ct1;
     const size_t seg = (size_t)s * b.seg_cap + sp.seg0 + i;
     store_chan(c, b.seg_sd + seg * SD_COUNT * Ppad, b.seg_si + seg * SI_COUNT * Ppad, Ppad, l);
-    chan_jump(c, k.ep, k.dur, k.max_filter_inc, seg_end - t);
+    chan_jump_phase(c, k.ep, k.dur, k.max_filter_inc, seg_end - t);
     t = seg_end;
     if (i == sp.nfb) break;
     const RaCmd cmd = b.cmd[((size_t)s * b.frames_cap + sp.fb0 + i) * Ppad + l];
-    apply_frame_events(c, cmd, L, k, p, b, l);
+    apply_frame_events<true>(c, cmd, L, k, p, b, l);
   }
   store_chan(c, sd, si, Ppad, l);
 }
@@ -338,6 +344,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_render_kernel(RaPara
   const size_t seg = (size_t)s * b.seg_cap + sp.seg0 + i;
   Chan c;
   load_chan(c, b.seg_sd + seg * SD_COUNT * Ppad, b.seg_si + seg * SI_COUNT * Ppad, Ppad, l);
+  chan_from_phase(c);
   const SynConst k = syn_const(p, s);
   const double *mix = (p.voc_enabled && b.voc_mix) ? b.voc_mix + (size_t)s * sp.n : nullptr;
   render_range_fast(c, L, k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
