@@ -427,7 +427,7 @@ int ensure_scratch(ra_context *c, int64_t nfb, int64_t n, int n_chunks) {
   int r;
   if (nfb > b.frames_cap) {
     HIP_TRY(hipStreamSynchronize(c->stream));
-    dev_free(c, b.pl_pitch); dev_free(c, b.pl_vol); dev_free(c, b.pl_key); dev_free(c, b.pl_count); dev_free(c, b.cmd);
+    dev_free(c, b.pl_pitch); dev_free(c, b.pl_vol); dev_free(c, b.pl_key); dev_free(c, b.pl_count); dev_free(c, b.cmd); dev_free(c, b.cmd_non);
     size_t S = p.n_streams, F = static_cast<size_t>(nfb);
     b.frames_cap = nfb;
     if ((r = dev_alloc(c, &b.pl_pitch, S * F * p.maxr, false))) return r;
@@ -435,6 +435,7 @@ int ensure_scratch(ra_context *c, int64_t nfb, int64_t n, int n_chunks) {
     if ((r = dev_alloc(c, &b.pl_key, S * F * p.maxr, false))) return r;
     if ((r = dev_alloc(c, &b.pl_count, S * F))) return r;
     if ((r = dev_alloc(c, &b.cmd, S * F * p.Ppad, false))) return r;
+    if ((r = dev_alloc(c, &b.cmd_non, S * F))) return r;
   }
   if (!c->cfg.reference_order && nfb + n_chunks > b.seg_cap) {
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -830,7 +831,7 @@ int64_t ra_get_events(ra_context *c, int32_t stream, ra_event *h_events, int64_t
     order.clear();
     for (int l = 0; l < p.P; ++l) {
       const RaCmd &m = cmds[fb * p.Ppad + l];
-      if (m.type != RA_CMD_NONE) order.push_back({m.ord, l});
+      if ((m.type & 0xff) != RA_CMD_NONE) order.push_back({m.ord, l});
     }
     std::sort(order.begin(), order.end());
     for (auto &o : order) {
@@ -838,7 +839,7 @@ int64_t ra_get_events(ra_context *c, int32_t stream, ra_event *h_events, int64_t
       if (count < cap && h_events) {
         ra_event e;
         e.sample = ra_fire_sample(p.N, p.H, c->last_f_lo + fb);
-        e.type = m.type == RA_CMD_ON ? 0 : m.type == RA_CMD_OFF ? 1 : 2;
+        e.type = (m.type & 0xff) == RA_CMD_ON ? 0 : (m.type & 0xff) == RA_CMD_OFF ? 1 : 2;
         e.channel = o.second;
         e.noteid = m.noteid;
         e.frequency = m.freq;

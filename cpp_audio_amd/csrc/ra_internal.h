@@ -103,6 +103,7 @@ struct RaBuffers {
   float *pl_key;
   int32_t *pl_count;        // [n_streams][frames_cap]
   RaCmd *cmd;               // [n_streams][frames_cap][Ppad]
+  int32_t *cmd_non;         // [n_streams][frames_cap] number of note-on commands of the frame (their RaCmd.type carries the rank << 8)
   double *voc_mix;          // [n_streams][n] when the vocoder is enabled
   int64_t mix_cap;
   double *seg_sd;           // [n_streams][seg_cap][SD_COUNT][Ppad] channel state at the start of every segment of the block

@@ -221,29 +221,31 @@ __device__ inline void render_range_fast(Chan &c, const SynLds &L, const SynCons
 // the one-shots of one analysis frame, in the order the reference queued them.  Workgroup-uniform control flow.
 // PHASE: the oscillator is carried as its angle theta (propagate kernel) instead of the phasor (cre, cim).
 template <bool PHASE>
-__device__ inline void apply_frame_events(Chan &c, const RaCmd &cmd, const SynLds &L, const SynConst &k, const RaParams &p, const RaBuffers &b, int l) {
-  const int Ppad = p.Ppad;
-  for (int i = l; i < 2 * Ppad; i += Ppad) L.ev_lane[i] = -1;
-  __syncthreads();
-  if (cmd.type == RA_CMD_OFF) {
+__device__ inline void apply_frame_events(Chan &c, const RaCmd &cmd, int n_on, const SynLds &L, const SynConst &k, const RaParams &p, const RaBuffers &b, int l) {
+  const int ctype = cmd.type & 0xff;
+  if (ctype == RA_CMD_OFF) {
     // canHandleExplicitKeyReleaseNow(0) && onKeyReleased(0), gen.crtp.h:581-583
     if (env_can_release_now(c, 0)) env_on_key_released(c, 0);
-  } else if (cmd.type == RA_CMD_CHANGE) { // gen.crtp.h:600-616
+  } else if (ctype == RA_CMD_CHANGE) { // gen.crtp.h:600-616
     float angleIncrements = 2 * cmd.freq / p.sample_rate;
     float angleIncrementsMult = angleIncrements * 1.f;
     c.target = (double)0.1f * (double)cmd.vel; c.flags |= FL_HAS_TARGET;
     chan_set_angle_increments(c, (double)angleIncrementsMult, 0);
-  } else if (cmd.type == RA_CMD_ON) {
-    L.ev_lane[cmd.ord] = l;
+  } else if (ctype == RA_CMD_ON) {
+    L.ev_lane[cmd.type >> 8] = l; // rank among the frame's note-ons, in the reference's one-shot order
   }
+  if (n_on == 0) return; // nothing reads the exchange arrays (workgroup-uniform)
   L.x_inc[l] = angle_increments(c, 0);
   L.x_cre[l] = PHASE ? c.theta : c.cre;
   L.x_cim[l] = c.cim;
   L.x_act[l] = rt_active(c) ? 1 : 0;
   __syncthreads();
-  for (int e = 0; e < 2 * Ppad; ++e) {
+  // scratch for the broadcast of one note-on's increment and the lowest matching lane (the tile is idle between hops)
+  double *bc_ai = L.tile;
+  int *bc_src = reinterpret_cast<int *>(L.tile + 1);
+  for (int e = 0; e < n_on; ++e) {
     const int el = L.ev_lane[e];
-    if (el < 0) continue;
+    double ai = 0.0;
     if (el == l) {
       // -- onEvent(NoteOn), gen.crtp.h:389-449 --
       if (c.state != ENV_DONE2) atomicOr(b.error_flags, RA_ERR_BOOKKEEPING); // tryAcquire must succeed here
@@ -262,15 +264,21 @@ __device__ inline void apply_frame_events(Chan &c, const RaCmd &cmd, const SynLd
       // setupAudioElement, gen.sine.h:9-21
       float inc_f = 2 * (cmd.freq * 1.f) / p.sample_rate;
       chan_set_angle_increments(c, (double)inc_f, 0);
-      // -- the one-shot, gen.crtp.h:455-527: setPhase (:128-156) then onKeyPressed(0) --
-      const double ai = angle_increments(c, 0);
-      int src = -1;
-      for (int q = 0; q < p.P; ++q) {
-        if (q == l) continue;
-        if (!L.x_act[q]) continue;
-        if (L.x_inc[q] == ai) { src = q; break; }
-      }
-      if (src >= 0) { // synchronizeAngles :2397-2399
+      ai = angle_increments(c, 0);
+      *bc_ai = ai;
+      *bc_src = 0x7fffffff;
+    }
+    __syncthreads();
+    // -- the one-shot, gen.crtp.h:455-527: setPhase (:128-156): the first RT-active channel (in channel order) whose increment
+    //    equals this one's donates its phase; every lane tests itself, the lowest match wins
+    {
+      const bool match = l != el && l < p.P && L.x_act[l] && L.x_inc[l] == *bc_ai;
+      if (match) atomicMin(bc_src, l);
+    }
+    __syncthreads();
+    if (el == l) {
+      const int src = *bc_src;
+      if (src != 0x7fffffff) { // synchronizeAngles :2397-2399
         if (PHASE) c.theta = L.x_cre[src]; else { c.cre = L.x_cre[src]; c.cim = L.x_cim[src]; }
       } else {
         float a = (p.phase_policy == RA_PHASE_HASH) ? hash_uniform_pm1(k.seed, (uint64_t)cmd.noteid, 0) : 0.f;
@@ -305,7 +313,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_serial_kernel(RaPara
     t = seg_end;
     if (i == sp.nfb) break;
     const RaCmd cmd = b.cmd[((size_t)s * b.frames_cap + sp.fb0 + i) * Ppad + l];
-    apply_frame_events<false>(c, cmd, L, k, p, b, l);
+    apply_frame_events<false>(c, cmd, b.cmd_non[(size_t)s * b.frames_cap + sp.fb0 + i], L, k, p, b, l);
   }
   store_chan(c, sd, si, Ppad, l);
 }
@@ -329,7 +337,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_propagate_kernel(RaP
     t = seg_end;
     if (i == sp.nfb) break;
     const RaCmd cmd = b.cmd[((size_t)s * b.frames_cap + sp.fb0 + i) * Ppad + l];
-    apply_frame_events<true>(c, cmd, L, k, p, b, l);
+    apply_frame_events<true>(c, cmd, b.cmd_non[(size_t)s * b.frames_cap + sp.fb0 + i], L, k, p, b, l);
   }
   store_chan(c, sd, si, Ppad, l);
 }

@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, i
       } else if (succ) {
         int c = free_list[crank];
         int64_t noteid = st.next_noteid + crank + 1;        // ++next_noteid for every attempted note-on, lib.cpp:350
-        ctype[c] = RA_CMD_ON; cord[c] = evi; cfreq[c] = nf[idx]; cvel[c] = nv[idx]; cnote[c] = noteid;
+        ctype[c] = RA_CMD_ON | (srank << 8); cord[c] = evi; cfreq[c] = nf[idx]; cvel[c] = nv[idx]; cnote[c] = noteid;
         held[c] = 1;
         minch[c] = nmc[idx];
         int slot = n_played + srank;
@@ -182,6 +182,7 @@ __global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, i
     }
     st.next_noteid += cand_base;
     st.dropped_note_on += cand_base - succ_base;
+    if (lane == 0) b.cmd_non[(size_t)s * b.frames_cap + fb] = succ_base;
     const int n_new = n_played + succ_base;
     __syncthreads();
 
