@@ -13,6 +13,8 @@
 
 extern __shared__ __align__(16) unsigned char ra_smem[];
 
+__host__ __device__ inline int ra_list_capacity(const RaParams &p) { return (p.harm_pre != 0.f || p.harm_post != 0.f) ? 2 * p.maxr : p.maxr; }
+
 namespace {
 
 __device__ inline double sqmag_to_db(double x) { return 10.0 * log10(x > 1e-300 ? x : 1e-300); }
@@ -111,6 +113,23 @@ __device__ inline float equal_loudness_db(const double *arr, const float *elv, d
   return ratio * elv[i] + (1.f - ratio) * elv[i - 1];
 }
 
+// exclusive prefix sum of one int per thread over the 256-thread workgroup: scan[tid] = sum of v over lower threads, scan[T] = total
+// (wave-level shuffles + 4 wave totals; scan needs T + 5 ints)
+__device__ inline void block_exclusive_scan(int *scan, int v, int tid) {
+  constexpr int T = RA_ANALYSIS_THREADS;
+  const int lane = tid & 63, w = tid >> 6;
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o); if (lane >= o) x += y; }
+  if (lane == 63) scan[T + 1 + w] = x;
+  __syncthreads();
+  int base = 0;
+  for (int i = 0; i < w; ++i) base += scan[T + 1 + i];
+  scan[tid] = base + x - v;
+  if (tid == T - 1) scan[T] = base + x;
+  __syncthreads();
+}
+
 __global__ void __launch_bounds__(RA_ANALYSIS_THREADS)
 ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int64_t t0, int64_t n, int64_t f_lo, int fb0, int nfb_total) {
   const int tid = threadIdx.x;
@@ -120,8 +139,9 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   const int M = p.M, N = p.N, T = RA_ANALYSIS_THREADS;
 
   double2 *z = reinterpret_cast<double2 *>(ra_smem);           // [max(M,1)]
-  double2 *listA = z + (M > 0 ? M : 1);                        // [2*maxr]
-  double2 *listB = listA + 2 * p.maxr;                         // [2*maxr]
+  const int cap = ra_list_capacity(p);                         // harmonize may double a list; otherwise maxr entries suffice
+  double2 *listA = z + (M > 0 ? M : 1);                        // [cap]
+  double2 *listB = listA + cap;                                // [cap]
   int *scan = reinterpret_cast<int *>(listA);                   // [T+1], aliases listA: consumed (K read) before the lists are written
 
   // ---- 1. load the window (coalesced), weight it, scatter to bit-reversed slots -------------------
@@ -180,14 +200,7 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
     double a = z[i - 1].x, m = z[i].x, c = z[i + 1].x;
     cnt += (a < m && m >= c) ? 1 : 0;
   }
-  scan[tid] = cnt;
-  __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    for (int i = 0; i < T; ++i) { int v = scan[i]; scan[i] = acc; acc += v; }
-    scan[T] = acc;
-  }
-  __syncthreads();
+  block_exclusive_scan(scan, cnt, tid);
   {
     int pos = scan[tid];
     const double bin_hz = (double)p.sample_rate / (double)p.L;
@@ -247,16 +260,8 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   {
     int kept = 0;
     for (int r = r0; r < r1; ++r) { double sv, spv; interval(r, sv, spv); kept += !(sv < p.min_volume) ? 1 : 0; }
-    scan[tid] = kept;
+    block_exclusive_scan(scan, kept, tid);
   }
-  __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    for (int i = 0; i < T; ++i) { int v = scan[i]; scan[i] = acc; acc += v; }
-    scan[T] = acc;
-  }
-  __syncthreads();
-  const int cap = 2 * p.maxr;
   int pos = scan[tid];
   const int Rk = scan[T];
   __syncthreads(); // scan aliases listA: everyone has its offset before the list is written
@@ -342,8 +347,8 @@ __global__ void ra_roll_history_kernel(RaParams p, RaBuffers b, const float *__r
 
 size_t ra_analysis_lds_bytes(const RaParams &p) {
   size_t m = p.M > 0 ? p.M : 1;
-  size_t lists = 4 * (size_t)p.maxr * sizeof(double2);
-  size_t scan = (RA_ANALYSIS_THREADS + 1) * sizeof(int);
+  size_t lists = 2 * (size_t)ra_list_capacity(p) * sizeof(double2);
+  size_t scan = (RA_ANALYSIS_THREADS + 8) * sizeof(int);
   return m * sizeof(double2) + (lists > scan ? lists : scan);
 }
 

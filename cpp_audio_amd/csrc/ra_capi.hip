@@ -302,6 +302,7 @@ int build_tables(ra_context *c) {
   p.vol_mod = cfg.voice_volume;
   p.vol_car = cfg.carrier_volume;
   p.vol_voc = cfg.vocoder_volume;
+  p.render_mode = cfg.reference_order >= 2 ? cfg.reference_order : 0;
   p.voc_enabled = (cfg.voice_volume != 0.f || cfg.carrier_volume != 0.f || cfg.vocoder_volume != 0.f) ? 1 : 0;
 
   RaBuffers &b = c->b;
@@ -437,7 +438,7 @@ int ensure_scratch(ra_context *c, int64_t nfb, int64_t n, int n_chunks) {
     if ((r = dev_alloc(c, &b.cmd, S * F * p.Ppad, false))) return r;
     if ((r = dev_alloc(c, &b.cmd_non, S * F))) return r;
   }
-  if (!c->cfg.reference_order && nfb + n_chunks > b.seg_cap) {
+  if (c->cfg.reference_order != 1 && nfb + n_chunks > b.seg_cap) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     dev_free(c, b.seg_sd); dev_free(c, b.seg_si);
     size_t S = p.n_streams, G = static_cast<size_t>(nfb + kMaxChunks);
@@ -525,7 +526,7 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
   int64_t f_lo, nfb;
   frames_in_block(p, t0, n, f_lo, nfb);
   int n_chunks = 1;
-  if (!c->cfg.reference_order && nfb >= 64) n_chunks = static_cast<int>(std::min<int64_t>(kMaxChunks, nfb / 48));
+  if (c->cfg.reference_order != 1 && nfb >= 64) n_chunks = static_cast<int>(std::min<int64_t>(kMaxChunks, nfb / 48));
   int r = ensure_scratch(c, nfb, n, n_chunks);
   if (r) return r;
   c->b.dbg_sqmag = c->dbg_sqmag;
@@ -538,7 +539,7 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
     timed_launch(c, ST_ANALYSIS, user, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, 0, nfb, nfb, user); });
     timed_launch(c, ST_TRACK, user, [&] { ra_launch_track(p, b, f_lo, 0, nfb, user); });
     if (p.voc_enabled) timed_launch(c, ST_VOCODER, user, [&] { ra_launch_vocoder(p, b, d_voice, d_carrier, t0, n, user); });
-    if (c->cfg.reference_order) timed_launch(c, ST_RENDER, user, [&] { ra_launch_synth_serial(p, b, sp, d_out, d_out_d, user); });
+    if (c->cfg.reference_order == 1) timed_launch(c, ST_RENDER, user, [&] { ra_launch_synth_serial(p, b, sp, d_out, d_out_d, user); });
     else {
       timed_launch(c, ST_PROPAGATE, user, [&] { ra_launch_synth_propagate(p, b, sp, user); });
       timed_launch(c, ST_RENDER, user, [&] { ra_launch_synth_render(p, b, sp, d_out, d_out_d, user); });

@@ -34,6 +34,7 @@ struct RaParams {
   // vocoder
   int voc_enabled, voc_S, voc_Wm, voc_Lm, voc_Mm, voc_Lc, voc_Mc, voc_bands;
   float vol_mod, vol_car, vol_voc;
+  int render_mode; // diagnostics: 0 regime renderer, 2 hop-parallel with the reference-order step, 3 with the cheap generic step
 };
 
 // ---- analysis -> tracking hand-off: one list per (stream, frame) ----------------------------------

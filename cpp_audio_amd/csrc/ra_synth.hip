@@ -153,47 +153,100 @@ __device__ inline void render_range_fast(Chan &c, const SynLds &L, const SynCons
                                          int64_t t0, int64_t n, const double *__restrict__ mix, float *__restrict__ out, double *__restrict__ out_d) {
   const int Ppad = p.Ppad, stride1 = Ppad + 1;
   const double inv_dur = 1.0 / k.dur;
+  const double lim = k.dur - 0.5; // a glide step that finds cur > lim clamps (InterpolatedFreq::step, audioelement.h:2768-2770)
   Regime r;
   regime_setup(c, k, inv_dur, r);
   constexpr int TD = 8; // tile depth: 16 rows x (Ppad + 1) doubles of LDS per workgroup -> up to 4 waves per SIMD stay resident
+
+  // the common step of a lane inside a regular stretch; (cd, sd) = per-step rotation of the oscillator's rotation (glides only)
+  auto fast_step = [&](double cd, double sd) -> double {
+    if (r.gliding) {
+      const double f = fma(r.slope, c.cur, r.base);
+      c.fres = f;
+      c.cur = fma(r.alpha, c.cur, r.beta);
+      const double mr = fma(c.mre, cd, -(c.mim * sd)), mi = fma(c.mre, sd, c.mim * cd);
+      c.mre = mr; c.mim = mi; c.inc = f;
+      if (r.hi) c.alias = alias_mult(f);
+    }
+    const double re = fma(c.cre, c.mre, -(c.cim * c.mim));
+    const double im = fma(c.cre, c.mim, c.cim * c.mre);
+    const double g = 0.5 * (3.0 - fma(re, re, im * im));
+    c.cre = re * g; c.cim = im * g;
+    c.y = fma(c.k, c.target - c.y, c.y);
+    c.vol = c.y;
+    c.value += r.dv;
+    ++r.pending; --r.steps_left;
+    return c.vol * ((c.alias * c.cim) * c.value);
+  };
+
   while (t < seg_end) {
     const int m = (int)min((int64_t)TD, seg_end - t);
-    for (int i = 0; i < m; ++i) {
-      double v = 0.0;
-      const bool irr = r.active && (r.irregular || r.steps_left == 0 || (r.gliding && c.cur + 0.5 > k.dur));
-      if (__any(irr)) {
-        if (irr) {
-          if (r.pending) env_jump(c, k.ep, r.pending);
-          chan_step_fast(c, k.ep, k.dur, inv_dur, k.max_filter_inc);
-          if (rt_active(c)) v = c.vol * ((c.alias * c.cim) * c.value);
-          regime_setup(c, k, inv_dur, r);
+    // Rotation of `mult` per step while gliding: pi (inc_i - inc_{i-1}).  The tile's first step turns by d0 = pi (inc_0 - inc),
+    // whatever the oscillator's increment currently is (0 right after a note change); the later steps turn by
+    // pi slope (cur_i - cur_{i-1}), a geometric sequence with ratio alpha (|alpha - 1| ~ 1e-5): their mean serves all of them.
+    double cd0 = 1.0, sd0 = 0.0, cd = 1.0, sd = 0.0, step0 = 0.0;
+    if (r.active && r.gliding) {
+      step0 = fma(r.alpha - 1.0, c.cur, r.beta);                       // cur increment of the tile's first step
+      const double d0 = M_PI * (fma(r.slope, c.cur, r.base) - c.inc);
+      const double dA = (M_PI * r.slope) * step0 * (1.0 + 0.5 * (m - 2) * (r.alpha - 1.0));
+      double d2 = d0 * d0;
+      sd0 = d0 * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
+      cd0 = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
+      d2 = dA * dA;
+      sd = dA * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
+      cd = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
+    }
+    // a tile is clean for a lane if no transition can fall inside it: then the loop needs no per-sample checks
+    const bool clean = !r.active || (!r.irregular && r.steps_left >= m &&
+                                     (!r.gliding || (fabs(r.alpha - 1.0) < 1e-2 && c.cur + (m - 1) * fabs(step0) * 1.1 <= lim)));
+    if (__all(clean)) {
+      for (int i = 0; i < m; ++i) {
+        double v = 0.0;
+        if (r.active) {
+          if (p.render_mode >= 4 && r.gliding) { // diagnostics: exact per-step rotation update
+            const double d = M_PI * (fma(r.slope, c.cur, r.base) - c.inc);
+            const double d2 = d * d;
+            sd = d * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
+            cd = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
+            v = fast_step(cd, sd);
+          } else v = (i == 0) ? fast_step(cd0, sd0) : fast_step(cd, sd);
         }
+        L.tile[i * stride1 + l] = c.gL * v;
+        L.tile[(TD + i) * stride1 + l] = c.gR * v;
       }
-      if (!irr && r.active) {
-        const double f = fma(r.slope, c.cur, r.base);
-        if (r.gliding) {
-          c.fres = f;
-          c.cur = fma(r.alpha, c.cur, r.beta);
-          const double d = M_PI * (f - c.inc);
-          const double d2 = d * d;
-          const double sd = d * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
-          const double cd = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
-          const double mr = fma(c.mre, cd, -(c.mim * sd)), mi = fma(c.mre, sd, c.mim * cd);
-          c.mre = mr; c.mim = mi; c.inc = f;
-          if (r.hi) c.alias = alias_mult(f);
+      if (r.active && r.gliding && p.render_mode < 4) {
+        // over the m' = m - 1 later steps the even spread runs ahead of the exact (linearly growing) rotation by b (j+1)(m'-1-j)/2
+        // at step j, b = pi slope step0 (alpha - 1); the oscillator has integrated that: take the sum b (m'-1) m' (m'+1) / 12 back out
+        const double dl = (M_PI * r.slope) * step0 * (r.alpha - 1.0) * ((m - 2) * (m - 1) * m * (1.0 / 12.0));
+        const double re = fma(c.cim, dl, c.cre), im = fma(-c.cre, dl, c.cim);
+        c.cre = re; c.cim = im;
+      }
+    } else {
+      for (int i = 0; i < m; ++i) {
+        double v = 0.0;
+        const bool irr = r.active && (r.irregular || r.steps_left == 0 || (r.gliding && c.cur > lim));
+        if (__any(irr)) {
+          if (irr) {
+            if (r.pending) env_jump(c, k.ep, r.pending);
+            chan_step_fast(c, k.ep, k.dur, inv_dur, k.max_filter_inc);
+            if (rt_active(c)) v = c.vol * ((c.alias * c.cim) * c.value);
+            regime_setup(c, k, inv_dur, r);
+          }
         }
-        const double re = fma(c.cre, c.mre, -(c.cim * c.mim));
-        const double im = fma(c.cre, c.mim, c.cim * c.mre);
-        const double g = 0.5 * (3.0 - fma(re, re, im * im));
-        c.cre = re * g; c.cim = im * g;
-        c.y = fma(c.k, c.target - c.y, c.y);
-        c.vol = c.y;
-        c.value += r.dv;
-        ++r.pending; --r.steps_left;
-        v = c.vol * ((c.alias * c.cim) * c.value);
+        if (!irr && r.active) {
+          // exact per-step rotation update here (the lane may have just left a transition)
+          double cdi = 1.0, sdi = 0.0;
+          if (r.gliding) {
+            const double d = M_PI * (fma(r.slope, c.cur, r.base) - c.inc);
+            const double d2 = d * d;
+            sdi = d * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
+            cdi = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
+          }
+          v = fast_step(cdi, sdi);
+        }
+        L.tile[i * stride1 + l] = c.gL * v;
+        L.tile[(TD + i) * stride1 + l] = c.gR * v;
       }
-      L.tile[i * stride1 + l] = c.gL * v;
-      L.tile[(TD + i) * stride1 + l] = c.gR * v;
     }
     __syncthreads();
     if (l < 64) { // 16 outputs (8 frames x 2) x 4 channel quarters
@@ -355,7 +408,9 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_render_kernel(RaPara
   chan_from_phase(c);
   const SynConst k = syn_const(p, s);
   const double *mix = (p.voc_enabled && b.voc_mix) ? b.voc_mix + (size_t)s * sp.n : nullptr;
-  render_range_fast(c, L, k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
+  if (p.render_mode == 2) render_range<false>(c, L, k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
+  else if (p.render_mode == 3) render_range<true>(c, L, k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
+  else render_range_fast(c, L, k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
 }
 
 } // namespace
@@ -370,6 +425,6 @@ void ra_launch_synth_propagate(const RaParams &p, const RaBuffers &b, const RaSp
 }
 void ra_launch_synth_render(const RaParams &p, const RaBuffers &b, const RaSpan &sp, float *d_out, double *d_out_d, hipStream_t st) {
   if (sp.ct1 <= sp.ct0) return;
-  const size_t lds_render = (size_t)16 * (p.Ppad + 1) * sizeof(double); // the 8-frame output tile only
+  const size_t lds_render = p.render_mode ? syn_lds_bytes(p.Ppad) : (size_t)16 * (p.Ppad + 1) * sizeof(double); // the 8-frame output tile only
   hipLaunchKernelGGL(ra_synth_render_kernel, dim3((unsigned)(sp.nfb + 1), (unsigned)p.n_streams), dim3((unsigned)p.Ppad), lds_render, st, p, b, sp, d_out, d_out_d);
 }
