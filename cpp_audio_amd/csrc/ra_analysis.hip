@@ -144,6 +144,7 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   double2 *listB = listA + cap;                                // [cap]
   int *scan = reinterpret_cast<int *>(listA);                   // [T+1], aliases listA: consumed (K read) before the lists are written
 
+  RaPhaseClock clk(b.dbg_clk, tid == 0);
   // ---- 1. load the window (coalesced), weight it, scatter to bit-reversed slots -------------------
   {
     const int64_t start = 2 + f * (int64_t)p.H; // absolute index of the window's first sample
@@ -166,9 +167,11 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
     for (int k = tid; k < M; k += T) z[b.bitrev[k]] = make_double2(sample(2 * k), sample(2 * k + 1));
   }
   __syncthreads();
+  clk.mark(0);
 
   // ---- 2. in-place radix-2 DIT, M points ----------------------------------------------------------
   ra_fft_dit(z, M, b.tw_half, tid, T, false);
+  clk.mark(1);
 
   // ---- 3. split into the real spectrum, |X|^2 written over .x of the same slots -------------------
   // X[k] = E[k] + W^k O[k],  E = (Z[k] + conj Z[M-k]) / 2,  O = -i/2 (Z[k] - conj Z[M-k]);  bins 0..M-1 kept
@@ -186,6 +189,7 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
     if (km != k) z[km].x = sm;
   }
   __syncthreads();
+  clk.mark(2);
   if (b.dbg_sqmag) {
     double *dst = b.dbg_sqmag + ((size_t)s * nfb_total + fb) * M;
     for (int k = tid; k < M; k += T) dst[k] = z[k].x;
@@ -201,6 +205,7 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
     cnt += (a < m && m >= c) ? 1 : 0;
   }
   block_exclusive_scan(scan, cnt, tid);
+  clk.mark(3);
   {
     int pos = scan[tid];
     const double bin_hz = (double)p.sample_rate / (double)p.L;
@@ -222,6 +227,7 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
     }
   }
   __syncthreads();
+  clk.mark(4);
 
   // ---- 5. aggregate_pitches + reduce_pitches (algo.cpp:124-184, PonderateByVolume / SumVolumes) -------------------
   // Pitches ascend, so an interval opened at peak i0 runs up to the first peak j with pitch[j] - pitch[i0] > nearby:
@@ -242,6 +248,7 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
     z[i].x = (double)lo;
   }
   __syncthreads();
+  clk.mark(5);
   if (tid == 0) {
     int R = 0;
     for (int i = 0; i < K; i = (int)z[i].x) z[Mh + R++].x = (double)i;
@@ -249,6 +256,7 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
     scan[T] = R;
   }
   __syncthreads();
+  clk.mark(6);
   const int R = scan[T];
   const int chunkR = (R + T - 1) / T;
   const int r0 = min(R, tid * chunkR), r1 = min(R, r0 + chunkR);
@@ -271,6 +279,7 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
     if (!(sv < p.min_volume)) { if (pos < cap) listA[pos] = make_double2(spv / sv, sv); ++pos; }
   }
   __syncthreads();
+  clk.mark(7);
 
   // ---- 6. shift / harmonize / autotune on the reduced list (tens of items): one lane ------------------------------
   int *pub = reinterpret_cast<int *>(z); // [0] = A, [1] = which list holds the result   (z is free now)
@@ -307,6 +316,7 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
     b.pl_count[(size_t)s * b.frames_cap + fb] = A;
   }
   __syncthreads();
+  clk.mark(8);
   {
     const int A = pub[0];
     const double2 *cur = pub[1] ? listB : listA;
@@ -319,6 +329,7 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
       b.pl_key[base + i] = (float)(pv.y / (double)equal_loudness_db(b.loud_pitches, b.loud_elv, pv.x));
     }
   }
+  clk.mark(9);
 }
 
 // keeps the last N input samples of every stream for the next block's overlapping windows

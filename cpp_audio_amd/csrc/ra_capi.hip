@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -34,6 +35,7 @@ struct ra_context {
   int64_t st_cap = 0;
   std::vector<float> pending_voice, pending_carrier; // ra_feed -> ra_compute
   double *dbg_sqmag = nullptr;
+  unsigned long long *dbg_clk = nullptr;
   // optional per-kernel timing with HIP events on the launch stream (ra_set_profiling)
   bool profiling = false;
   struct Timed { int stage; hipEvent_t a, b; };
@@ -527,9 +529,12 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
   frames_in_block(p, t0, n, f_lo, nfb);
   int n_chunks = 1;
   if (c->cfg.reference_order != 1 && nfb >= 64) n_chunks = static_cast<int>(std::min<int64_t>(kMaxChunks, nfb / 48));
+  static const int forced_chunks = std::getenv("RA_PIPELINE_CHUNKS") ? std::atoi(std::getenv("RA_PIPELINE_CHUNKS")) : 0; // tuning aid
+  if (forced_chunks > 0 && c->cfg.reference_order != 1 && nfb >= forced_chunks) n_chunks = std::min(forced_chunks, kMaxChunks);
   int r = ensure_scratch(c, nfb, n, n_chunks);
   if (r) return r;
   c->b.dbg_sqmag = c->dbg_sqmag;
+  c->b.dbg_clk = c->dbg_clk;
   if (c->profiling && (r = resolve_timing(c))) return r;
   const RaBuffers &b = c->b;
   hipStream_t user = c->stream;
@@ -677,6 +682,9 @@ int ra_create(const ra_config *cfg, int32_t n_streams, int32_t device, ra_contex
   c->p.n_streams = n_streams;
   if (!r) r = alloc_state(c);
   if (!r) r = init_state(c);
+  if (!r && std::getenv("RA_PHASE_CLOCKS")) {
+    r = dev_alloc(c, &c->dbg_clk, 64, true);
+  }
   if (r) { std::string keep = g_last_error; ra_destroy(c); g_last_error = keep; return r; }
   *out = c;
   return RA_OK;
@@ -686,6 +694,14 @@ void ra_destroy(ra_context *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->dbg_clk) { // tuning aid: ticks of the 100 MHz s_memtime counter per kernel phase, summed over workgroups
+    unsigned long long h[64];
+    if (hipMemcpy(h, c->dbg_clk, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+      std::fprintf(stderr, "[resynth_amd] phase clocks:");
+      for (int i = 0; i < 64; ++i) if (h[i]) std::fprintf(stderr, " [%d]=%llu", i, h[i]);
+      std::fprintf(stderr, "\n");
+    }
+  }
   for (void *p : c->allocs) (void)hipFree(p);
   for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);

@@ -111,6 +111,7 @@ struct RaBuffers {
   int32_t *seg_si;          // [n_streams][seg_cap][SI_COUNT][Ppad]
   int64_t seg_cap;
   double *dbg_sqmag;        // optional [frames][M] tap of |X|^2 (ra_sqmag), normally null
+  unsigned long long *dbg_clk; // optional [64] in-kernel phase clocks (env RA_PHASE_CLOCKS=1, printed by ra_destroy), normally null
   // ---- vocoder (only allocated when a vocoder volume is non-zero) ----
   double *voc_half_window;  // [Wm/2] Gaussian 4 sigma
   double2 *vm_tw_half, *vm_tw_full; int *vm_bitrev;   // modulator FFT, length Lm
@@ -125,6 +126,18 @@ struct RaBuffers {
   double *voc_amp;          // [n_streams][voc_mod_cap][bands]
   double *voc_sig;          // [n_streams][voc_car_cap][2S]
   int64_t voc_mod_cap, voc_car_cap;
+};
+
+// in-kernel phase timing for tuning: lane 0 of the workgroup adds the s_memtime ticks since the previous mark to slot i
+struct RaPhaseClock {
+  unsigned long long *dst, t;
+  __device__ inline RaPhaseClock(unsigned long long *d, bool on) : dst(on ? d : nullptr), t(0) { if (dst) t = __builtin_readcyclecounter(); }
+  __device__ inline void mark(int i) {
+    if (!dst) return;
+    unsigned long long now = __builtin_readcyclecounter();
+    atomicAdd(dst + i, now - t);
+    t = now;
+  }
 };
 
 // frames of the block [t0, t0+n) for a PeriodicFFT fed from sample 0 with window W and stride S: fire = W - 1 + j S

@@ -149,14 +149,52 @@ __device__ inline void regime_setup(const Chan &c, const SynConst &k, double inv
   }
 }
 
-__device__ inline void render_range_fast(Chan &c, const SynLds &L, const SynConst &k, const RaParams &p, int s, int l, int64_t t, int64_t seg_end,
+constexpr int TD = 8;            // tile depth of the regime renderer
+constexpr int TROW = 2 * TD + 1; // its LDS tile is lane-major: [Ppad][TROW] doubles, entry out * TD + frame (odd row length: conflict-free both ways)
+
+// TD steps of a lane whose wave has no transition inside the tile: straight-line code, no state machine.
+// GLIDE: some lane of the wave glides (the others run the same code with the identity rotation, alpha = 1, beta = 0);
+// HI: some gliding lane passes above fs/8, where the anti-aliasing gain follows the increment.
+// The phasor is renormalised once per tile instead of once per step (drift < 1e-15 per tile; every hop restarts from the angle).
+template <bool GLIDE, bool HI>
+__device__ inline void clean_tile(Chan &c, const Regime &r, double cd0, double sd0, double cd, double sd, double (&v)[TD]) {
+  double cur = c.cur, mre = c.mre, mim = c.mim, cre = c.cre, cim = c.cim, y = c.y, value = c.value, alias = c.alias, f = c.inc;
+  const double kk = c.k, target = c.target;
+#pragma unroll
+  for (int i = 0; i < TD; ++i) {
+    if (GLIDE) {
+      f = fma(r.slope, cur, r.base);
+      cur = fma(r.alpha, cur, r.beta);
+      const double rc = i == 0 ? cd0 : cd, rs = i == 0 ? sd0 : sd;
+      const double mr = fma(mre, rc, -(mim * rs)), mi = fma(mre, rs, mim * rc);
+      mre = mr; mim = mi;
+      if (HI) { if (r.hi) alias = alias_mult(f); }
+    }
+    const double re = fma(cre, mre, -(cim * mim)), im = fma(cre, mim, cim * mre);
+    cre = re; cim = im;
+    y = fma(kk, target - y, y);
+    value += r.dv;
+    v[i] = y * ((alias * cim) * value);
+  }
+  const double g = 0.5 * (3.0 - fma(cre, cre, cim * cim));
+  c.cre = cre * g; c.cim = cim * g;
+  c.y = y; c.vol = y; c.value = value;
+  if (GLIDE) {
+    c.mre = mre; c.mim = mim; c.cur = cur; c.alias = alias;
+    if (r.gliding) { c.fres = f; c.inc = f; }
+  }
+}
+
+__device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &k, const RaParams &p, int s, int l, int64_t t, int64_t seg_end,
                                          int64_t t0, int64_t n, const double *__restrict__ mix, float *__restrict__ out, double *__restrict__ out_d) {
-  const int Ppad = p.Ppad, stride1 = Ppad + 1;
+  const int Ppad = p.Ppad;
   const double inv_dur = 1.0 / k.dur;
   const double lim = k.dur - 0.5; // a glide step that finds cur > lim clamps (InterpolatedFreq::step, audioelement.h:2768-2770)
   Regime r;
   regime_setup(c, k, inv_dur, r);
-  constexpr int TD = 8; // tile depth: 16 rows x (Ppad + 1) doubles of LDS per workgroup -> up to 4 waves per SIMD stay resident
+  double *mine = tile + l * TROW;                                               // this lane's row
+  const int fr = l & (TD - 1), ch = (l >> 3) & 1, quarter = (l >> 4) & 3;       // reduction role of lanes 0..63
+  const double *col = tile + (quarter * (Ppad >> 2)) * TROW + ch * TD + fr;     // entry (ch, fr) of the quarter's first channel
 
   // the common step of a lane inside a regular stretch; (cd, sd) = per-step rotation of the oscillator's rotation (glides only)
   auto fast_step = [&](double cd, double sd) -> double {
@@ -181,46 +219,45 @@ __device__ inline void render_range_fast(Chan &c, const SynLds &L, const SynCons
 
   while (t < seg_end) {
     const int m = (int)min((int64_t)TD, seg_end - t);
-    // Rotation of `mult` per step while gliding: pi (inc_i - inc_{i-1}).  The tile's first step turns by d0 = pi (inc_0 - inc),
-    // whatever the oscillator's increment currently is (0 right after a note change); the later steps turn by
-    // pi slope (cur_i - cur_{i-1}), a geometric sequence with ratio alpha (|alpha - 1| ~ 1e-5): their mean serves all of them.
-    double cd0 = 1.0, sd0 = 0.0, cd = 1.0, sd = 0.0, step0 = 0.0;
-    if (r.active && r.gliding) {
-      step0 = fma(r.alpha - 1.0, c.cur, r.beta);                       // cur increment of the tile's first step
-      const double d0 = M_PI * (fma(r.slope, c.cur, r.base) - c.inc);
-      const double dA = (M_PI * r.slope) * step0 * (1.0 + 0.5 * (m - 2) * (r.alpha - 1.0));
-      double d2 = d0 * d0;
-      sd0 = d0 * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
-      cd0 = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
-      d2 = dA * dA;
-      sd = dA * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
-      cd = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
-    }
     // a tile is clean for a lane if no transition can fall inside it: then the loop needs no per-sample checks
-    const bool clean = !r.active || (!r.irregular && r.steps_left >= m &&
-                                     (!r.gliding || (fabs(r.alpha - 1.0) < 1e-2 && c.cur + (m - 1) * fabs(step0) * 1.1 <= lim)));
-    if (__all(clean)) {
-      for (int i = 0; i < m; ++i) {
-        double v = 0.0;
-        if (r.active) {
-          if (p.render_mode >= 4 && r.gliding) { // diagnostics: exact per-step rotation update
-            const double d = M_PI * (fma(r.slope, c.cur, r.base) - c.inc);
-            const double d2 = d * d;
-            sd = d * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
+    double step0 = 0.0;
+    if (r.active && r.gliding) step0 = fma(r.alpha - 1.0, c.cur, r.beta); // cur increment of the tile's first step
+    const bool clean = !r.active || (!r.irregular && r.steps_left >= TD &&
+                                     (!r.gliding || (fabs(r.alpha - 1.0) < 1e-2 && c.cur + (TD - 1) * fabs(step0) * 1.1 <= lim)));
+    if (m == TD && __all(clean)) {
+      double v[TD];
+#pragma unroll
+      for (int i = 0; i < TD; ++i) v[i] = 0.0;
+      const bool any_glide = __any(r.active && r.gliding);
+      if (r.active) {
+        if (!any_glide) clean_tile<false, false>(c, r, 1.0, 0.0, 1.0, 0.0, v);
+        else {
+          // Rotation of `mult` per step while gliding: pi (inc_i - inc_{i-1}).  The tile's first step turns by d0 = pi (inc_0 - inc),
+          // whatever the oscillator's increment currently is (0 right after a note change); the later steps turn by
+          // pi slope (cur_i - cur_{i-1}), a geometric sequence with ratio alpha (|alpha - 1| ~ 1e-5): their mean serves all of them.
+          double cd0 = 1.0, sd0 = 0.0, cd = 1.0, sd = 0.0;
+          if (r.gliding) {
+            const double d0 = M_PI * (fma(r.slope, c.cur, r.base) - c.inc);
+            const double dA = (M_PI * r.slope) * step0 * (1.0 + 0.5 * (TD - 2) * (r.alpha - 1.0));
+            double d2 = d0 * d0;
+            sd0 = d0 * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
+            cd0 = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
+            d2 = dA * dA;
+            sd = dA * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
             cd = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
-            v = fast_step(cd, sd);
-          } else v = (i == 0) ? fast_step(cd0, sd0) : fast_step(cd, sd);
+          }
+          if (__any(r.active && r.gliding && r.hi)) clean_tile<true, true>(c, r, cd0, sd0, cd, sd, v);
+          else clean_tile<true, false>(c, r, cd0, sd0, cd, sd, v);
+          // over the m' = TD - 1 later steps the even spread runs ahead of the exact (linearly growing) rotation by b (j+1)(m'-1-j)/2
+          // at step j, b = pi slope step0 (alpha - 1); the oscillator has integrated that: take the sum b (m'-1) m' (m'+1) / 12 back out
+          const double dl = (M_PI * r.slope) * step0 * (r.alpha - 1.0) * ((TD - 2) * (TD - 1) * TD * (1.0 / 12.0));
+          const double re = fma(c.cim, dl, c.cre), im = fma(-c.cre, dl, c.cim);
+          c.cre = re; c.cim = im;
         }
-        L.tile[i * stride1 + l] = c.gL * v;
-        L.tile[(TD + i) * stride1 + l] = c.gR * v;
+        r.pending += TD; r.steps_left -= TD;
       }
-      if (r.active && r.gliding && p.render_mode < 4) {
-        // over the m' = m - 1 later steps the even spread runs ahead of the exact (linearly growing) rotation by b (j+1)(m'-1-j)/2
-        // at step j, b = pi slope step0 (alpha - 1); the oscillator has integrated that: take the sum b (m'-1) m' (m'+1) / 12 back out
-        const double dl = (M_PI * r.slope) * step0 * (r.alpha - 1.0) * ((m - 2) * (m - 1) * m * (1.0 / 12.0));
-        const double re = fma(c.cim, dl, c.cre), im = fma(-c.cre, dl, c.cim);
-        c.cre = re; c.cim = im;
-      }
+#pragma unroll
+      for (int i = 0; i < TD; ++i) { mine[i] = c.gL * v[i]; mine[TD + i] = c.gR * v[i]; }
     } else {
       for (int i = 0; i < m; ++i) {
         double v = 0.0;
@@ -244,18 +281,19 @@ __device__ inline void render_range_fast(Chan &c, const SynLds &L, const SynCons
           }
           v = fast_step(cdi, sdi);
         }
-        L.tile[i * stride1 + l] = c.gL * v;
-        L.tile[(TD + i) * stride1 + l] = c.gR * v;
+        mine[i] = c.gL * v;
+        mine[TD + i] = c.gR * v;
       }
     }
     __syncthreads();
     if (l < 64) { // 16 outputs (8 frames x 2) x 4 channel quarters
-      const int fr = l & (TD - 1), ch = (l >> 3) & 1, quarter = l >> 4;
       double acc = 0.0;
       if (fr < m) {
-        const double *row = L.tile + (ch * TD + fr) * stride1;
-        const int c0 = quarter * (Ppad >> 2), c1 = c0 + (Ppad >> 2);
-        for (int q = c0; q < c1; ++q) acc += row[q];
+        const double *q = col;
+        for (int blk = 0; blk < (Ppad >> 6); ++blk, q += 16 * TROW) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) acc += q[j * TROW];
+        }
       }
       acc += __shfl_down(acc, 32);
       acc += __shfl_down(acc, 16);
@@ -396,21 +434,30 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_propagate_kernel(RaP
 }
 
 // ---- K3b: render one segment ----------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_render_kernel(RaParams p, RaBuffers b, RaSpan sp, float *__restrict__ out, double *__restrict__ out_d) {
+template <bool DIAG>
+__device__ inline void render_segment(const RaParams &p, const RaBuffers &b, const RaSpan &sp, float *__restrict__ out, double *__restrict__ out_d) {
   const int i = blockIdx.x, s = blockIdx.y, l = threadIdx.x, Ppad = p.Ppad;
   const int64_t seg_begin = (i == 0) ? sp.ct0 : ra_fire_sample(p.N, p.H, sp.f_lo + sp.fb0 + i - 1);
   const int64_t seg_end = (i < sp.nfb) ? ra_fire_sample(p.N, p.H, sp.f_lo + sp.fb0 + i) : sp.ct1;
   if (seg_end <= seg_begin) return;
-  SynLds L = carve(ra_smem_syn, Ppad);
   const size_t seg = (size_t)s * b.seg_cap + sp.seg0 + i;
   Chan c;
   load_chan(c, b.seg_sd + seg * SD_COUNT * Ppad, b.seg_si + seg * SI_COUNT * Ppad, Ppad, l);
   chan_from_phase(c);
   const SynConst k = syn_const(p, s);
   const double *mix = (p.voc_enabled && b.voc_mix) ? b.voc_mix + (size_t)s * sp.n : nullptr;
-  if (p.render_mode == 2) render_range<false>(c, L, k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
-  else if (p.render_mode == 3) render_range<true>(c, L, k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
-  else render_range_fast(c, L, k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
+  if (DIAG) {
+    SynLds L = carve(ra_smem_syn, Ppad);
+    if (p.render_mode == 2) render_range<false>(c, L, k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
+    else render_range<true>(c, L, k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
+  } else render_range_fast(c, reinterpret_cast<double *>(ra_smem_syn), k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
+}
+__global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_render_kernel(RaParams p, RaBuffers b, RaSpan sp, float *__restrict__ out, double *__restrict__ out_d) {
+  render_segment<false>(p, b, sp, out, out_d);
+}
+// tuning aid (ra_config.reference_order 2 / 3): hop-parallel like the product kernel, but every sample takes the general step
+__global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_render_diag_kernel(RaParams p, RaBuffers b, RaSpan sp, float *__restrict__ out, double *__restrict__ out_d) {
+  render_segment<true>(p, b, sp, out, out_d);
 }
 
 } // namespace
@@ -425,6 +472,7 @@ void ra_launch_synth_propagate(const RaParams &p, const RaBuffers &b, const RaSp
 }
 void ra_launch_synth_render(const RaParams &p, const RaBuffers &b, const RaSpan &sp, float *d_out, double *d_out_d, hipStream_t st) {
   if (sp.ct1 <= sp.ct0) return;
-  const size_t lds_render = p.render_mode ? syn_lds_bytes(p.Ppad) : (size_t)16 * (p.Ppad + 1) * sizeof(double); // the 8-frame output tile only
-  hipLaunchKernelGGL(ra_synth_render_kernel, dim3((unsigned)(sp.nfb + 1), (unsigned)p.n_streams), dim3((unsigned)p.Ppad), lds_render, st, p, b, sp, d_out, d_out_d);
+  const dim3 grid((unsigned)(sp.nfb + 1), (unsigned)p.n_streams), block((unsigned)p.Ppad);
+  if (p.render_mode) hipLaunchKernelGGL(ra_synth_render_diag_kernel, grid, block, syn_lds_bytes(p.Ppad), st, p, b, sp, d_out, d_out_d);
+  else hipLaunchKernelGGL(ra_synth_render_kernel, grid, block, (size_t)p.Ppad * TROW * sizeof(double), st, p, b, sp, d_out, d_out_d); // the 8-frame tile only
 }

@@ -10,7 +10,7 @@ x = np.concatenate([signals.make_streams(3, n), signals.make_streams(2, n, kind=
 kw = dict(analysis_volume=1.0, stereo_spread=0.0, carrier_volume=0.0, seed=1234)
 ref = np.stack([O.run_offline(O.default_config(**dict(kw, seed=1234 + s)), x[s])[0] for s in range(5)]).astype(np.float64)
 outs = {}
-for mode in (1, 2, 3, 4, 0):
+for mode in (1, 2, 3, 0):
     with api.Context(api.default_config(reference_order=mode, **kw), 5, 0) as ctx:
         outs[mode] = ctx.process_host(x).astype(np.float64)
     d = outs[mode] - ref
