@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libresynth_amd.so")
+# RESYNTH_AMD_LIB: load another build of the same library (A/B tuning runs); the default is the in-tree build
+LIB_PATH = os.environ.get("RESYNTH_AMD_LIB") or os.path.join(_HERE, "libresynth_amd.so")
 
 RA_OK = 0
 

@@ -138,46 +138,45 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   const int64_t f = f_lo + fb;
   const int M = p.M, N = p.N, T = RA_ANALYSIS_THREADS;
 
-  double2 *z = reinterpret_cast<double2 *>(ra_smem);           // [max(M,1)]
+  double2 *z = reinterpret_cast<double2 *>(ra_smem);           // [ra_zpad_size(M)], element i lives in slot ra_zpad(i)
+  auto Z = [&](int i) -> double2 & { return z[ra_zpad(i)]; };
   const int cap = ra_list_capacity(p);                         // harmonize may double a list; otherwise maxr entries suffice
-  double2 *listA = z + (M > 0 ? M : 1);                        // [cap]
+  double2 *listA = z + ra_zpad_size(M);                        // [cap]
   double2 *listB = listA + cap;                                // [cap]
   int *scan = reinterpret_cast<int *>(listA);                   // [T+1], aliases listA: consumed (K read) before the lists are written
 
   RaPhaseClock clk(b.dbg_clk, tid == 0);
-  // ---- 1. load the window (coalesced), weight it, scatter to bit-reversed slots -------------------
+  // ---- 1 + 2. weighted window -> M point complex FFT of the packed sequence (x[2k], x[2k+1]) ------------------------
+  // the first fused pass reads its (bit-reversed) inputs straight from HBM/L2: the window is 4 N bytes, touched once
   {
     const int64_t start = 2 + f * (int64_t)p.H; // absolute index of the window's first sample
     const float *hist = b.hist + (size_t)s * N;
     const float *vs = voice ? voice + (size_t)s * n : nullptr;
     const int h = N / 2;
+    // branch-free so that the 16 sample / 16 window loads of a thread are all in flight together
+    const float *vs0 = vs ? vs : hist; // never dereferenced past the block when voice is null (the select below picks 0)
     auto sample = [&](int i) -> double {
-      if (i >= N) return 0.0;
-      int64_t a = start + i;
-      float v;
-      if (a < t0) v = hist[N - (t0 - a)]; else v = vs ? vs[a - t0] : 0.f;
+      const int ic = min(i, N - 1);
+      const int64_t a = start + ic;
+      const float *src = (a < t0) ? hist + (N - (t0 - a)) : vs0 + (vs ? a - t0 : 0);
+      float v = *src;
+      if (!(a < t0) && !vs) v = 0.f;
       float sum = 0.f;
       sum += p.input_gain * v; // analyze_until_input_starvation, lib.cpp:1626,1636 (float)
       double x = (double)sum;  // PeriodicFFT::feed stores the float as FPT = double (periodicfft.cpp:61)
-      int j = (i >= h) ? (i - h) : (h - 1 - i);
-      return x * b.half_window[j];
+      const int j = (ic >= h) ? (ic - h) : (h - 1 - ic);
+      const double w = b.half_window[j];
+      return i < N ? x * w : 0.0;
     };
-    if (M == 0) { // L == 1 cannot happen (N even >= 2), kept for safety
-    }
-    for (int k = tid; k < M; k += T) z[b.bitrev[k]] = make_double2(sample(2 * k), sample(2 * k + 1));
+    ra_fft_fused(z, M, p.log2M, b.tw_half, tid, T, [&](int k) { return make_double2(sample(2 * k), sample(2 * k + 1)); });
   }
-  __syncthreads();
-  clk.mark(0);
-
-  // ---- 2. in-place radix-2 DIT, M points ----------------------------------------------------------
-  ra_fft_dit(z, M, b.tw_half, tid, T, false);
   clk.mark(1);
 
   // ---- 3. split into the real spectrum, |X|^2 written over .x of the same slots -------------------
   // X[k] = E[k] + W^k O[k],  E = (Z[k] + conj Z[M-k]) / 2,  O = -i/2 (Z[k] - conj Z[M-k]);  bins 0..M-1 kept
   for (int k = tid; k <= (M >> 1); k += T) {
     int km = (M - k) % M; // partner (k = 0 pairs with itself, k = M/2 too)
-    double2 zk = z[k], zm = z[km];
+    double2 zk = Z(k), zm = Z(km);
     auto bin = [&](double2 a, double2 c, int kk) -> double { // a = Z[kk], c = Z[M-kk] (conjugated inside)
       double2 x = ra_real_split_bin(a, c, b.tw_full[kk]);
       return x.x * x.x + x.y * x.y;
@@ -185,45 +184,54 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
     double sk = bin(zk, zm, k);
     double sm = (km != k) ? bin(zm, zk, km) : 0.0;
     // the two slots are private to this thread: safe to overwrite now
-    z[k].x = sk;
-    if (km != k) z[km].x = sm;
+    Z(k).x = sk;
+    if (km != k) Z(km).x = sm;
   }
   __syncthreads();
   clk.mark(2);
   if (b.dbg_sqmag) {
     double *dst = b.dbg_sqmag + ((size_t)s * nfb_total + fb) * M;
-    for (int k = tid; k < M; k += T) dst[k] = z[k].x;
+    for (int k = tid; k < M; k += T) dst[k] = Z(k).x;
   }
 
   // ---- 4. local maxima -> (pitch, volume) list in bin order ---------------------------------------
-  // peak entries go to the .y halves: pitch of entry j at z[j].y, volume at z[M/2 + j].y  (count <= M/2)
+  // peak entries go to the .y halves: pitch of entry j at Z(j).y, volume at Z(M/2 + j).y  (count <= M/2 - 1).
+  // Bins are scanned in contiguous chunks (count, block scan, compact the peak bins); the logarithms are then spread evenly:
+  // thread t refines peaks t, t + T, ...
   const int chunk = (M + T - 1) / T;
   const int c0 = tid * chunk, c1 = min(M, c0 + chunk);
+  const int Mh = M >> 1;
   int cnt = 0;
   for (int i = max(c0, 1); i < c1 && i + 1 < M; ++i) {
-    double a = z[i - 1].x, m = z[i].x, c = z[i + 1].x;
+    double a = Z(i - 1).x, m = Z(i).x, c = Z(i + 1).x;
     cnt += (a < m && m >= c) ? 1 : 0;
   }
   block_exclusive_scan(scan, cnt, tid);
-  clk.mark(3);
   {
     int pos = scan[tid];
-    const double bin_hz = (double)p.sample_rate / (double)p.L;
     for (int i = max(c0, 1); i < c1 && i + 1 < M; ++i) {
-      double a = z[i - 1].x, m = z[i].x, c = z[i + 1].x;
-      if (a < m && m >= c) {
-        double da = sqmag_to_db(a), db = sqmag_to_db(m), dc = sqmag_to_db(c);
-        double den = da - 2.0 * db + dc;
-        double pp = den != 0.0 ? 0.5 * (da - dc) / den : 0.0;
-        double freq = (i + pp) * bin_hz;
-        double mag_db = db - 0.25 * (da - dc) * pp;
-        // frequencies_to_pitches, algo.cpp:10-29 with midi.h:223-232 (f > 0 always holds here: i >= 1, pp > -1/2)
-        double pitch = 69.0 + (12 / 1.0) * log2(freq / (double)440.f);
-        double vol = pow(10.0, mag_db / 20.0);
-        z[pos].y = pitch;
-        z[(M >> 1) + pos].y = vol;
-        ++pos;
-      }
+      double a = Z(i - 1).x, m = Z(i).x, c = Z(i + 1).x;
+      if (a < m && m >= c) Z(pos++).y = (double)i;
+    }
+  }
+  const int K = scan[T];
+  __syncthreads();
+  clk.mark(3);
+  {
+    const double bin_hz = (double)p.sample_rate / (double)p.L;
+    for (int pk = tid; pk < K; pk += T) {
+      const int i = (int)Z(pk).y;
+      double a = Z(i - 1).x, m = Z(i).x, c = Z(i + 1).x;
+      double da = sqmag_to_db(a), db = sqmag_to_db(m), dc = sqmag_to_db(c);
+      double den = da - 2.0 * db + dc;
+      double pp = den != 0.0 ? 0.5 * (da - dc) / den : 0.0;
+      double freq = (i + pp) * bin_hz;
+      double mag_db = db - 0.25 * (da - dc) * pp;
+      // frequencies_to_pitches, algo.cpp:10-29 with midi.h:223-232 (f > 0 always holds here: i >= 1, pp > -1/2)
+      double pitch = 69.0 + (12 / 1.0) * log2(freq / (double)440.f);
+      double vol = pow(10.0, mag_db / 20.0);
+      Z(pk).y = pitch;        // slot pk held this peak's bin: read above by this thread only
+      Z(Mh + pk).y = vol;     // Mh + pk > K - 1: never a bin slot
     }
   }
   __syncthreads();
@@ -235,24 +243,21 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   //  5b one lane follows the nxt chain from peak 0 to list the interval starts (tens to a few hundred hops)
   //  5c each interval is summed by one thread in index order (the reference's summation order) and kept if its volume
   //     reaches min_volume; kept intervals are compacted in order with a block scan
-  const int K = scan[T];
-  const int Mh = M >> 1;
-  __syncthreads();
   for (int i = tid; i < K; i += T) {
-    const double pi0 = z[i].y;
+    const double pi0 = Z(i).y;
     int lo = i + 1, hi = K;
     while (lo < hi) {
       int mid = (lo + hi) >> 1;
-      if (z[mid].y - pi0 > p.nearby) hi = mid; else lo = mid + 1;
+      if (Z(mid).y - pi0 > p.nearby) hi = mid; else lo = mid + 1;
     }
-    z[i].x = (double)lo;
+    Z(i).x = (double)lo;
   }
   __syncthreads();
   clk.mark(5);
   if (tid == 0) {
     int R = 0;
-    for (int i = 0; i < K; i = (int)z[i].x) z[Mh + R++].x = (double)i;
-    z[Mh + R].x = (double)K;   // R <= K <= Mh - 1, so slot Mh + R exists
+    for (int i = 0; i < K; i = (int)Z(i).x) Z(Mh + R++).x = (double)i;
+    Z(Mh + R).x = (double)K;   // R <= K <= Mh - 1, so slot Mh + R exists
     scan[T] = R;
   }
   __syncthreads();
@@ -261,9 +266,9 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   const int chunkR = (R + T - 1) / T;
   const int r0 = min(R, tid * chunkR), r1 = min(R, r0 + chunkR);
   auto interval = [&](int r, double &sumV, double &sumPV) {
-    const int i0 = (int)z[Mh + r].x, i1 = (int)z[Mh + r + 1].x;
+    const int i0 = (int)Z(Mh + r).x, i1 = (int)Z(Mh + r + 1).x;
     sumV = 0; sumPV = 0;
-    for (int i = i0; i < i1; ++i) { double pt = z[i].y, v = z[Mh + i].y; sumV += v; sumPV += pt * v; }
+    for (int i = i0; i < i1; ++i) { double pt = Z(i).y, v = Z(Mh + i).y; sumV += v; sumPV += pt * v; }
   };
   {
     int kept = 0;
@@ -281,32 +286,59 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   __syncthreads();
   clk.mark(7);
 
-  // ---- 6. shift / harmonize / autotune on the reduced list (tens of items): one lane ------------------------------
-  int *pub = reinterpret_cast<int *>(z); // [0] = A, [1] = which list holds the result   (z is free now)
+  // ---- 6. shift / harmonize / autotune on the reduced list ---------------------------------------------------------
+  // The autotune function (divisions, scale / chord searches) is evaluated for all items at once; one lane then runs the
+  // order-dependent merge of algo.cpp:191-229 over the precomputed values, and the harmonize steps when they are enabled.
+  int *pub = reinterpret_cast<int *>(z); // [0] = A, [1] = which list holds the result, [2] = Rn, [3] = input list, [4] = err   (z is free now)
   if (tid == 0) {
     int err = Rk > cap ? 1 : 0;
     int Rn = min(Rk, cap);
     double2 *cur = listA, *oth = listB;
-    shift_list(cur, Rn, p.shift_pre);
-    Rn = harmonize_list(cur, oth, Rn, cap, p.harm_pre, &err);
-    // autotune_pitches, algo.cpp:191-229
-    int A = 0;
-    for (int i = 0; i < Rn; ++i) {
+    if (p.harm_pre != 0.f) {
+      shift_list(cur, Rn, p.shift_pre);
+      Rn = harmonize_list(cur, oth, Rn, cap, p.harm_pre, &err);
+    }
+    pub[2] = Rn; pub[3] = (cur == listA) ? 0 : 1; pub[4] = err;
+  }
+  __syncthreads();
+  {
+    const int Rn = pub[2];
+    double2 *cur = pub[3] ? listB : listA, *oth = pub[3] ? listA : listB;
+    const bool shift_here = p.harm_pre == 0.f && p.shift_pre != 0.f; // shift_pitches, algo.cpp:307-316
+    for (int i = tid; i < Rn; i += T) { // autotune_pitches, algo.cpp:191-229: the per-item half
       double2 pv = cur[i];
+      if (shift_here) pv.x += p.shift_pre;
       double t;
       bool has;
       if (pv.x <= p.autotune_max_pitch) {
         has = autotune_fn(p, b.allowed, pv.x, t);
         if (has && t > p.autotune_max_pitch) t = pv.x;
       } else { t = pv.x; has = true; }
-      if (has) {
-        if (fabs(t - pv.x) <= (double)p.tolerance) {
-          if (A > 0 && fabs(oth[A - 1].x - t) < (double)0.0001f) oth[A - 1].y += pv.y;
-          else oth[A++] = make_double2(t, pv.y);
-        }
+      const bool keep = has && fabs(t - pv.x) <= (double)p.tolerance;
+      oth[i] = make_double2(t, keep ? pv.y : -1.0); // volumes are sums of positive magnitudes: -1 marks a dropped item
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int err = pub[4];
+    const int Rn = pub[2];
+    double2 *cur = pub[3] ? listB : listA, *oth = pub[3] ? listA : listB;
+    // the merge half: equal (within 1e-4) consecutive autotuned pitches pool their volumes.  Output overwrites cur (A <= i).
+    int A = 0;
+    double2 last = make_double2(0.0, 0.0);
+    bool have = false;
+    for (int i0 = 0; i0 < Rn; i0 += 4) {
+      double2 e[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) e[q] = (i0 + q < Rn) ? oth[i0 + q] : make_double2(0.0, -1.0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (!(e[q].y >= 0.0)) continue;
+        if (have && fabs(last.x - e[q].x) < (double)0.0001f) last.y += e[q].y;
+        else { if (have) cur[A++] = last; last = e[q]; have = true; }
       }
     }
-    { double2 *t = cur; cur = oth; oth = t; }
+    if (have) cur[A++] = last;
     shift_list(cur, A, p.shift_post);
     A = harmonize_list(cur, oth, A, cap, p.harm_post, &err);
     if (A > p.maxr) { err = 1; A = p.maxr; }
@@ -357,7 +389,7 @@ __global__ void ra_roll_history_kernel(RaParams p, RaBuffers b, const float *__r
 } // namespace
 
 size_t ra_analysis_lds_bytes(const RaParams &p) {
-  size_t m = p.M > 0 ? p.M : 1;
+  size_t m = (size_t)ra_zpad_size(p.M);
   size_t lists = 2 * (size_t)ra_list_capacity(p) * sizeof(double2);
   size_t scan = (RA_ANALYSIS_THREADS + 8) * sizeof(int);
   return m * sizeof(double2) + (lists > scan ? lists : scan);

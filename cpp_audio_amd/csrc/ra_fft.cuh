@@ -24,6 +24,76 @@ __device__ inline void ra_fft_dit(double2 *z, int M, const double2 *__restrict__
   }
 }
 
+// ---- the same butterfly network, three stages at a time in registers ------------------------------------------------------
+// Stages with half = h, 2h, 4h of the radix-2 DIT network close over groups of 8 points {base + k h}: a thread loads one group,
+// runs the 3 x 4 butterflies exactly as ra_fft_dit would (same operands, same twiddles, same operation order: results are
+// bit-identical) and stores it back, so an M-point transform takes ceil(log2 M / 3) LDS round trips and barriers instead of
+// log2 M.  z is indexed through ra_zpad (one spare slot per 16) so that the stride-8 and stride-8h accesses of every pass
+// spread over all LDS banks.
+__host__ __device__ inline int ra_zpad(int i) { return i + (i >> 4); }
+__host__ __device__ inline int ra_zpad_size(int M) { return M > 0 ? ra_zpad(M - 1) + 1 : 1; }
+
+// S fused stages starting at half = 1 << log2h.  FIRST: the group's inputs come from load(packed index) (bit-reversed order is
+// resolved here: slot i of the DIT input holds packed element bitrev(i)) instead of from z.
+template <int S, bool FIRST, typename LoadFn>
+__device__ inline void ra_fft_pass(double2 *z, int M, int log2M, int log2h, const double2 *__restrict__ tw_half, int tid, int T, LoadFn load) {
+  constexpr int R = 1 << S;
+  const int groups = M >> S, h = 1 << log2h;
+  for (int gi = tid; gi < groups; gi += T) {
+    // FIRST: slot 8 g + k of the DIT input holds packed element bitrev_m(8 g + k) = bitrev_S(k) << (m - S) | bitrev_{m-S}(g);
+    // thread gi takes group g = bitrev_{m-S}(gi), so that consecutive lanes load consecutive packed elements (coalesced)
+    const int g = (FIRST && log2M > S) ? (int)(__brev((unsigned)gi) >> (32 - (log2M - S))) : gi;
+    const int r = g & (h - 1), base = ((g - r) << S) + r;
+    double2 x[R], w[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      if (FIRST) {
+        const unsigned rk = __brev((unsigned)k) >> (32 - S);
+        x[k] = load((int)((rk << (log2M - S)) | (unsigned)gi));
+      } else x[k] = z[ra_zpad(base + k * h)];
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+#pragma unroll
+      for (int q = 0; q < (1 << s); ++q) w[(1 << s) - 1 + q] = tw_half[(r + q * h) << (log2M - 1 - s - log2h)]; // j * (M / len), len = 2 h 2^s
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        if (k & (1 << s)) continue;
+        const double2 ww = w[(1 << s) - 1 + (k & ((1 << s) - 1))];
+        const double2 u = x[k], y = x[k | (1 << s)];
+        const double vr = y.x * ww.x - y.y * ww.y;
+        const double vi = y.x * ww.y + y.y * ww.x;
+        x[k] = make_double2(u.x + vr, u.y + vi);
+        x[k | (1 << s)] = make_double2(u.x - vr, u.y - vi);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) z[ra_zpad(base + k * h)] = x[k];
+  }
+  __syncthreads();
+}
+
+// forward transform of the packed sequence load(0..M-1) into z (ra_zpad indexing), M = 1 << log2M
+template <typename LoadFn>
+__device__ inline void ra_fft_fused(double2 *z, int M, int log2M, const double2 *__restrict__ tw_half, int tid, int T, LoadFn load) {
+  auto none = [](int) { return make_double2(0.0, 0.0); };
+  int done;
+  if (log2M == 0) {
+    if (tid == 0) z[0] = load(0);
+    __syncthreads();
+    return;
+  }
+  if (log2M >= 3) { ra_fft_pass<3, true>(z, M, log2M, 0, tw_half, tid, T, load); done = 3; }
+  else if (log2M == 2) { ra_fft_pass<2, true>(z, M, log2M, 0, tw_half, tid, T, load); done = 2; }
+  else { ra_fft_pass<1, true>(z, M, log2M, 0, tw_half, tid, T, load); done = 1; }
+  while (log2M - done >= 3) { ra_fft_pass<3, false>(z, M, log2M, done, tw_half, tid, T, none); done += 3; }
+  if (log2M - done == 2) ra_fft_pass<2, false>(z, M, log2M, done, tw_half, tid, T, none);
+  else if (log2M - done == 1) ra_fft_pass<1, false>(z, M, log2M, done, tw_half, tid, T, none);
+}
+
 // One bin of the real spectrum from the packed transform: X[k] = E[k] + W^k O[k],
 // E = (Z[k] + conj Z[M-k]) / 2, O = -i/2 (Z[k] - conj Z[M-k]).  a = Z[k mod M], c = Z[(M-k) mod M].
 __device__ inline double2 ra_real_split_bin(double2 a, double2 c, double2 w) {

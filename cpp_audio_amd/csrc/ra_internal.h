@@ -128,15 +128,30 @@ struct RaBuffers {
   int64_t voc_mod_cap, voc_car_cap;
 };
 
-// in-kernel phase timing for tuning: lane 0 of the workgroup adds the s_memtime ticks since the previous mark to slot i
+// in-kernel phase timing for tuning: lane 0 of the workgroup adds the s_memtime ticks since the previous mark to slot i.
+// lap<I>() accumulates in registers instead (inner loops); flush() adds those totals and lap counts to slots base + I / base + 4 + I.
 struct RaPhaseClock {
-  unsigned long long *dst, t;
-  __device__ inline RaPhaseClock(unsigned long long *d, bool on) : dst(on ? d : nullptr), t(0) { if (dst) t = __builtin_readcyclecounter(); }
+  unsigned long long *dst, t, acc[4];
+  unsigned laps[4];
+  __device__ inline RaPhaseClock(unsigned long long *d, bool on) : dst(on ? d : nullptr), t(0) {
+    for (int i = 0; i < 4; ++i) { acc[i] = 0; laps[i] = 0; }
+    if (dst) t = __builtin_readcyclecounter();
+  }
   __device__ inline void mark(int i) {
     if (!dst) return;
     unsigned long long now = __builtin_readcyclecounter();
     atomicAdd(dst + i, now - t);
     t = now;
+  }
+  template <int I> __device__ inline void lap() {
+    if (!dst) return;
+    unsigned long long now = __builtin_readcyclecounter();
+    acc[I] += now - t; ++laps[I];
+    t = now;
+  }
+  __device__ inline void flush(int base) {
+    if (!dst) return;
+    for (int i = 0; i < 4; ++i) if (laps[i]) { atomicAdd(dst + base + i, acc[i]); atomicAdd(dst + base + 4 + i, (unsigned long long)laps[i]); }
   }
 };
 

@@ -20,6 +20,24 @@
 
 extern __shared__ __align__(16) unsigned char ra_smem_syn[];
 
+// register budgets (waves per SIMD the compiler must leave room for); overridable for tuning builds
+#ifndef RA_PROP_EU
+#define RA_PROP_EU 2
+#endif
+#ifndef RA_REND_EU
+#define RA_REND_EU 0
+#endif
+#if RA_PROP_EU > 0
+#define RA_PROP_OCC __attribute__((amdgpu_waves_per_eu(RA_PROP_EU)))
+#else
+#define RA_PROP_OCC
+#endif
+#if RA_REND_EU > 0
+#define RA_REND_OCC __attribute__((amdgpu_waves_per_eu(RA_REND_EU)))
+#else
+#define RA_REND_OCC
+#endif
+
 namespace {
 
 // LDS carve for a workgroup of Ppad lanes
@@ -186,12 +204,14 @@ __device__ inline void clean_tile(Chan &c, const Regime &r, double cd0, double s
 }
 
 __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &k, const RaParams &p, int s, int l, int64_t t, int64_t seg_end,
-                                         int64_t t0, int64_t n, const double *__restrict__ mix, float *__restrict__ out, double *__restrict__ out_d) {
+                                         int64_t t0, int64_t n, const double *__restrict__ mix, float *__restrict__ out, double *__restrict__ out_d,
+                                         RaPhaseClock &clk) {
   const int Ppad = p.Ppad;
   const double inv_dur = 1.0 / k.dur;
   const double lim = k.dur - 0.5; // a glide step that finds cur > lim clamps (InterpolatedFreq::step, audioelement.h:2768-2770)
   Regime r;
   regime_setup(c, k, inv_dur, r);
+  clk.mark(21);
   double *mine = tile + l * TROW;                                               // this lane's row
   const int fr = l & (TD - 1), ch = (l >> 3) & 1, quarter = (l >> 4) & 3;       // reduction role of lanes 0..63
   const double *col = tile + (quarter * (Ppad >> 2)) * TROW + ch * TD + fr;     // entry (ch, fr) of the quarter's first channel
@@ -258,6 +278,7 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
       }
 #pragma unroll
       for (int i = 0; i < TD; ++i) { mine[i] = c.gL * v[i]; mine[TD + i] = c.gR * v[i]; }
+      clk.lap<0>();
     } else {
       for (int i = 0; i < m; ++i) {
         double v = 0.0;
@@ -284,6 +305,7 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
         mine[i] = c.gL * v;
         mine[TD + i] = c.gR * v;
       }
+      clk.lap<1>();
     }
     __syncthreads();
     if (l < 64) { // 16 outputs (8 frames x 2) x 4 channel quarters
@@ -305,8 +327,10 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
       }
     }
     __syncthreads();
+    clk.lap<2>();
     t += m;
   }
+  clk.flush(24);
 }
 
 // the one-shots of one analysis frame, in the order the reference queued them.  Workgroup-uniform control flow.
@@ -410,7 +434,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_serial_kernel(RaPara
 }
 
 // ---- K3a: state at the start of every segment (segment i of a chunk = samples between its frames i-1 and i) -----------
-__global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_propagate_kernel(RaParams p, RaBuffers b, RaSpan sp) {
+__global__ void __launch_bounds__(RA_MAX_CHANNELS) RA_PROP_OCC ra_synth_propagate_kernel(RaParams p, RaBuffers b, RaSpan sp) {
   __builtin_amdgcn_s_setprio(3); // a dependency chain a few hundred waves wide: let it win issue arbitration against the throughput kernels it runs beside
   const int s = blockIdx.x, l = threadIdx.x, Ppad = p.Ppad;
   SynLds L = carve(ra_smem_syn, Ppad);
@@ -419,18 +443,26 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_propagate_kernel(RaP
   Chan c;
   load_chan(c, sd, si, Ppad, l);
   const SynConst k = syn_const(p, s);
+  RaPhaseClock clk(b.dbg_clk, l == 0);
   int64_t t = sp.ct0;
   for (int64_t i = 0; i <= sp.nfb; ++i) {
     const int64_t seg_end = (i < sp.nfb) ? ra_fire_sample(p.N, p.H, sp.f_lo + sp.fb0 + i) : sp.ct1;
     const size_t seg = (size_t)s * b.seg_cap + sp.seg0 + i;
     store_chan(c, b.seg_sd + seg * SD_COUNT * Ppad, b.seg_si + seg * SI_COUNT * Ppad, Ppad, l);
+    clk.lap<0>();
     chan_jump_phase(c, k.ep, k.dur, k.max_filter_inc, seg_end - t);
+    clk.lap<1>();
     t = seg_end;
     if (i == sp.nfb) break;
     const RaCmd cmd = b.cmd[((size_t)s * b.frames_cap + sp.fb0 + i) * Ppad + l];
-    apply_frame_events<true>(c, cmd, b.cmd_non[(size_t)s * b.frames_cap + sp.fb0 + i], L, k, p, b, l);
+    const int n_on = b.cmd_non[(size_t)s * b.frames_cap + sp.fb0 + i];
+    if (clk.dst && cmd.type + n_on == -12345) clk.acc[3] += 1; // tuning aid: makes the lap below wait for the loads
+    clk.lap<2>();
+    apply_frame_events<true>(c, cmd, n_on, L, k, p, b, l);
+    clk.lap<3>();
   }
   store_chan(c, sd, si, Ppad, l);
+  clk.flush(40);
 }
 
 // ---- K3b: render one segment ----------------------------------------------------------------------------------------
@@ -441,18 +473,20 @@ __device__ inline void render_segment(const RaParams &p, const RaBuffers &b, con
   const int64_t seg_end = (i < sp.nfb) ? ra_fire_sample(p.N, p.H, sp.f_lo + sp.fb0 + i) : sp.ct1;
   if (seg_end <= seg_begin) return;
   const size_t seg = (size_t)s * b.seg_cap + sp.seg0 + i;
+  RaPhaseClock clk(b.dbg_clk, l == 0);
   Chan c;
   load_chan(c, b.seg_sd + seg * SD_COUNT * Ppad, b.seg_si + seg * SI_COUNT * Ppad, Ppad, l);
   chan_from_phase(c);
+  clk.mark(20);
   const SynConst k = syn_const(p, s);
   const double *mix = (p.voc_enabled && b.voc_mix) ? b.voc_mix + (size_t)s * sp.n : nullptr;
   if (DIAG) {
     SynLds L = carve(ra_smem_syn, Ppad);
     if (p.render_mode == 2) render_range<false>(c, L, k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
     else render_range<true>(c, L, k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
-  } else render_range_fast(c, reinterpret_cast<double *>(ra_smem_syn), k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
+  } else render_range_fast(c, reinterpret_cast<double *>(ra_smem_syn), k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d, clk);
 }
-__global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_render_kernel(RaParams p, RaBuffers b, RaSpan sp, float *__restrict__ out, double *__restrict__ out_d) {
+__global__ void __launch_bounds__(RA_MAX_CHANNELS) RA_REND_OCC ra_synth_render_kernel(RaParams p, RaBuffers b, RaSpan sp, float *__restrict__ out, double *__restrict__ out_d) {
   render_segment<false>(p, b, sp, out, out_d);
 }
 // tuning aid (ra_config.reference_order 2 / 3): hop-parallel like the product kernel, but every sample takes the general step
