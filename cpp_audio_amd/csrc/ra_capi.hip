@@ -562,6 +562,8 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
     // ROCm multiplexes HIP streams onto 4 hardware queues by default: the analysis launches ride on the caller's stream so that
     // tracking, propagation and render each keep a queue of their own (on a shared queue propagate(i+1) would wait for render(i))
     hipStream_t sA = user, sT = c->pipe_stream[1], sP = c->pipe_stream[2], sR = c->pipe_stream[3];
+    static const bool one_queue = std::getenv("RA_PIPELINE_SERIAL") != nullptr; // tuning aid: same chunks, no overlap
+    if (one_queue) sT = sP = sR = user;
     HIP_TRY(hipEventRecord(c->ev_fork, user));
     for (int i = 1; i < 4; ++i) HIP_TRY(hipStreamWaitEvent(c->pipe_stream[i], c->ev_fork, 0));
     if (p.voc_enabled) { // independent of the analysis chain: runs beside it, only the render waits for the mix

@@ -482,11 +482,35 @@ __device__ inline void chan_jump_phase(Chan &c, const RaEnvParams &p, double dur
       double lo = gliding ? fmin(fabs(c.from + (c.to - c.from) * (c.cur * inv_dur)), fabs(new_fres)) : fabs(c.fres);
       double want = fmin(max_filter_inc, lo);
       bool ok = (c.finit == want) && (!gliding || lo >= max_filter_inc);
-      if (!ok) { chan_step_phase(c, p, dur, inv_dur, max_filter_inc); --n; continue; }
-      if (c.k != k_cached) { k_cached = c.k; lk = log1p_small(-c.k); }
-      double q = exp((double)j * lk);
-      c.y = c.target + (c.y - c.target) * q;
-      c.vol = c.y;
+      if (!ok && gliding && c.from > 0. && c.to > 0.) {
+        // a glide below the filter's maximum increment: the coefficient k = a / (1 + a), a = pi min(max_filter_inc, |inc|), follows the
+        // increment step by step (BaseVolumeAdjusted::step, audioelement.h:1195-1216).  Only the filter is stepped (a lean loop; the
+        // reciprocal tracks 1 + a by two Newton steps per sample, exact to rounding since a moves by ~1e-6 per step); glide, envelope
+        // and angle keep their closed forms.
+        const double slope = (c.to - c.from) * inv_dur, alpha = 1.0 + c.C * slope, beta = c.C * (c.from + 0.5 * slope), lim = dur - 0.5;
+        double cur = c.cur, y = c.y, fin = c.finit, kk = c.k, rr = 1.0 / (1.0 + M_PI * c.finit);
+        for (int i = 0; i < j; ++i) {
+          const bool ended = cur > lim;
+          const double f = ended ? f_end : fma(slope, cur, c.from);
+          cur = ended ? dur : fma(alpha, cur, beta);
+          if (y != c.target) {
+            const double w = fmin(max_filter_inc, fabs(f));
+            if (w != fin) {
+              const double a1 = 1.0 + M_PI * w;
+              rr = rr * (2.0 - a1 * rr); rr = rr * (2.0 - a1 * rr);
+              kk = (M_PI * w) * rr; fin = w;
+            }
+          }
+          y = y + kk * (c.target - y);
+        }
+        c.y = y; c.vol = y; c.finit = fin; c.k = kk;
+      } else {
+        if (!ok) { chan_step_phase(c, p, dur, inv_dur, max_filter_inc); --n; continue; }
+        if (c.k != k_cached) { k_cached = c.k; lk = log1p_small(-c.k); }
+        double q = exp((double)j * lk);
+        c.y = c.target + (c.y - c.target) * q;
+        c.vol = c.y;
+      }
     }
     env_jump(c, p, j);
     if (gliding) { c.cur = new_cur; c.fres = new_fres; c.inc = new_fres; }

@@ -127,12 +127,13 @@ struct Regime {
   int pending;                      // steps taken since the envelope counters were last brought up to date
   bool active, gliding, irregular;  // irregular: the next step must be the general one
   bool hi;                          // the glide passes above fs/8: the anti-aliasing gain follows the increment
+  bool kvar;                        // the glide passes below the volume filter's maximum increment: its coefficient follows the increment
 };
 
 __device__ inline void regime_setup(const Chan &c, const SynConst &k, double inv_dur, Regime &r) {
   r.pending = 0;
   r.active = rt_active(c);
-  r.dv = 0; r.base = c.inc; r.slope = 0; r.alpha = 1; r.beta = 0; r.steps_left = 0x7fffffff; r.gliding = false; r.irregular = false; r.hi = false;
+  r.dv = 0; r.base = c.inc; r.slope = 0; r.alpha = 1; r.beta = 0; r.steps_left = 0x7fffffff; r.gliding = false; r.irregular = false; r.hi = false; r.kvar = false;
   if (!r.active) return;
   r.steps_left = env_regular_steps(c, k.ep);
   switch (c.state) {
@@ -161,9 +162,10 @@ __device__ inline void regime_setup(const Chan &c, const SynConst &k, double inv
     lo = fmin(fabs(c.from + r.slope * c.cur), fabs(f_end));
     r.hi = fmax(fabs(c.from), fabs(c.to)) > 0.25 || c.from <= 0. || c.to <= 0.;
   }
-  if (c.vol != c.target) { // the volume filter's coefficient must stay constant over the stretch (cf. chan_jump)
+  if (c.vol != c.target) { // the volume filter's coefficient is constant over the stretch, or follows a (positive) glide step by step
     double want = fmin(k.max_filter_inc, lo);
-    if (!(c.finit == want && (!r.gliding || lo >= k.max_filter_inc))) r.irregular = true;
+    if (r.gliding && lo < k.max_filter_inc) { if (c.from > 0. && c.to > 0.) r.kvar = true; else r.irregular = true; }
+    else if (!(c.finit == want)) r.irregular = true;
   }
 }
 
@@ -174,10 +176,12 @@ constexpr int TROW = 2 * TD + 1; // its LDS tile is lane-major: [Ppad][TROW] dou
 // GLIDE: some lane of the wave glides (the others run the same code with the identity rotation, alpha = 1, beta = 0);
 // HI: some gliding lane passes above fs/8, where the anti-aliasing gain follows the increment.
 // The phasor is renormalised once per tile instead of once per step (drift < 1e-15 per tile; every hop restarts from the angle).
-template <bool GLIDE, bool HI>
-__device__ inline void clean_tile(Chan &c, const Regime &r, double cd0, double sd0, double cd, double sd, double (&v)[TD]) {
+template <bool GLIDE, bool HI, bool KVAR>
+__device__ inline void clean_tile(Chan &c, const Regime &r, double max_filter_inc, double cd0, double sd0, double cd, double sd, double (&v)[TD]) {
   double cur = c.cur, mre = c.mre, mim = c.mim, cre = c.cre, cim = c.cim, y = c.y, value = c.value, alias = c.alias, f = c.inc;
-  const double kk = c.k, target = c.target;
+  double kk = c.k, fin = c.finit, rr = 0.0;
+  const double target = c.target;
+  if (KVAR) rr = 1.0 / (1.0 + M_PI * c.finit);
 #pragma unroll
   for (int i = 0; i < TD; ++i) {
     if (GLIDE) {
@@ -187,6 +191,16 @@ __device__ inline void clean_tile(Chan &c, const Regime &r, double cd0, double s
       const double mr = fma(mre, rc, -(mim * rs)), mi = fma(mre, rs, mim * rc);
       mre = mr; mim = mi;
       if (HI) { if (r.hi) alias = alias_mult(f); }
+      if (KVAR) { // BaseVolumeAdjusted::step, audioelement.h:1195-1216: k = a / (1 + a), a = pi min(max increment, |inc|); 1 / (1 + a) by Newton
+        if (r.kvar && y != target) {
+          const double w = fmin(max_filter_inc, fabs(f));
+          if (w != fin) {
+            const double a1 = 1.0 + M_PI * w;
+            rr = rr * (2.0 - a1 * rr); rr = rr * (2.0 - a1 * rr);
+            kk = (M_PI * w) * rr; fin = w;
+          }
+        }
+      }
     }
     const double re = fma(cre, mre, -(cim * mim)), im = fma(cre, mim, cim * mre);
     cre = re; cim = im;
@@ -200,6 +214,7 @@ __device__ inline void clean_tile(Chan &c, const Regime &r, double cd0, double s
   if (GLIDE) {
     c.mre = mre; c.mim = mim; c.cur = cur; c.alias = alias;
     if (r.gliding) { c.fres = f; c.inc = f; }
+    if (KVAR) { c.k = kk; c.finit = fin; }
   }
 }
 
@@ -225,6 +240,10 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
       const double mr = fma(c.mre, cd, -(c.mim * sd)), mi = fma(c.mre, sd, c.mim * cd);
       c.mre = mr; c.mim = mi; c.inc = f;
       if (r.hi) c.alias = alias_mult(f);
+      if (r.kvar && c.y != c.target) {
+        const double w = fmin(k.max_filter_inc, fabs(f));
+        if (w != c.finit) { c.finit = w; const double a = M_PI * w; c.k = a / (1.0 + a); }
+      }
     }
     const double re = fma(c.cre, c.mre, -(c.cim * c.mim));
     const double im = fma(c.cre, c.mim, c.cim * c.mre);
@@ -250,7 +269,7 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
       for (int i = 0; i < TD; ++i) v[i] = 0.0;
       const bool any_glide = __any(r.active && r.gliding);
       if (r.active) {
-        if (!any_glide) clean_tile<false, false>(c, r, 1.0, 0.0, 1.0, 0.0, v);
+        if (!any_glide) clean_tile<false, false, false>(c, r, k.max_filter_inc, 1.0, 0.0, 1.0, 0.0, v);
         else {
           // Rotation of `mult` per step while gliding: pi (inc_i - inc_{i-1}).  The tile's first step turns by d0 = pi (inc_0 - inc),
           // whatever the oscillator's increment currently is (0 right after a note change); the later steps turn by
@@ -266,8 +285,9 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
             sd = dA * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
             cd = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
           }
-          if (__any(r.active && r.gliding && r.hi)) clean_tile<true, true>(c, r, cd0, sd0, cd, sd, v);
-          else clean_tile<true, false>(c, r, cd0, sd0, cd, sd, v);
+          if (__any(r.active && r.kvar)) clean_tile<true, true, true>(c, r, k.max_filter_inc, cd0, sd0, cd, sd, v);
+          else if (__any(r.active && r.gliding && r.hi)) clean_tile<true, true, false>(c, r, k.max_filter_inc, cd0, sd0, cd, sd, v);
+          else clean_tile<true, false, false>(c, r, k.max_filter_inc, cd0, sd0, cd, sd, v);
           // over the m' = TD - 1 later steps the even spread runs ahead of the exact (linearly growing) rotation by b (j+1)(m'-1-j)/2
           // at step j, b = pi slope step0 (alpha - 1); the oscillator has integrated that: take the sum b (m'-1) m' (m'+1) / 12 back out
           const double dl = (M_PI * r.slope) * step0 * (r.alpha - 1.0) * ((TD - 2) * (TD - 1) * TD * (1.0 / 12.0));
@@ -474,6 +494,7 @@ __device__ inline void render_segment(const RaParams &p, const RaBuffers &b, con
   if (seg_end <= seg_begin) return;
   const size_t seg = (size_t)s * b.seg_cap + sp.seg0 + i;
   RaPhaseClock clk(b.dbg_clk, l == 0);
+  const unsigned long long wg_t0 = clk.t;
   Chan c;
   load_chan(c, b.seg_sd + seg * SD_COUNT * Ppad, b.seg_si + seg * SI_COUNT * Ppad, Ppad, l);
   chan_from_phase(c);
@@ -485,6 +506,11 @@ __device__ inline void render_segment(const RaParams &p, const RaBuffers &b, con
     if (p.render_mode == 2) render_range<false>(c, L, k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
     else render_range<true>(c, L, k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
   } else render_range_fast(c, reinterpret_cast<double *>(ra_smem_syn), k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d, clk);
+  if (clk.dst) { // workgroup lifetime: maximum and a histogram in steps of 200 k ticks
+    const unsigned long long d = __builtin_readcyclecounter() - wg_t0;
+    atomicMax(clk.dst + 39, d);
+    atomicAdd(clk.dst + 32 + (int)min(d / 200000ull, 6ull), 1ull);
+  }
 }
 __global__ void __launch_bounds__(RA_MAX_CHANNELS) RA_REND_OCC ra_synth_render_kernel(RaParams p, RaBuffers b, RaSpan sp, float *__restrict__ out, double *__restrict__ out_d) {
   render_segment<false>(p, b, sp, out, out_d);

@@ -80,6 +80,8 @@ __global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, i
   __syncthreads();
 
   const int R_env = p.envR;
+  RaPhaseClock clk(b.dbg_clk, lane == 0);
+  unsigned long long sumA = 0, sumPlayed = 0;
 
   for (int64_t fb = fb0; fb < fb0 + n_frames_blk; ++fb) { // frames fb0 .. of the block; scratch is indexed by fb
     const int64_t k_f = ra_fire_sample(p.N, p.H, f_lo + fb);
@@ -99,6 +101,7 @@ __global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, i
     for (int i = lane; i < P; i += 64) { ctype[i] = RA_CMD_NONE; if (i < n_played) cont[i] = 0; }
     __syncthreads();
 
+    clk.lap<0>(); sumA += A; sumPlayed += n_played;
     // ---- phase 1: track_pitches, algo.cpp:256-305 (sequential two-pointer scan) ----
     if (lane == 0) {
       int it = 0;
@@ -111,6 +114,7 @@ __global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, i
         }
       }
     }
+    clk.lap<1>();
     // ---- phase 2: loudness order = stable rank sort by key, descending ----
     for (int i = lane; i < A; i += 64) {
       float k = key[i];
@@ -120,6 +124,7 @@ __global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, i
     }
     __syncthreads();
 
+    clk.lap<2>();
     // ---- phase 3: note-offs for played notes that were not continued, lib.cpp:296-313 ----
     int n_off = 0;
     for (int j0 = 0; j0 < n_played; j0 += 64) {
@@ -211,7 +216,10 @@ __global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, i
       out[i] = c;
     }
     __syncthreads();
+    clk.lap<3>();
   }
+  clk.flush(48);
+  if (clk.dst) { atomicAdd(clk.dst + 56, sumA); atomicAdd(clk.dst + 57, sumPlayed); }
 
   for (int i = lane; i < P; i += 64) {
     b.chan_free_at[(size_t)s * P + i] = free_at[i];
