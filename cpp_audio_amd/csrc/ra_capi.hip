@@ -551,7 +551,15 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
     }
   } else {
     if (!c->pipe_ready) {
-      for (int i = 1; i < 4; ++i) HIP_TRY(hipStreamCreateWithFlags(&c->pipe_stream[i], hipStreamNonBlocking));
+      // The dependency chain (analysis -> tracking -> propagation) must stay ahead of the renderer, which is the long pole and
+      // fills whatever the chain leaves free: the chain's queues get dispatch priority over the render queue.
+      int prio_least = 0, prio_greatest = 0;
+      HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+      static const int prio_mode = std::getenv("RA_PIPELINE_PRIO") ? std::atoi(std::getenv("RA_PIPELINE_PRIO")) : 1; // tuning aid: 0 = flat
+      for (int i = 0; i < 4; ++i) {
+        const int prio = !prio_mode ? 0 : (i == 3 ? prio_least : prio_greatest);
+        HIP_TRY(hipStreamCreateWithPriority(&c->pipe_stream[i], hipStreamNonBlocking, prio));
+      }
       HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&c->ev_voc, hipEventDisableTiming));
       for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
@@ -559,26 +567,41 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
         for (int k = 0; k < 3; ++k) HIP_TRY(hipEventCreateWithFlags(&c->ev_chunk[k][i], hipEventDisableTiming));
       c->pipe_ready = true;
     }
-    // ROCm multiplexes HIP streams onto 4 hardware queues by default: the analysis launches ride on the caller's stream so that
-    // tracking, propagation and render each keep a queue of their own (on a shared queue propagate(i+1) would wait for render(i))
-    hipStream_t sA = user, sT = c->pipe_stream[1], sP = c->pipe_stream[2], sR = c->pipe_stream[3];
+    // every stage has a queue of its own (on a shared queue propagate(i+1) would wait for render(i)); the caller's stream only
+    // forks into them and joins them at the end of the block
+    hipStream_t sA = c->pipe_stream[0], sT = c->pipe_stream[1], sP = c->pipe_stream[2], sR = c->pipe_stream[3];
     static const bool one_queue = std::getenv("RA_PIPELINE_SERIAL") != nullptr; // tuning aid: same chunks, no overlap
-    if (one_queue) sT = sP = sR = user;
+    if (one_queue) sA = sT = sP = sR = user;
     HIP_TRY(hipEventRecord(c->ev_fork, user));
-    for (int i = 1; i < 4; ++i) HIP_TRY(hipStreamWaitEvent(c->pipe_stream[i], c->ev_fork, 0));
+    for (int i = 0; i < 4; ++i) HIP_TRY(hipStreamWaitEvent(c->pipe_stream[i], c->ev_fork, 0));
     if (p.voc_enabled) { // independent of the analysis chain: runs beside it, only the render waits for the mix
       timed_launch(c, ST_VOCODER, sR, [&] { ra_launch_vocoder(p, b, d_voice, d_carrier, t0, n, sR); });
     }
-    for (int i = 0; i < n_chunks; ++i) {
-      const int64_t fb0 = nfb * i / n_chunks, fb1 = nfb * (i + 1) / n_chunks;
+    // chunk 0 is short: nothing overlaps its analysis -> tracking -> propagation, so the render stream starts that much sooner
+    const int64_t head = n_chunks > 2 ? std::min<int64_t>(16, nfb / (2 * n_chunks)) : nfb / n_chunks;
+    auto cut = [&](int i) -> int64_t { return i == 0 ? 0 : (n_chunks > 2 ? head + (nfb - head) * (i - 1) / (n_chunks - 1) : nfb * i / n_chunks); };
+    auto span_of = [&](int i) {
+      const int64_t fb0 = cut(i), fb1 = (i == n_chunks - 1) ? nfb : cut(i + 1);
       RaSpan sp;
       sp.t0 = t0; sp.n = n; sp.f_lo = f_lo; sp.fb0 = fb0; sp.nfb = fb1 - fb0; sp.seg0 = fb0 + i;
       sp.ct0 = (i == 0) ? t0 : ra_fire_sample(p.N, p.H, f_lo + fb0);
       sp.ct1 = (i == n_chunks - 1) ? t0 + n : ra_fire_sample(p.N, p.H, f_lo + fb1);
-      timed_launch(c, ST_ANALYSIS, sA, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, fb0, sp.nfb, nfb, sA); });
+      return sp;
+    };
+    // An analysis workgroup needs four wave slots and a third of a CU's LDS at once: beside a chip full of single-wave render
+    // workgroups it gets few slots.  Measured on configs[1], letting the renderer start early still wins by ~3 % over holding it
+    // back until the block's analysis is done (RA_RENDER_AFTER_ANALYSIS=1, kept as a tuning aid): both orders are work-bound.
+    static const bool render_after_analysis = std::getenv("RA_RENDER_AFTER_ANALYSIS") != nullptr;
+    for (int i = 0; i < n_chunks; ++i) {
+      const RaSpan sp = span_of(i);
+      timed_launch(c, ST_ANALYSIS, sA, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, sp.fb0, sp.nfb, nfb, sA); });
       HIP_TRY(hipEventRecord(c->ev_chunk[0][i], sA));
+    }
+    if (render_after_analysis && !one_queue) HIP_TRY(hipStreamWaitEvent(sR, c->ev_chunk[0][n_chunks - 1], 0));
+    for (int i = 0; i < n_chunks; ++i) {
+      const RaSpan sp = span_of(i);
       HIP_TRY(hipStreamWaitEvent(sT, c->ev_chunk[0][i], 0));
-      timed_launch(c, ST_TRACK, sT, [&] { ra_launch_track(p, b, f_lo, fb0, sp.nfb, sT); });
+      timed_launch(c, ST_TRACK, sT, [&] { ra_launch_track(p, b, f_lo, sp.fb0, sp.nfb, sT); });
       HIP_TRY(hipEventRecord(c->ev_chunk[1][i], sT));
       HIP_TRY(hipStreamWaitEvent(sP, c->ev_chunk[1][i], 0));
       timed_launch(c, ST_PROPAGATE, sP, [&] { ra_launch_synth_propagate(p, b, sp, sP); });
@@ -586,7 +609,7 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
       HIP_TRY(hipStreamWaitEvent(sR, c->ev_chunk[2][i], 0));
       timed_launch(c, ST_RENDER, sR, [&] { ra_launch_synth_render(p, b, sp, d_out, d_out_d, sR); });
     }
-    for (int i = 1; i < 4; ++i) {
+    for (int i = 0; i < 4; ++i) {
       HIP_TRY(hipEventRecord(c->ev_join[i], c->pipe_stream[i]));
       HIP_TRY(hipStreamWaitEvent(user, c->ev_join[i], 0));
     }
@@ -708,7 +731,7 @@ void ra_destroy(ra_context *c) {
   for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->pipe_ready) {
-    for (int i = 1; i < 4; ++i) { (void)hipStreamSynchronize(c->pipe_stream[i]); (void)hipStreamDestroy(c->pipe_stream[i]); }
+    for (int i = 0; i < 4; ++i) { (void)hipStreamSynchronize(c->pipe_stream[i]); (void)hipStreamDestroy(c->pipe_stream[i]); }
     (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_voc);
     for (auto e : c->ev_join) (void)hipEventDestroy(e);
     for (auto &row : c->ev_chunk) for (auto e : row) if (e) (void)hipEventDestroy(e);

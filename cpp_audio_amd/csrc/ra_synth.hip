@@ -25,7 +25,7 @@ extern __shared__ __align__(16) unsigned char ra_smem_syn[];
 #define RA_PROP_EU 2
 #endif
 #ifndef RA_REND_EU
-#define RA_REND_EU 0
+#define RA_REND_EU 3
 #endif
 #if RA_PROP_EU > 0
 #define RA_PROP_OCC __attribute__((amdgpu_waves_per_eu(RA_PROP_EU)))
@@ -171,6 +171,7 @@ __device__ inline void regime_setup(const Chan &c, const SynConst &k, double inv
 
 constexpr int TD = 8;            // tile depth of the regime renderer
 constexpr int TROW = 2 * TD + 1; // its LDS tile is lane-major: [Ppad][TROW] doubles, entry out * TD + frame (odd row length: conflict-free both ways)
+constexpr int TROW_MONO = TD + 1; // stereo_spread 0: every channel has the same two gains, applied after the channel sum
 
 // TD steps of a lane whose wave has no transition inside the tile: straight-line code, no state machine.
 // GLIDE: some lane of the wave glides (the others run the same code with the identity rotation, alpha = 1, beta = 0);
@@ -182,6 +183,8 @@ __device__ inline void clean_tile(Chan &c, const Regime &r, double max_filter_in
   double kk = c.k, fin = c.finit, rr = 0.0;
   const double target = c.target;
   if (KVAR) rr = 1.0 / (1.0 + M_PI * c.finit);
+  double va = alias * value;
+  const double dva = alias * r.dv;
 #pragma unroll
   for (int i = 0; i < TD; ++i) {
     if (GLIDE) {
@@ -205,12 +208,12 @@ __device__ inline void clean_tile(Chan &c, const Regime &r, double max_filter_in
     const double re = fma(cre, mre, -(cim * mim)), im = fma(cre, mim, cim * mre);
     cre = re; cim = im;
     y = fma(kk, target - y, y);
-    value += r.dv;
-    v[i] = y * ((alias * cim) * value);
+    if (HI) { value += r.dv; v[i] = y * ((alias * cim) * value); }
+    else { va += dva; v[i] = y * (cim * va); } // the anti-aliasing gain is constant here: folded into the envelope ramp
   }
   const double g = 0.5 * (3.0 - fma(cre, cre, cim * cim));
   c.cre = cre * g; c.cim = cim * g;
-  c.y = y; c.vol = y; c.value = value;
+  c.y = y; c.vol = y; c.value = HI ? value : fma((double)TD, r.dv, value);
   if (GLIDE) {
     c.mre = mre; c.mim = mim; c.cur = cur; c.alias = alias;
     if (r.gliding) { c.fres = f; c.inc = f; }
@@ -218,6 +221,7 @@ __device__ inline void clean_tile(Chan &c, const Regime &r, double max_filter_in
   }
 }
 
+template <bool MONO>
 __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &k, const RaParams &p, int s, int l, int64_t t, int64_t seg_end,
                                          int64_t t0, int64_t n, const double *__restrict__ mix, float *__restrict__ out, double *__restrict__ out_d,
                                          RaPhaseClock &clk) {
@@ -227,9 +231,13 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
   Regime r;
   regime_setup(c, k, inv_dur, r);
   clk.mark(21);
-  double *mine = tile + l * TROW;                                               // this lane's row
-  const int fr = l & (TD - 1), ch = (l >> 3) & 1, quarter = (l >> 4) & 3;       // reduction role of lanes 0..63
-  const double *col = tile + (quarter * (Ppad >> 2)) * TROW + ch * TD + fr;     // entry (ch, fr) of the quarter's first channel
+  constexpr int ROW = MONO ? TROW_MONO : TROW;
+  double *mine = tile + l * ROW;                                                // this lane's row
+  // reduction role of lanes 0..63: frame fr of output ch over a quarter of the channels (MONO: frame fr over an eighth)
+  const int fr = l & (TD - 1), ch = (l >> 3) & 1, part = MONO ? (l >> 3) & 7 : (l >> 4) & 3;
+  const double *col = MONO ? tile + (part * (Ppad >> 3)) * ROW + fr : tile + (part * (Ppad >> 2)) * ROW + ch * TD + fr;
+  double gLm = 0.0, gRm = 0.0;
+  if (MONO) { const double ang = (0.25 * M_PI) * (0.0 + 1.); gLm = cos(ang); gRm = sin(ang); } // stereo(0), stereo.h:18-27, as at note-on
 
   // the common step of a lane inside a regular stretch; (cd, sd) = per-step rotation of the oscillator's rotation (glides only)
   auto fast_step = [&](double cd, double sd) -> double {
@@ -297,7 +305,7 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
         r.pending += TD; r.steps_left -= TD;
       }
 #pragma unroll
-      for (int i = 0; i < TD; ++i) { mine[i] = c.gL * v[i]; mine[TD + i] = c.gR * v[i]; }
+      for (int i = 0; i < TD; ++i) { if (MONO) mine[i] = v[i]; else { mine[i] = c.gL * v[i]; mine[TD + i] = c.gR * v[i]; } }
       clk.lap<0>();
     } else {
       for (int i = 0; i < m; ++i) {
@@ -322,24 +330,33 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
           }
           v = fast_step(cdi, sdi);
         }
-        mine[i] = c.gL * v;
-        mine[TD + i] = c.gR * v;
+        if (MONO) mine[i] = v; else { mine[i] = c.gL * v; mine[TD + i] = c.gR * v; }
       }
       clk.lap<1>();
     }
     __syncthreads();
-    if (l < 64) { // 16 outputs (8 frames x 2) x 4 channel quarters
+    if (l < 64) { // 16 outputs (8 frames x 2) x 4 channel quarters; MONO: 8 sums x 8 channel eighths
       double acc = 0.0;
       if (fr < m) {
         const double *q = col;
-        for (int blk = 0; blk < (Ppad >> 6); ++blk, q += 16 * TROW) {
+        constexpr int NJ = MONO ? 8 : 16;
+        for (int blk = 0; blk < (Ppad >> 6); ++blk, q += NJ * ROW) {
 #pragma unroll
-          for (int j = 0; j < 16; ++j) acc += q[j * TROW];
+          for (int j = 0; j < NJ; ++j) acc += q[j * ROW];
         }
       }
       acc += __shfl_down(acc, 32);
       acc += __shfl_down(acc, 16);
-      if (l < 16 && fr < m) {
+      if (MONO) {
+        acc += __shfl_down(acc, 8);
+        if (l < 8 && fr < m) {
+          const int64_t rel = (t - t0) + fr;
+          double oL = gLm * acc, oR = gRm * acc;
+          if (mix) { oL += mix[rel]; oR += mix[rel]; }
+          if (out) { out[((size_t)s * n + rel) * 2] = (float)oL; out[((size_t)s * n + rel) * 2 + 1] = (float)oR; }
+          if (out_d) { out_d[((size_t)s * n + rel) * 2] = oL; out_d[((size_t)s * n + rel) * 2 + 1] = oR; }
+        }
+      } else if (l < 16 && fr < m) {
         const int64_t rel = (t - t0) + fr;
         if (mix) acc += mix[rel];
         if (out) out[((size_t)s * n + rel) * 2 + ch] = (float)acc;
@@ -486,7 +503,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) RA_PROP_OCC ra_synth_propagat
 }
 
 // ---- K3b: render one segment ----------------------------------------------------------------------------------------
-template <bool DIAG>
+template <bool DIAG, bool MONO>
 __device__ inline void render_segment(const RaParams &p, const RaBuffers &b, const RaSpan &sp, float *__restrict__ out, double *__restrict__ out_d) {
   const int i = blockIdx.x, s = blockIdx.y, l = threadIdx.x, Ppad = p.Ppad;
   const int64_t seg_begin = (i == 0) ? sp.ct0 : ra_fire_sample(p.N, p.H, sp.f_lo + sp.fb0 + i - 1);
@@ -505,7 +522,7 @@ __device__ inline void render_segment(const RaParams &p, const RaBuffers &b, con
     SynLds L = carve(ra_smem_syn, Ppad);
     if (p.render_mode == 2) render_range<false>(c, L, k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
     else render_range<true>(c, L, k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
-  } else render_range_fast(c, reinterpret_cast<double *>(ra_smem_syn), k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d, clk);
+  } else render_range_fast<MONO>(c, reinterpret_cast<double *>(ra_smem_syn), k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d, clk);
   if (clk.dst) { // workgroup lifetime: maximum and a histogram in steps of 200 k ticks
     const unsigned long long d = __builtin_readcyclecounter() - wg_t0;
     atomicMax(clk.dst + 39, d);
@@ -513,11 +530,15 @@ __device__ inline void render_segment(const RaParams &p, const RaBuffers &b, con
   }
 }
 __global__ void __launch_bounds__(RA_MAX_CHANNELS) RA_REND_OCC ra_synth_render_kernel(RaParams p, RaBuffers b, RaSpan sp, float *__restrict__ out, double *__restrict__ out_d) {
-  render_segment<false>(p, b, sp, out, out_d);
+  render_segment<false, false>(p, b, sp, out, out_d);
+}
+// stereo_spread 0 (every channel panned to the centre): the two equal-for-all gains are applied after the channel sum
+__global__ void __launch_bounds__(RA_MAX_CHANNELS) RA_REND_OCC ra_synth_render_mono_kernel(RaParams p, RaBuffers b, RaSpan sp, float *__restrict__ out, double *__restrict__ out_d) {
+  render_segment<false, true>(p, b, sp, out, out_d);
 }
 // tuning aid (ra_config.reference_order 2 / 3): hop-parallel like the product kernel, but every sample takes the general step
 __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_render_diag_kernel(RaParams p, RaBuffers b, RaSpan sp, float *__restrict__ out, double *__restrict__ out_d) {
-  render_segment<true>(p, b, sp, out, out_d);
+  render_segment<true, false>(p, b, sp, out, out_d);
 }
 
 } // namespace
@@ -534,5 +555,6 @@ void ra_launch_synth_render(const RaParams &p, const RaBuffers &b, const RaSpan 
   if (sp.ct1 <= sp.ct0) return;
   const dim3 grid((unsigned)(sp.nfb + 1), (unsigned)p.n_streams), block((unsigned)p.Ppad);
   if (p.render_mode) hipLaunchKernelGGL(ra_synth_render_diag_kernel, grid, block, syn_lds_bytes(p.Ppad), st, p, b, sp, d_out, d_out_d);
+  else if (p.stereo_spread == 0.f) hipLaunchKernelGGL(ra_synth_render_mono_kernel, grid, block, (size_t)p.Ppad * TROW_MONO * sizeof(double), st, p, b, sp, d_out, d_out_d);
   else hipLaunchKernelGGL(ra_synth_render_kernel, grid, block, (size_t)p.Ppad * TROW * sizeof(double), st, p, b, sp, d_out, d_out_d); // the 8-frame tile only
 }
