@@ -23,6 +23,10 @@ sys.path.insert(0, ROOT)
 ALGO_BYTES_PER_FRAME = 12.0
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # nominal vector fp64
+# One fp64 VALU instruction of a wave64 occupies its SIMD for 4 cycles (16 lanes / clk: the 78.6 TFLOP/s above); at 2.4 GHz
+# the 1024 SIMDs issue at most 614 G wave-instructions / s.  scripts/ubench/fp64_rate.hip measures 2.3 - 2.4 ns per instruction
+# and SIMD with >= 2 waves resident (~70 % of nominal) and 4.4 ns with one wave.
+VALU_PEAK_GINST = 1024 * 2.4 / 4.0
 
 
 def algo_flops_per_frame(N, H, P):
@@ -51,10 +55,10 @@ def host_cores():
     return int(env) if env else cores
 
 
-def measured_traffic(kernel, S, n, N, H, P):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r*/traffic.json, separate --pmc runs of
-    FETCH_SIZE and WRITE_SIZE, gfx950 x2 read correction) — PMC counters cannot be read from inside this process.  None unless a
-    profile of exactly this workload shape exists."""
+def measured_counters(kernel, S, n, N, H, P):
+    """Per-step PMC sums of `kernel` from the committed rocprofv3 passes (profiles/r*/traffic.json: separate --pmc runs of FETCH_SIZE,
+    WRITE_SIZE and SQ_INSTS_VALU) — PMC counters cannot be read from inside this process.  None unless a profile of exactly
+    this workload shape exists."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
         try:
@@ -62,11 +66,10 @@ def measured_traffic(kernel, S, n, N, H, P):
             w = doc["workload"]
             if (w["streams"], w["frames_per_stream"], w["window"], w["stride"], w["partials"]) != (S, n, N, H, P):
                 continue
-            k = doc["kernels"][kernel]
-            return (2.0 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0
+            return doc["kernels"][kernel], os.path.relpath(path, ROOT)
         except Exception:
             continue
-    return None
+    return None, None
 
 
 def synth_inputs_torch(n_streams, n_frames, sr, seed, device):
@@ -167,6 +170,7 @@ def main():
     dt = time.perf_counter() - t0
     ctx.synchronize()         # raises on device-side error flags
     kms, calls = ctx.kernel_ms()
+    ctx_launches = ctx.kernel_launches()
     ctx.set_profiling(False)
     st = ctx.stats()
     if world > 1:
@@ -181,15 +185,29 @@ def main():
 
     result = None
     if rank == 0:
+        launches = ctx_launches
         synth_ms = (kms["propagate"] + kms["render"]) / max(calls, 1)
-        dom = max(kms, key=kms.get)
-        dom_ms = kms[dom] / max(calls, 1)
-        algo_bytes = ALGO_BYTES_PER_FRAME * frames_per_step_gpu
+        # the sine-bank renderer carries ~75 % of the path's VALU work; the analysis launches overlap it and their
+        # event-to-event time is mostly waiting for CU slots, so "largest summed duration" would not name the kernel that bounds the step
+        dom = "render" if kms["render"] > 0 else max(kms, key=kms.get)
+        dom_launches = max(launches[dom], 1)
+        dom_ms = kms[dom] / dom_launches                       # average duration of ONE launch (HIP events on its stream)
+        launches_per_step = dom_launches / max(calls, 1)
+        algo_bytes = ALGO_BYTES_PER_FRAME * frames_per_step_gpu / launches_per_step   # a launch covers 1 / launches_per_step of the block
         achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         flops = algo_flops_per_frame(N, H, P)
         KNAME = {"analysis": "ra_analysis_kernel", "track": "ra_track_kernel", "vocoder": "ra_voc_*_kernel",
-                 "propagate": "ra_synth_propagate_kernel", "render": "ra_synth_render_kernel", "history": "ra_roll_history_kernel"}
-        traffic = measured_traffic(KNAME[dom], S, n, N, H, P)
+                 "propagate": "ra_synth_propagate_kernel", "render": "ra_synth_render_mono_kernel", "history": "ra_roll_history_kernel"}
+        pmc, pmc_src = measured_counters(KNAME[dom], S, n, N, H, P)
+        traffic = (2.0 * pmc["FETCH_SIZE_KB"] + pmc["WRITE_SIZE_KB"]) * 1024.0 / pmc.get("launches", 1) if pmc else None
+        valu = {"algorithmic_flop_per_frame": flops,
+                "achieved_tflops_fp64": flops * frames_per_step_gpu / (synth_ms * 1e-3 + 1e-30) / 1e12 if synth_ms > 0 else None,
+                "peak_tflops_fp64_vector": FP64_VALU_PEAK_TFLOPS}
+        if pmc and "SQ_INSTS_VALU" in pmc:  # issue-slot view of the same kernel: wave-instructions / s against 1 per 4 cycles per SIMD
+            ginst = pmc["SQ_INSTS_VALU"] / (kms[dom] / max(calls, 1) * 1e-3) / 1e9
+            valu.update({"kernel": KNAME[dom], "valu_insts_per_step": pmc["SQ_INSTS_VALU"], "valu_insts_per_frame_channel":
+                         pmc["SQ_INSTS_VALU"] * 64.0 / (frames_per_step_gpu * P), "issue_rate_ginst_s": ginst,
+                         "peak_issue_rate_ginst_s": VALU_PEAK_GINST, "issue_frac": ginst / VALU_PEAK_GINST, "counters_from": pmc_src})
         result = {
             "metric": "audio frames/sec (48 kHz, 4096-pt FFT, 64 partials) per GPU; CPU ref x",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -201,11 +219,11 @@ def main():
             "x_realtime_per_stream": value / (sr * S * world),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": KNAME[dom],
-                         "kernel_ms_per_launch": dom_ms, "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "path is fp64-VALU / serial-latency bound (SURVEY.md §8d): see valu"},
-            "valu": {"algorithmic_flop_per_frame": flops, "achieved_tflops_fp64": flops * frames_per_step_gpu / (synth_ms * 1e-3 + 1e-30) / 1e12
-                     if synth_ms > 0 else None, "peak_tflops_fp64_vector": FP64_VALU_PEAK_TFLOPS},
+                         "kernel_ms_per_launch": dom_ms, "launches_per_step": launches_per_step, "algorithmic_bytes_per_launch": algo_bytes,
+                         "note": "the path is fp64-VALU issue bound, not HBM bound (SURVEY.md §8d): see valu.issue_frac"},
+            "valu": valu,
             "kernel_ms_per_step": {k: v / max(calls, 1) for k, v in kms.items()},
+            "kernel_launches_per_step": {k: v / max(calls, 1) for k, v in launches.items()},
             "checks": {"out_rms": out_rms, "dropped_note_on": int(st.dropped_note_on), "error_flags": int(st.error_flags)},
         }
 

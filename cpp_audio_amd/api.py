@@ -63,7 +63,7 @@ EXPORTED_SYMBOLS = [
     "ra_last_error", "ra_device_count", "ra_default_config", "ra_even_window_size_frames", "ra_window_center_stride_frames",
     "ra_create", "ra_destroy", "ra_reset", "ra_set_hip_stream", "ra_process_device", "ra_process_host", "ra_synchronize",
     "ra_feed", "ra_compute", "ra_get_stats", "ra_get_events", "ra_get_frame_pitches", "ra_resynth_notes", "ra_sqmag",
-    "ra_set_profiling", "ra_get_kernel_ms", "ra_render_note",
+    "ra_set_profiling", "ra_get_kernel_ms", "ra_get_kernel_launches", "ra_render_note",
 ]
 
 _lib = None
@@ -97,6 +97,7 @@ def lib():
         L.ra_sqmag.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]
         L.ra_set_profiling.argtypes = [C.c_void_p, C.c_int32]
         L.ra_get_kernel_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+        L.ra_get_kernel_launches.argtypes = [C.c_void_p, C.c_void_p]
         L.ra_even_window_size_frames.argtypes = [C.c_float, C.c_int]
         L.ra_window_center_stride_frames.argtypes = [C.c_float, C.c_int]
         _lib = L
@@ -193,6 +194,12 @@ class Context:
         calls = C.c_int64(0)
         _check(lib().ra_get_kernel_ms(self._h, _p(ms), C.byref(calls)))
         return dict(zip(("analysis", "track", "vocoder", "propagate", "render", "history"), ms.tolist())), calls.value
+
+    def kernel_launches(self):
+        """kernel launches behind each kernel_ms() entry (a block is cut into pipeline chunks)."""
+        k = np.zeros(6, np.int64)
+        _check(lib().ra_get_kernel_launches(self._h, _p(k)))
+        return dict(zip(("analysis", "track", "vocoder", "propagate", "render", "history"), k.tolist()))
 
     def stats(self):
         s = RaStats()

@@ -43,6 +43,7 @@ struct ra_context {
   std::vector<hipEvent_t> ev_pool;   // recycled timing events
   double kernel_ms[6] = {0, 0, 0, 0, 0, 0}; // analysis, track, vocoder, propagate, render, history
   int64_t kernel_calls = 0;
+  int64_t kernel_launches[6] = {0, 0, 0, 0, 0, 0};
   // chunk pipeline: analysis / tracking / propagation / render streams and the events chaining them
   bool pipe_ready = false;
   hipStream_t pipe_stream[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -493,6 +494,7 @@ int resolve_timing(ra_context *c) {
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b));
     c->kernel_ms[t.stage] += ms;
+    ++c->kernel_launches[t.stage];
     c->ev_pool.push_back(t.a);
     c->ev_pool.push_back(t.b);
   }
@@ -759,7 +761,7 @@ int ra_set_profiling(ra_context *c, int32_t enable) {
   int r = resolve_timing(c);
   if (r) return r;
   c->profiling = enable != 0;
-  for (int i = 0; i < 6; ++i) c->kernel_ms[i] = 0;
+  for (int i = 0; i < 6; ++i) { c->kernel_ms[i] = 0; c->kernel_launches[i] = 0; }
   c->kernel_calls = 0;
   return RA_OK;
 }
@@ -771,6 +773,15 @@ int ra_get_kernel_ms(ra_context *c, double *ms6, int64_t *calls) {
   if (r) return r;
   for (int i = 0; i < 6; ++i) ms6[i] = c->kernel_ms[i];
   if (calls) *calls = c->kernel_calls;
+  return RA_OK;
+}
+
+int ra_get_kernel_launches(ra_context *c, int64_t *launches6) {
+  if (!c || !launches6) return fail(RA_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(c->device));
+  int r = resolve_timing(c);
+  if (r) return r;
+  for (int i = 0; i < 6; ++i) launches6[i] = c->kernel_launches[i];
   return RA_OK;
 }
 

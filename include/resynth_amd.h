@@ -171,6 +171,8 @@ int ra_compute(ra_context *ctx, int32_t stream, double *h_buffer, int32_t n_fram
  */
 int ra_set_profiling(ra_context *ctx, int32_t enable);
 int ra_get_kernel_ms(ra_context *ctx, double *ms6, int64_t *calls);
+/* number of kernel launches behind each entry of ms6 (a block is cut into pipeline chunks: several launches per stage and call) */
+int ra_get_kernel_launches(ra_context *ctx, int64_t *launches6);
 
 /* counters and device-side error flags (synchronises) */
 int ra_get_stats(ra_context *ctx, ra_stats *stats);
