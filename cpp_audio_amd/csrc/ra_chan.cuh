@@ -161,17 +161,20 @@ __device__ inline void chan_step(Chan &c, const RaEnvParams &p, double dur, doub
     c.cre = re * g;
     c.cim = im * g;
   }
-  if (!(c.flags & FL_HAS_VOL)) {
-    c.finit = fmin(max_filter_inc, fabs(angle_increments(c, mode)));
-    double a = M_PI * c.finit; c.k = a / (1.0 + a); // one-pole low-pass coefficient (DESIGN.md §5, L0 decision)
-    c.y = c.target;
-  } else if (c.vol != c.target) {
-    double inc = fmin(max_filter_inc, fabs(angle_increments(c, mode)));
-    if (c.finit != inc) { c.finit = inc; double a = M_PI * inc; c.k = a / (1.0 + a); }
+  { // BaseVolumeAdjusted::step, audioelement.h:1195-1216.  Written with selects: conditional stores to c.k / c.y in the two branches get
+    // merged by the compiler into one store through a pointer, which pins both fields in scratch memory for the whole kernel.
+    const bool first = !(c.flags & FL_HAS_VOL);
+    const double inc = fmin(max_filter_inc, fabs(angle_increments(c, mode)));
+    const bool new_k = first || (c.vol != c.target && c.finit != inc);
+    const double a = M_PI * inc; // one-pole low-pass coefficient (DESIGN.md §5, L0 decision)
+    const double k_new = a / (1.0 + a);
+    c.finit = new_k ? inc : c.finit;
+    c.k = new_k ? k_new : c.k;
+    const double y0 = first ? c.target : c.y;
+    c.y = y0 + c.k * (c.target - y0);
+    c.vol = c.y;
+    c.flags |= FL_HAS_VOL;
   }
-  c.y = c.y + c.k * (c.target - c.y);
-  c.vol = c.y;
-  c.flags |= FL_HAS_VOL;
 }
 
 // ---- the same step with cheaper arithmetic, for the hop-parallel render kernel (not reference order) ------------------
@@ -221,17 +224,20 @@ __device__ inline void chan_step_fast(Chan &c, const RaEnvParams &p, double dur,
     c.cre = re * g;
     c.cim = im * g;
   }
-  if (!(c.flags & FL_HAS_VOL)) {
-    c.finit = fmin(max_filter_inc, fabs(angle_increments(c, 0)));
-    double a = M_PI * c.finit; c.k = a / (1.0 + a);
-    c.y = c.target;
-  } else if (c.vol != c.target) {
-    double inc = fmin(max_filter_inc, fabs(angle_increments(c, 0)));
-    if (c.finit != inc) { c.finit = inc; double a = M_PI * inc; c.k = a / (1.0 + a); }
+  { // BaseVolumeAdjusted::step, audioelement.h:1195-1216.  Written with selects: conditional stores to c.k / c.y in the two branches get
+    // merged by the compiler into one store through a pointer, which pins both fields in scratch memory for the whole kernel.
+    const bool first = !(c.flags & FL_HAS_VOL);
+    const double inc = fmin(max_filter_inc, fabs(angle_increments(c, 0)));
+    const bool new_k = first || (c.vol != c.target && c.finit != inc);
+    const double a = M_PI * inc;
+    const double k_new = a / (1.0 + a);
+    c.finit = new_k ? inc : c.finit;
+    c.k = new_k ? k_new : c.k;
+    const double y0 = first ? c.target : c.y;
+    c.y = y0 + c.k * (c.target - y0);
+    c.vol = c.y;
+    c.flags |= FL_HAS_VOL;
   }
-  c.y = c.y + c.k * (c.target - c.y);
-  c.vol = c.y;
-  c.flags |= FL_HAS_VOL;
 }
 
 // Enveloped::setAngleIncrements :218-225 -> FreqCtrl_::setAngleIncrements :3103-3108 -> InterpolatedFreq::setAngleIncrements :2752-2762
@@ -417,17 +423,20 @@ __device__ inline void chan_step_phase(Chan &c, const RaEnvParams &p, double dur
     c.inc = f;
   }
   c.theta += c.inc;
-  if (!(c.flags & FL_HAS_VOL)) {
-    c.finit = fmin(max_filter_inc, fabs(angle_increments(c, 0)));
-    double a = M_PI * c.finit; c.k = a / (1.0 + a);
-    c.y = c.target;
-  } else if (c.vol != c.target) {
-    double inc = fmin(max_filter_inc, fabs(angle_increments(c, 0)));
-    if (c.finit != inc) { c.finit = inc; double a = M_PI * inc; c.k = a / (1.0 + a); }
+  { // BaseVolumeAdjusted::step, audioelement.h:1195-1216.  Written with selects: conditional stores to c.k / c.y in the two branches get
+    // merged by the compiler into one store through a pointer, which pins both fields in scratch memory for the whole kernel.
+    const bool first = !(c.flags & FL_HAS_VOL);
+    const double inc = fmin(max_filter_inc, fabs(angle_increments(c, 0)));
+    const bool new_k = first || (c.vol != c.target && c.finit != inc);
+    const double a = M_PI * inc;
+    const double k_new = a / (1.0 + a);
+    c.finit = new_k ? inc : c.finit;
+    c.k = new_k ? k_new : c.k;
+    const double y0 = first ? c.target : c.y;
+    c.y = y0 + c.k * (c.target - y0);
+    c.vol = c.y;
+    c.flags |= FL_HAS_VOL;
   }
-  c.y = c.y + c.k * (c.target - c.y);
-  c.vol = c.y;
-  c.flags |= FL_HAS_VOL;
 }
 
 // chan_jump in the phase domain; a glide that ends inside the stretch is taken in one go (glide part, clamp step, constant tail)

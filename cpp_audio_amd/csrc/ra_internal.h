@@ -149,6 +149,7 @@ struct RaPhaseClock {
     acc[I] += now - t; ++laps[I];
     t = now;
   }
+  __device__ inline void count(int i) { if (dst) atomicAdd(dst + i, 1ull); }
   __device__ inline void flush(int base) {
     if (!dst) return;
     for (int i = 0; i < 4; ++i) if (laps[i]) { atomicAdd(dst + base + i, acc[i]); atomicAdd(dst + base + 4 + i, (unsigned long long)laps[i]); }

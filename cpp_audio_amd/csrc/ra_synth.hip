@@ -123,6 +123,7 @@ __device__ inline void render_range(Chan &c, const SynLds &L, const SynConst &k,
 struct Regime {
   double dv;                        // envelope value increment per step
   double base, slope, alpha, beta;  // glide: inc = base + slope * cur ; cur' = alpha * cur + beta  (steady: slope 0, alpha 1, beta 0)
+  double rf;                        // hi: running reciprocal of the increment (refined by Newton steps as the glide moves)
   int steps_left;                   // envelope steps before its next transition
   int pending;                      // steps taken since the envelope counters were last brought up to date
   bool active, gliding, irregular;  // irregular: the next step must be the general one
@@ -133,7 +134,7 @@ struct Regime {
 __device__ inline void regime_setup(const Chan &c, const SynConst &k, double inv_dur, Regime &r) {
   r.pending = 0;
   r.active = rt_active(c);
-  r.dv = 0; r.base = c.inc; r.slope = 0; r.alpha = 1; r.beta = 0; r.steps_left = 0x7fffffff; r.gliding = false; r.irregular = false; r.hi = false; r.kvar = false;
+  r.dv = 0; r.base = c.inc; r.slope = 0; r.alpha = 1; r.beta = 0; r.steps_left = 0x7fffffff; r.gliding = false; r.irregular = false; r.hi = false; r.kvar = false; r.rf = 0;
   if (!r.active) return;
   r.steps_left = env_regular_steps(c, k.ep);
   switch (c.state) {
@@ -160,13 +161,35 @@ __device__ inline void regime_setup(const Chan &c, const SynConst &k, double inv
     r.alpha = 1.0 + c.C * r.slope;
     r.beta = c.C * (c.from + 0.5 * r.slope);
     lo = fmin(fabs(c.from + r.slope * c.cur), fabs(f_end));
-    r.hi = fmax(fabs(c.from), fabs(c.to)) > 0.25 || c.from <= 0. || c.to <= 0.;
+    if (c.from <= 0. || c.to <= 0.) { r.irregular = true; return; } // increments are positive for every event the path produces
+    r.hi = fmax(c.from, c.to) > 0.25;
+    if (r.hi) r.rf = 1.0 / (c.from + r.slope * c.cur);
   }
   if (c.vol != c.target) { // the volume filter's coefficient is constant over the stretch, or follows a (positive) glide step by step
     double want = fmin(k.max_filter_inc, lo);
     if (r.gliding && lo < k.max_filter_inc) { if (c.from > 0. && c.to > 0.) r.kvar = true; else r.irregular = true; }
     else if (!(c.finit == want)) r.irregular = true;
   }
+}
+
+// cross-lane moves on the VALU (gfx950 permlane swaps / DPP) for the channel sums: a ds_bpermute round trip costs ~100 cycles each
+__device__ inline double lane_xor32_low(double x) { // value of lane ^ 32, valid in lanes 0..31
+  const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ inline double lane_xor16_even(double x) { // value of lane ^ 16, valid in the even rows of 16 lanes
+  const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ inline double lane_ror8(double x) { // value of lane (i + 8) mod 16 of the same row
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
 }
 
 constexpr int TD = 8;            // tile depth of the regime renderer
@@ -178,9 +201,9 @@ constexpr int TROW_MONO = TD + 1; // stereo_spread 0: every channel has the same
 // HI: some gliding lane passes above fs/8, where the anti-aliasing gain follows the increment.
 // The phasor is renormalised once per tile instead of once per step (drift < 1e-15 per tile; every hop restarts from the angle).
 template <bool GLIDE, bool HI, bool KVAR>
-__device__ inline void clean_tile(Chan &c, const Regime &r, double max_filter_inc, double cd0, double sd0, double cd, double sd, double (&v)[TD]) {
+__device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, double cd0, double sd0, double cd, double sd, double (&v)[TD]) {
   double cur = c.cur, mre = c.mre, mim = c.mim, cre = c.cre, cim = c.cim, y = c.y, value = c.value, alias = c.alias, f = c.inc;
-  double kk = c.k, fin = c.finit, rr = 0.0;
+  double kk = c.k, fin = c.finit, rr = 0.0, rf = r.rf;
   const double target = c.target;
   if (KVAR) rr = 1.0 / (1.0 + M_PI * c.finit);
   double va = alias * value;
@@ -193,7 +216,15 @@ __device__ inline void clean_tile(Chan &c, const Regime &r, double max_filter_in
       const double rc = i == 0 ? cd0 : cd, rs = i == 0 ? sd0 : sd;
       const double mr = fma(mre, rc, -(mim * rs)), mi = fma(mre, rs, mim * rc);
       mre = mr; mim = mi;
-      if (HI) { if (r.hi) alias = alias_mult(f); }
+      if (HI) { // freqAliasingMultiplicator (audioelement.h:466-483) without its division: 1 / inc follows the glide by two Newton steps
+        double rn = rf * (2.0 - f * rf);
+        rn = rn * (2.0 - f * rn);
+        double a = (rn - 1.0) * (1. / 3.);
+        a = rn > 4. ? 1. : a;
+        a = rn < 1. ? 0. : a;
+        alias = r.hi ? a : alias;
+        rf = r.hi ? rn : rf;
+      }
       if (KVAR) { // BaseVolumeAdjusted::step, audioelement.h:1195-1216: k = a / (1 + a), a = pi min(max increment, |inc|); 1 / (1 + a) by Newton
         if (r.kvar && y != target) {
           const double w = fmin(max_filter_inc, fabs(f));
@@ -218,7 +249,18 @@ __device__ inline void clean_tile(Chan &c, const Regime &r, double max_filter_in
     c.mre = mre; c.mim = mim; c.cur = cur; c.alias = alias;
     if (r.gliding) { c.fres = f; c.inc = f; }
     if (KVAR) { c.k = kk; c.finit = fin; }
+    if (HI) r.rf = rf;
   }
+}
+
+// One sample of a lane at a transition: bring the envelope counters up to date, take the general step, re-derive the regime.
+__device__ inline double transition_step(Chan &c, Regime &r, const SynConst &k, double inv_dur) {
+  double v = 0.0;
+  if (r.pending) env_jump(c, k.ep, r.pending);
+  chan_step_fast(c, k.ep, k.dur, inv_dur, k.max_filter_inc);
+  if (rt_active(c)) v = c.vol * ((c.alias * c.cim) * c.value);
+  regime_setup(c, k, inv_dur, r);
+  return v;
 }
 
 template <bool MONO>
@@ -247,7 +289,7 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
       c.cur = fma(r.alpha, c.cur, r.beta);
       const double mr = fma(c.mre, cd, -(c.mim * sd)), mi = fma(c.mre, sd, c.mim * cd);
       c.mre = mr; c.mim = mi; c.inc = f;
-      if (r.hi) c.alias = alias_mult(f);
+      if (r.hi) { c.alias = alias_mult(f); r.rf = 1.0 / f; }
       if (r.kvar && c.y != c.target) {
         const double w = fmin(k.max_filter_inc, fabs(f));
         if (w != c.finit) { c.finit = w; const double a = M_PI * w; c.k = a / (1.0 + a); }
@@ -271,12 +313,20 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
     if (r.active && r.gliding) step0 = fma(r.alpha - 1.0, c.cur, r.beta); // cur increment of the tile's first step
     const bool clean = !r.active || (!r.irregular && r.steps_left >= TD &&
                                      (!r.gliding || (fabs(r.alpha - 1.0) < 1e-2 && c.cur + (TD - 1) * fabs(step0) * 1.1 <= lim)));
+#ifdef RA_X_ALLCLEAN
+    if (m == TD) {
+#else
     if (m == TD && __all(clean)) {
+#endif
       double v[TD];
 #pragma unroll
       for (int i = 0; i < TD; ++i) v[i] = 0.0;
       const bool any_glide = __any(r.active && r.gliding);
+#ifdef RA_X_NOCOMPUTE
+      if (false) {
+#else
       if (r.active) {
+#endif
         if (!any_glide) clean_tile<false, false, false>(c, r, k.max_filter_inc, 1.0, 0.0, 1.0, 0.0, v);
         else {
           // Rotation of `mult` per step while gliding: pi (inc_i - inc_{i-1}).  The tile's first step turns by d0 = pi (inc_0 - inc),
@@ -313,10 +363,7 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
         const bool irr = r.active && (r.irregular || r.steps_left == 0 || (r.gliding && c.cur > lim));
         if (__any(irr)) {
           if (irr) {
-            if (r.pending) env_jump(c, k.ep, r.pending);
-            chan_step_fast(c, k.ep, k.dur, inv_dur, k.max_filter_inc);
-            if (rt_active(c)) v = c.vol * ((c.alias * c.cim) * c.value);
-            regime_setup(c, k, inv_dur, r);
+            v = transition_step(c, r, k, inv_dur);
           }
         }
         if (!irr && r.active) {
@@ -334,8 +381,12 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
       }
       clk.lap<1>();
     }
-    __syncthreads();
-    if (l < 64) { // 16 outputs (8 frames x 2) x 4 channel quarters; MONO: 8 sums x 8 channel eighths
+    if (Ppad > 64) __syncthreads(); // one wave: its LDS operations execute in order, no barrier needed
+#ifdef RA_X_NOREDUCE
+    if (l < 64 && t == seg_end - 8) {
+#else
+    if (l < 64) {
+#endif // 16 outputs (8 frames x 2) x 4 channel quarters; MONO: 8 sums x 8 channel eighths
       double acc = 0.0;
       if (fr < m) {
         const double *q = col;
@@ -345,15 +396,19 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
           for (int j = 0; j < NJ; ++j) acc += q[j * ROW];
         }
       }
-      acc += __shfl_down(acc, 32);
-      acc += __shfl_down(acc, 16);
+      acc += lane_xor32_low(acc);
+      acc += lane_xor16_even(acc);
       if (MONO) {
-        acc += __shfl_down(acc, 8);
+        acc += lane_ror8(acc);
         if (l < 8 && fr < m) {
           const int64_t rel = (t - t0) + fr;
           double oL = gLm * acc, oR = gRm * acc;
           if (mix) { oL += mix[rel]; oR += mix[rel]; }
-          if (out) { out[((size_t)s * n + rel) * 2] = (float)oL; out[((size_t)s * n + rel) * 2 + 1] = (float)oR; }
+          if (out) { // one 8-byte store per frame when the caller's buffer allows it (two 4-byte stores make partial-line writes)
+            float *o = out + ((size_t)s * n + rel) * 2;
+            if ((reinterpret_cast<uintptr_t>(out) & 7) == 0) *reinterpret_cast<float2 *>(o) = make_float2((float)oL, (float)oR);
+            else { o[0] = (float)oL; o[1] = (float)oR; }
+          }
           if (out_d) { out_d[((size_t)s * n + rel) * 2] = oL; out_d[((size_t)s * n + rel) * 2 + 1] = oR; }
         }
       } else if (l < 16 && fr < m) {
@@ -363,7 +418,7 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
         if (out_d) out_d[((size_t)s * n + rel) * 2 + ch] = acc;
       }
     }
-    __syncthreads();
+    if (Ppad > 64) __syncthreads();
     clk.lap<2>();
     t += m;
   }
