@@ -132,9 +132,9 @@ struct RaBuffers {
 // lap<I>() accumulates in registers instead (inner loops); flush() adds those totals and lap counts to slots base + I / base + 4 + I.
 struct RaPhaseClock {
   unsigned long long *dst, t, acc[4];
-  unsigned laps[4];
+  unsigned laps[4], cnt[4];
   __device__ inline RaPhaseClock(unsigned long long *d, bool on) : dst(on ? d : nullptr), t(0) {
-    for (int i = 0; i < 4; ++i) { acc[i] = 0; laps[i] = 0; }
+    for (int i = 0; i < 4; ++i) { acc[i] = 0; laps[i] = 0; cnt[i] = 0; }
     if (dst) t = __builtin_readcyclecounter();
   }
   __device__ inline void mark(int i) {
@@ -150,9 +150,11 @@ struct RaPhaseClock {
     t = now;
   }
   __device__ inline void count(int i) { if (dst) atomicAdd(dst + i, 1ull); }
+  template <int I> __device__ inline void tally() { if (dst) ++cnt[I]; }
   __device__ inline void flush(int base) {
     if (!dst) return;
     for (int i = 0; i < 4; ++i) if (laps[i]) { atomicAdd(dst + base + i, acc[i]); atomicAdd(dst + base + 4 + i, (unsigned long long)laps[i]); }
+    for (int i = 0; i < 4; ++i) if (cnt[i]) atomicAdd(dst + base + 8 + i, (unsigned long long)cnt[i]);
   }
 };
 

@@ -200,37 +200,40 @@ constexpr int TROW_MONO = TD + 1; // stereo_spread 0: every channel has the same
 // GLIDE: some lane of the wave glides (the others run the same code with the identity rotation, alpha = 1, beta = 0);
 // HI: some gliding lane passes above fs/8, where the anti-aliasing gain follows the increment.
 // The phasor is renormalised once per tile instead of once per step (drift < 1e-15 per tile; every hop restarts from the angle).
-template <bool GLIDE, bool HI, bool KVAR>
-__device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, double cd0, double sd0, double cd, double sd, double (&v)[TD]) {
+#ifndef RA_TILE_UNROLL
+#define RA_TILE_UNROLL 8 // measured on configs[1]: 8 (straight-line tile) 14.9 ms, 1 (rolled) 15.4 ms, 2: 16.5 ms per step
+#endif
+#define RA_PRAGMA(x) _Pragma(#x)
+#define RA_UNROLL(n) RA_PRAGMA(unroll n)
+template <bool GLIDE, bool HI, bool KVAR, bool MONO>
+__device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, double cd0, double sd0, double cd, double sd, double *mine) {
   double cur = c.cur, mre = c.mre, mim = c.mim, cre = c.cre, cim = c.cim, y = c.y, value = c.value, alias = c.alias, f = c.inc;
   double kk = c.k, fin = c.finit, rr = 0.0, rf = r.rf;
   const double target = c.target;
   if (KVAR) rr = 1.0 / (1.0 + M_PI * c.finit);
   double va = alias * value;
   const double dva = alias * r.dv;
-#pragma unroll
-  for (int i = 0; i < TD; ++i) {
+  auto step = [&](double rc, double rs) -> double {
     if (GLIDE) {
       f = fma(r.slope, cur, r.base);
       cur = fma(r.alpha, cur, r.beta);
-      const double rc = i == 0 ? cd0 : cd, rs = i == 0 ? sd0 : sd;
       const double mr = fma(mre, rc, -(mim * rs)), mi = fma(mre, rs, mim * rc);
       mre = mr; mim = mi;
       if (HI) { // freqAliasingMultiplicator (audioelement.h:466-483) without its division: 1 / inc follows the glide by two Newton steps
-        double rn = rf * (2.0 - f * rf);
-        rn = rn * (2.0 - f * rn);
-        double a = (rn - 1.0) * (1. / 3.);
-        a = rn > 4. ? 1. : a;
-        a = rn < 1. ? 0. : a;
+        // (lanes that are not hi carry rf = 0, which stays 0); (1 / inc - 1) / 3, 1 above 4 and 0 below 1 as in the function's branches
+        rf = rf * fma(-f, rf, 2.0);
+        rf = rf * fma(-f, rf, 2.0);
+        double a = fma(rf, 1. / 3., -1. / 3.);
+        a = rf > 4. ? 1. : a;
+        a = rf < 1. ? 0. : a;
         alias = r.hi ? a : alias;
-        rf = r.hi ? rn : rf;
       }
       if (KVAR) { // BaseVolumeAdjusted::step, audioelement.h:1195-1216: k = a / (1 + a), a = pi min(max increment, |inc|); 1 / (1 + a) by Newton
         if (r.kvar && y != target) {
           const double w = fmin(max_filter_inc, fabs(f));
           if (w != fin) {
             const double a1 = 1.0 + M_PI * w;
-            rr = rr * (2.0 - a1 * rr); rr = rr * (2.0 - a1 * rr);
+            rr = rr * fma(-a1, rr, 2.0); rr = rr * fma(-a1, rr, 2.0);
             kk = (M_PI * w) * rr; fin = w;
           }
         }
@@ -239,9 +242,14 @@ __device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, dou
     const double re = fma(cre, mre, -(cim * mim)), im = fma(cre, mim, cim * mre);
     cre = re; cim = im;
     y = fma(kk, target - y, y);
-    if (HI) { value += r.dv; v[i] = y * ((alias * cim) * value); }
-    else { va += dva; v[i] = y * (cim * va); } // the anti-aliasing gain is constant here: folded into the envelope ramp
-  }
+    if (HI) { value += r.dv; return y * ((alias * cim) * value); }
+    va += dva;
+    return y * (cim * va); // the anti-aliasing gain is constant here: folded into the envelope ramp
+  };
+  auto put = [&](int i, double v) { if (MONO) mine[i] = v; else { mine[i] = c.gL * v; mine[TD + i] = c.gR * v; } };
+  put(0, step(cd0, sd0));
+  RA_UNROLL(RA_TILE_UNROLL)
+  for (int i = 1; i < TD; ++i) put(i, step(cd, sd));
   const double g = 0.5 * (3.0 - fma(cre, cre, cim * cim));
   c.cre = cre * g; c.cim = cim * g;
   c.y = y; c.vol = y; c.value = HI ? value : fma((double)TD, r.dv, value);
@@ -254,6 +262,7 @@ __device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, dou
 }
 
 // One sample of a lane at a transition: bring the envelope counters up to date, take the general step, re-derive the regime.
+// (Inlined: an out-of-line version on private copies, with or without a register budget of its own, measured 1.5 - 3x slower.)
 __device__ inline double transition_step(Chan &c, Regime &r, const SynConst &k, double inv_dur) {
   double v = 0.0;
   if (r.pending) env_jump(c, k.ep, r.pending);
@@ -318,16 +327,13 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
 #else
     if (m == TD && __all(clean)) {
 #endif
-      double v[TD];
-#pragma unroll
-      for (int i = 0; i < TD; ++i) v[i] = 0.0;
       const bool any_glide = __any(r.active && r.gliding);
 #ifdef RA_X_NOCOMPUTE
       if (false) {
 #else
       if (r.active) {
 #endif
-        if (!any_glide) clean_tile<false, false, false>(c, r, k.max_filter_inc, 1.0, 0.0, 1.0, 0.0, v);
+        if (!any_glide) { clk.tally<0>(); clean_tile<false, false, false, MONO>(c, r, k.max_filter_inc, 1.0, 0.0, 1.0, 0.0, mine); }
         else {
           // Rotation of `mult` per step while gliding: pi (inc_i - inc_{i-1}).  The tile's first step turns by d0 = pi (inc_0 - inc),
           // whatever the oscillator's increment currently is (0 right after a note change); the later steps turn by
@@ -343,9 +349,10 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
             sd = dA * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
             cd = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
           }
-          if (__any(r.active && r.kvar)) clean_tile<true, true, true>(c, r, k.max_filter_inc, cd0, sd0, cd, sd, v);
-          else if (__any(r.active && r.gliding && r.hi)) clean_tile<true, true, false>(c, r, k.max_filter_inc, cd0, sd0, cd, sd, v);
-          else clean_tile<true, false, false>(c, r, k.max_filter_inc, cd0, sd0, cd, sd, v);
+          if (__any(r.active && r.kvar)) clk.tally<3>(); else if (__any(r.active && r.gliding && r.hi)) clk.tally<2>(); else clk.tally<1>();
+          if (__any(r.active && r.kvar)) clean_tile<true, true, true, MONO>(c, r, k.max_filter_inc, cd0, sd0, cd, sd, mine);
+          else if (__any(r.active && r.gliding && r.hi)) clean_tile<true, true, false, MONO>(c, r, k.max_filter_inc, cd0, sd0, cd, sd, mine);
+          else clean_tile<true, false, false, MONO>(c, r, k.max_filter_inc, cd0, sd0, cd, sd, mine);
           // over the m' = TD - 1 later steps the even spread runs ahead of the exact (linearly growing) rotation by b (j+1)(m'-1-j)/2
           // at step j, b = pi slope step0 (alpha - 1); the oscillator has integrated that: take the sum b (m'-1) m' (m'+1) / 12 back out
           const double dl = (M_PI * r.slope) * step0 * (r.alpha - 1.0) * ((TD - 2) * (TD - 1) * TD * (1.0 / 12.0));
@@ -353,11 +360,15 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
           c.cre = re; c.cim = im;
         }
         r.pending += TD; r.steps_left -= TD;
-      }
+      } else {
 #pragma unroll
-      for (int i = 0; i < TD; ++i) { if (MONO) mine[i] = v[i]; else { mine[i] = c.gL * v[i]; mine[TD + i] = c.gR * v[i]; } }
+        for (int i = 0; i < (MONO ? TD : 2 * TD); ++i) mine[i] = 0.0;
+      }
       clk.lap<0>();
     } else {
+#ifdef RA_X_NOUNCLEAN
+      for (int i = 0; i < m; ++i) mine[i] = 0.0;
+#else
       for (int i = 0; i < m; ++i) {
         double v = 0.0;
         const bool irr = r.active && (r.irregular || r.steps_left == 0 || (r.gliding && c.cur > lim));
@@ -379,6 +390,7 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
         }
         if (MONO) mine[i] = v; else { mine[i] = c.gL * v; mine[TD + i] = c.gR * v; }
       }
+#endif
       clk.lap<1>();
     }
     if (Ppad > 64) __syncthreads(); // one wave: its LDS operations execute in order, no barrier needed
