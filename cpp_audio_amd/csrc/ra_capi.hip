@@ -590,24 +590,33 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
       sp.ct1 = (i == n_chunks - 1) ? t0 + n : ra_fire_sample(p.N, p.H, f_lo + fb1);
       return sp;
     };
-    // An analysis workgroup needs four wave slots and a third of a CU's LDS at once: beside a chip full of single-wave render
-    // workgroups it gets few slots.  Measured on configs[1], letting the renderer start early still wins by ~3 % over holding it
-    // back until the block's analysis is done (RA_RENDER_AFTER_ANALYSIS=1, kept as a tuning aid): both orders are work-bound.
-    static const bool render_after_analysis = std::getenv("RA_RENDER_AFTER_ANALYSIS") != nullptr;
-    for (int i = 0; i < n_chunks; ++i) {
+    // Queue order.  An analysis workgroup needs four wave slots and a third of a CU's LDS at once, so beside a chip full of single-wave
+    // render workgroups it gets few slots and its chunks stretch from 0.6 to ~2.8 ms.  Measured on configs[1] (ms per step):
+    //   0  every stage on its own queue, all concurrent                                   23.8 - 24.7   <- default
+    //   1  analysis and render share one queue, analysis `lead` chunks ahead (A0 A1 R0 A2 R1 ...)  26.3
+    //   2  concurrent queues, but the render waits for the last analysis chunk              25.1
+    // i.e. overlapping the two throughput kernels beats giving each the chip to itself, although both then run slower.
+    static const int order = std::getenv("RA_PIPELINE_ORDER") ? std::atoi(std::getenv("RA_PIPELINE_ORDER")) : 0;
+    static const int lead = std::getenv("RA_PIPELINE_LEAD") ? std::max(1, std::atoi(std::getenv("RA_PIPELINE_LEAD"))) : 2;
+    if (order == 1 && !one_queue) sA = sR;
+    auto front = [&](int i) -> int { // analysis of chunk i, and the two chains that hang off it
       const RaSpan sp = span_of(i);
       timed_launch(c, ST_ANALYSIS, sA, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, sp.fb0, sp.nfb, nfb, sA); });
       HIP_TRY(hipEventRecord(c->ev_chunk[0][i], sA));
-    }
-    if (render_after_analysis && !one_queue) HIP_TRY(hipStreamWaitEvent(sR, c->ev_chunk[0][n_chunks - 1], 0));
-    for (int i = 0; i < n_chunks; ++i) {
-      const RaSpan sp = span_of(i);
       HIP_TRY(hipStreamWaitEvent(sT, c->ev_chunk[0][i], 0));
       timed_launch(c, ST_TRACK, sT, [&] { ra_launch_track(p, b, f_lo, sp.fb0, sp.nfb, sT); });
       HIP_TRY(hipEventRecord(c->ev_chunk[1][i], sT));
       HIP_TRY(hipStreamWaitEvent(sP, c->ev_chunk[1][i], 0));
       timed_launch(c, ST_PROPAGATE, sP, [&] { ra_launch_synth_propagate(p, b, sp, sP); });
       HIP_TRY(hipEventRecord(c->ev_chunk[2][i], sP));
+      return RA_OK;
+    };
+    const int ahead = order == 1 ? std::min(lead, n_chunks) : n_chunks;
+    for (int i = 0; i < ahead; ++i) if (int fr = front(i)) return fr;
+    if (order == 2 && !one_queue) HIP_TRY(hipStreamWaitEvent(sR, c->ev_chunk[0][n_chunks - 1], 0));
+    for (int i = 0; i < n_chunks; ++i) {
+      if (i + ahead < n_chunks) if (int fr = front(i + ahead)) return fr;
+      const RaSpan sp = span_of(i);
       HIP_TRY(hipStreamWaitEvent(sR, c->ev_chunk[2][i], 0));
       timed_launch(c, ST_RENDER, sR, [&] { ra_launch_synth_render(p, b, sp, d_out, d_out_d, sR); });
     }
