@@ -195,7 +195,7 @@ __device__ inline void osc_set_inc_fast(Chan &c, double f) {
     c.mre = mr; c.mim = mi;
   } else {
     double sn, cs;
-    sincos(M_PI * f, &sn, &cs);
+    sincospi(f, &sn, &cs); // e^{i pi f}: no large-argument reduction to carry around (|f| < 1 on this path)
     c.mre = cs; c.mim = sn;
   }
   c.inc = f;

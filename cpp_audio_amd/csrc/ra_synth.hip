@@ -322,17 +322,9 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
     if (r.active && r.gliding) step0 = fma(r.alpha - 1.0, c.cur, r.beta); // cur increment of the tile's first step
     const bool clean = !r.active || (!r.irregular && r.steps_left >= TD &&
                                      (!r.gliding || (fabs(r.alpha - 1.0) < 1e-2 && c.cur + (TD - 1) * fabs(step0) * 1.1 <= lim)));
-#ifdef RA_X_ALLCLEAN
-    if (m == TD) {
-#else
     if (m == TD && __all(clean)) {
-#endif
       const bool any_glide = __any(r.active && r.gliding);
-#ifdef RA_X_NOCOMPUTE
-      if (false) {
-#else
       if (r.active) {
-#endif
         if (!any_glide) { clk.tally<0>(); clean_tile<false, false, false, MONO>(c, r, k.max_filter_inc, 1.0, 0.0, 1.0, 0.0, mine); }
         else {
           // Rotation of `mult` per step while gliding: pi (inc_i - inc_{i-1}).  The tile's first step turns by d0 = pi (inc_0 - inc),
@@ -366,9 +358,6 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
       }
       clk.lap<0>();
     } else {
-#ifdef RA_X_NOUNCLEAN
-      for (int i = 0; i < m; ++i) mine[i] = 0.0;
-#else
       for (int i = 0; i < m; ++i) {
         double v = 0.0;
         const bool irr = r.active && (r.irregular || r.steps_left == 0 || (r.gliding && c.cur > lim));
@@ -390,15 +379,10 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
         }
         if (MONO) mine[i] = v; else { mine[i] = c.gL * v; mine[TD + i] = c.gR * v; }
       }
-#endif
       clk.lap<1>();
     }
     if (Ppad > 64) __syncthreads(); // one wave: its LDS operations execute in order, no barrier needed
-#ifdef RA_X_NOREDUCE
-    if (l < 64 && t == seg_end - 8) {
-#else
-    if (l < 64) {
-#endif // 16 outputs (8 frames x 2) x 4 channel quarters; MONO: 8 sums x 8 channel eighths
+    if (l < 64) { // 16 outputs (8 frames x 2) x 4 channel quarters; MONO: 8 sums x 8 channel eighths
       double acc = 0.0;
       if (fr < m) {
         const double *q = col;
