@@ -530,7 +530,7 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
   int64_t f_lo, nfb;
   frames_in_block(p, t0, n, f_lo, nfb);
   int n_chunks = 1;
-  if (c->cfg.reference_order != 1 && nfb >= 64) n_chunks = static_cast<int>(std::min<int64_t>(kMaxChunks, nfb / 48));
+  if (c->cfg.reference_order != 1 && nfb >= 64) n_chunks = static_cast<int>(std::min<int64_t>(kMaxChunks, nfb / 48 + 2));
   static const int forced_chunks = std::getenv("RA_PIPELINE_CHUNKS") ? std::atoi(std::getenv("RA_PIPELINE_CHUNKS")) : 0; // tuning aid
   if (forced_chunks > 0 && c->cfg.reference_order != 1 && nfb >= forced_chunks) n_chunks = std::min(forced_chunks, kMaxChunks);
   int r = ensure_scratch(c, nfb, n, n_chunks);
@@ -579,9 +579,26 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
     if (p.voc_enabled) { // independent of the analysis chain: runs beside it, only the render waits for the mix
       timed_launch(c, ST_VOCODER, sR, [&] { ra_launch_vocoder(p, b, d_voice, d_carrier, t0, n, sR); });
     }
-    // chunk 0 is short: nothing overlaps its analysis -> tracking -> propagation, so the render stream starts that much sooner
-    const int64_t head = n_chunks > 2 ? std::min<int64_t>(16, nfb / (2 * n_chunks)) : nfb / n_chunks;
-    auto cut = [&](int i) -> int64_t { return i == 0 ? 0 : (n_chunks > 2 ? head + (nfb - head) * (i - 1) / (n_chunks - 1) : nfb * i / n_chunks); };
+    // Chunk boundaries (in frames).  The first chunk is short — nothing overlaps its analysis -> tracking -> propagation, so the render
+    // stream starts that much sooner — and so are the last two: when the analysis of the block is over, only the chain and the render of
+    // the final chunks remain and the chip drains; short final chunks make that drain short.
+    int64_t bounds[kMaxChunks + 1];
+    {
+      static const int tail1 = std::getenv("RA_PIPELINE_TAIL1") ? std::atoi(std::getenv("RA_PIPELINE_TAIL1")) : 28; // tuning aids
+      static const int tail2 = std::getenv("RA_PIPELINE_TAIL2") ? std::atoi(std::getenv("RA_PIPELINE_TAIL2")) : 12;
+      bounds[0] = 0; bounds[n_chunks] = nfb;
+      if (n_chunks >= 5) {
+        const int64_t head = std::min<int64_t>(16, nfb / (2 * n_chunks));
+        const int64_t t2 = std::min<int64_t>(tail2, nfb / (2 * n_chunks)), t1 = std::min<int64_t>(tail1, nfb / n_chunks);
+        const int64_t mid = nfb - head - t1 - t2;
+        bounds[1] = head;
+        for (int i = 2; i <= n_chunks - 2; ++i) bounds[i] = head + mid * (i - 1) / (n_chunks - 3);
+        bounds[n_chunks - 1] = nfb - t2;
+      } else {
+        for (int i = 1; i < n_chunks; ++i) bounds[i] = nfb * i / n_chunks;
+      }
+    }
+    auto cut = [&](int i) -> int64_t { return bounds[i]; };
     auto span_of = [&](int i) {
       const int64_t fb0 = cut(i), fb1 = (i == n_chunks - 1) ? nfb : cut(i + 1);
       RaSpan sp;
