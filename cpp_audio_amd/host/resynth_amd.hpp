@@ -108,6 +108,7 @@ public:
   }
   int64_t frames() const { return frames_; }
   int countDroppedNoteOns() const { return static_cast<int>(stats_.dropped_note_on); } // lib.cpp:549-551
+  ra_stats stats() const { return stats_; }
 
 private:
   int64_t frames_ = 0;
