@@ -552,14 +552,15 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
       timed_launch(c, ST_RENDER, user, [&] { ra_launch_synth_render(p, b, sp, d_out, d_out_d, user); });
     }
   } else {
+    static const int prio_mode = std::getenv("RA_PIPELINE_PRIO") ? std::atoi(std::getenv("RA_PIPELINE_PRIO")) : 1;
     if (!c->pipe_ready) {
       // The dependency chain (analysis -> tracking -> propagation) must stay ahead of the renderer, which is the long pole and
       // fills whatever the chain leaves free: the chain's queues get dispatch priority over the render queue.
       int prio_least = 0, prio_greatest = 0;
       HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-      static const int prio_mode = std::getenv("RA_PIPELINE_PRIO") ? std::atoi(std::getenv("RA_PIPELINE_PRIO")) : 1; // tuning aid: 0 = flat
       for (int i = 0; i < 4; ++i) {
-        const int prio = !prio_mode ? 0 : (i == 3 ? prio_least : prio_greatest);
+        // RA_PIPELINE_PRIO (tuning aid): 0 = flat, 1 = chain high / render low, 2 = tracking and propagation high, analysis and render normal
+        const int prio = prio_mode == 0 ? 0 : prio_mode == 2 ? ((i == 1 || i == 2) ? prio_greatest : 0) : (i == 3 ? prio_least : prio_greatest);
         HIP_TRY(hipStreamCreateWithPriority(&c->pipe_stream[i], hipStreamNonBlocking, prio));
       }
       HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -572,6 +573,9 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
     // every stage has a queue of its own (on a shared queue propagate(i+1) would wait for render(i)); the caller's stream only
     // forks into them and joins them at the end of the block
     hipStream_t sA = c->pipe_stream[0], sT = c->pipe_stream[1], sP = c->pipe_stream[2], sR = c->pipe_stream[3];
+    // streams of one priority share ROCm's 4 hardware queues; with flat priorities the analysis rides on the caller's stream instead so that
+    // no two stages end up behind each other on one queue
+    if (prio_mode == 0) sA = user;
     static const bool one_queue = std::getenv("RA_PIPELINE_SERIAL") != nullptr; // tuning aid: same chunks, no overlap
     if (one_queue) sA = sT = sP = sR = user;
     HIP_TRY(hipEventRecord(c->ev_fork, user));

@@ -17,6 +17,8 @@
 // Outputs of a 16-frame tile are transposed through LDS and summed over channels by 32 lanes (one per frame x output),
 // so the cross-lane reduction costs ~2 LDS ops per channel-sample instead of a 64-lane butterfly per sample.
 #include "ra_chan.cuh"
+#include <algorithm>
+#include <cstdlib>
 
 extern __shared__ __align__(16) unsigned char ra_smem_syn[];
 
@@ -556,7 +558,13 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) RA_PROP_OCC ra_synth_propagat
 // ---- K3b: render one segment ----------------------------------------------------------------------------------------
 template <bool DIAG, bool MONO>
 __device__ inline void render_segment(const RaParams &p, const RaBuffers &b, const RaSpan &sp, float *__restrict__ out, double *__restrict__ out_d) {
-  const int i = blockIdx.x, s = blockIdx.y, l = threadIdx.x, Ppad = p.Ppad;
+  // blockDim.y > 1 (RA_RENDER_GROUP, single-wave streams only): wave y of the workgroup renders its own hop, nothing is shared between the
+  // waves.  Grouping four hops into a workgroup makes the renderer release wave slots on all four SIMDs of a CU at once, which lets the
+  // 4-wave analysis workgroups queued beside it be placed (their launches shrink from 18 to 13 ms per step), but the renderer then loses
+  // more than the chain gains: 24.6 ms per step against 22.7 ms with one hop per workgroup (the default).
+  const int wy = __builtin_amdgcn_readfirstlane((int)threadIdx.y); // wave-uniform (blockDim.x is a multiple of 64): keeps the hop's loops scalar
+  const int i = blockIdx.x * blockDim.y + wy, s = blockIdx.y, l = threadIdx.x, Ppad = p.Ppad;
+  if (i > sp.nfb) return;
   const int64_t seg_begin = (i == 0) ? sp.ct0 : ra_fire_sample(p.N, p.H, sp.f_lo + sp.fb0 + i - 1);
   const int64_t seg_end = (i < sp.nfb) ? ra_fire_sample(p.N, p.H, sp.f_lo + sp.fb0 + i) : sp.ct1;
   if (seg_end <= seg_begin) return;
@@ -573,7 +581,8 @@ __device__ inline void render_segment(const RaParams &p, const RaBuffers &b, con
     SynLds L = carve(ra_smem_syn, Ppad);
     if (p.render_mode == 2) render_range<false>(c, L, k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
     else render_range<true>(c, L, k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
-  } else render_range_fast<MONO>(c, reinterpret_cast<double *>(ra_smem_syn), k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d, clk);
+  } else render_range_fast<MONO>(c, reinterpret_cast<double *>(ra_smem_syn) + (size_t)wy * Ppad * (MONO ? TROW_MONO : TROW), k, p, s, l, seg_begin, seg_end,
+                                 sp.t0, sp.n, mix, out, out_d, clk);
   if (clk.dst) { // workgroup lifetime: maximum and a histogram in steps of 200 k ticks
     const unsigned long long d = __builtin_readcyclecounter() - wg_t0;
     atomicMax(clk.dst + 39, d);
@@ -604,8 +613,15 @@ void ra_launch_synth_propagate(const RaParams &p, const RaBuffers &b, const RaSp
 }
 void ra_launch_synth_render(const RaParams &p, const RaBuffers &b, const RaSpan &sp, float *d_out, double *d_out_d, hipStream_t st) {
   if (sp.ct1 <= sp.ct0) return;
-  const dim3 grid((unsigned)(sp.nfb + 1), (unsigned)p.n_streams), block((unsigned)p.Ppad);
-  if (p.render_mode) hipLaunchKernelGGL(ra_synth_render_diag_kernel, grid, block, syn_lds_bytes(p.Ppad), st, p, b, sp, d_out, d_out_d);
-  else if (p.stereo_spread == 0.f) hipLaunchKernelGGL(ra_synth_render_mono_kernel, grid, block, (size_t)p.Ppad * TROW_MONO * sizeof(double), st, p, b, sp, d_out, d_out_d);
-  else hipLaunchKernelGGL(ra_synth_render_kernel, grid, block, (size_t)p.Ppad * TROW * sizeof(double), st, p, b, sp, d_out, d_out_d); // the 8-frame tile only
+  if (p.render_mode) {
+    const dim3 grid((unsigned)(sp.nfb + 1), (unsigned)p.n_streams), block((unsigned)p.Ppad);
+    hipLaunchKernelGGL(ra_synth_render_diag_kernel, grid, block, syn_lds_bytes(p.Ppad), st, p, b, sp, d_out, d_out_d);
+    return;
+  }
+  static const int group_env = std::getenv("RA_RENDER_GROUP") ? std::atoi(std::getenv("RA_RENDER_GROUP")) : 1; // tuning aid, see below
+  const unsigned group = (p.Ppad == 64) ? (unsigned)std::min(std::max(group_env, 1), RA_MAX_CHANNELS / 64) : 1u; // hops per workgroup
+  const dim3 grid((unsigned)((sp.nfb + 1 + group - 1) / group), (unsigned)p.n_streams), block((unsigned)p.Ppad, group);
+  const size_t lds = (size_t)group * p.Ppad * (p.stereo_spread == 0.f ? TROW_MONO : TROW) * sizeof(double); // the 8-frame tiles only
+  if (p.stereo_spread == 0.f) hipLaunchKernelGGL(ra_synth_render_mono_kernel, grid, block, lds, st, p, b, sp, d_out, d_out_d);
+  else hipLaunchKernelGGL(ra_synth_render_kernel, grid, block, lds, st, p, b, sp, d_out, d_out_d);
 }
