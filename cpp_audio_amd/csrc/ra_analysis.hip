@@ -149,6 +149,9 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   const int cap = ra_list_capacity(p);                         // harmonize may double a list; otherwise maxr entries suffice
   double2 *listA = z + ra_zpad_size(M);                        // [cap]
   double2 *listB = listA + cap;                                // [cap]
+  double *lds_loud_pitches = reinterpret_cast<double *>(listB + cap); // [29] ISO-226 pitches and, behind them as floats, the 60 phon row:
+  float *lds_loud_elv = reinterpret_cast<float *>(lds_loud_pitches + 29); // [29]   the loudness keys' binary search stays out of global memory
+  if (tid < 29) { lds_loud_pitches[tid] = b.loud_pitches[tid]; lds_loud_elv[tid] = b.loud_elv[tid]; } // visible after the FFT's barriers
   int *scan = reinterpret_cast<int *>(listA);                   // [T+1], aliases listA: consumed (K read) before the lists are written
 
   RaPhaseClock clk(b.dbg_clk, tid == 0);
@@ -180,18 +183,26 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
 
   // ---- 3. split into the real spectrum, |X|^2 written over .x of the same slots -------------------
   // X[k] = E[k] + W^k O[k],  E = (Z[k] + conj Z[M-k]) / 2,  O = -i/2 (Z[k] - conj Z[M-k]);  bins 0..M-1 kept
-  for (int k = tid; k <= (M >> 1); k += T) {
-    int km = (M - k) % M; // partner (k = 0 pairs with itself, k = M/2 too)
-    double2 zk = Z(k), zm = Z(km);
-    auto bin = [&](double2 a, double2 c, int kk) -> double { // a = Z[kk], c = Z[M-kk] (conjugated inside)
-      double2 x = ra_real_split_bin(a, c, b.tw_full[kk]);
+  {
+    auto bin = [&](double2 a, double2 c, double2 w) -> double { // a = Z[kk], c = Z[M-kk] (conjugated inside), w = W^kk
+      double2 x = ra_real_split_bin(a, c, w);
       return x.x * x.x + x.y * x.y;
     };
-    double sk = bin(zk, zm, k);
-    double sm = (km != k) ? bin(zm, zk, km) : 0.0;
-    // the two slots are private to this thread: safe to overwrite now
-    Z(k).x = sk;
-    if (km != k) Z(km).x = sm;
+    const int Mh1 = M >> 1;
+    for (int k0 = tid; k0 <= Mh1; k0 += 2 * T) { // two pairs per trip, their eight loads in flight together
+      const int k1 = k0 + T;
+      const bool has1 = k1 <= Mh1;
+      const int ka = k0, kb = has1 ? k1 : k0;
+      const int kma = (M - ka) % M, kmb = (M - kb) % M; // partner (k = 0 pairs with itself, k = M/2 too)
+      const double2 za = Z(ka), zma = Z(kma), zb = Z(kb), zmb = Z(kmb);
+      const double2 wa = b.tw_full[ka], wma = b.tw_full[kma], wb = b.tw_full[kb], wmb = b.tw_full[kmb];
+      const double sa = bin(za, zma, wa), sma = bin(zma, za, wma);
+      const double sb = bin(zb, zmb, wb), smb = bin(zmb, zb, wmb);
+      // the slots of a pair are private to this thread: safe to overwrite now
+      Z(ka).x = sa;
+      if (kma != ka) Z(kma).x = sma;
+      if (has1) { Z(kb).x = sb; if (kmb != kb) Z(kmb).x = smb; }
+    }
   }
   __syncthreads();
   clk.mark(2);
@@ -246,9 +257,13 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   // ---- 5. aggregate_pitches + reduce_pitches (algo.cpp:124-184, PonderateByVolume / SumVolumes) -------------------
   // Pitches ascend, so an interval opened at peak i0 runs up to the first peak j with pitch[j] - pitch[i0] > nearby:
   //  5a every peak finds that j by binary search (nxt, kept in the now unused .x half of its slot)
-  //  5b one lane follows the nxt chain from peak 0 to list the interval starts (tens to a few hundred hops)
+  //  5b the nxt chain from peak 0 lists the interval starts (tens to a few hundred hops): pointer jumping, ~log2 rounds
   //  5c each interval is summed by one thread in index order (the reference's summation order) and kept if its volume
   //     reaches min_volume; kept intervals are compacted in order with a block scan
+  // pointer jumping needs two ints per peak beside the scan area (all inside the list region, which is idle until 5c)
+  const int area_ints = max(8 * cap, T + 8);
+  int *jump = scan + T + 16, *mark = jump + K;
+  const bool par = K > 0 && K <= 4 * T && T + 16 + 2 * K <= area_ints;
   for (int i = tid; i < K; i += T) {
     const double pi0 = Z(i).y;
     int lo = i + 1, hi = K;
@@ -256,14 +271,43 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
       int mid = (lo + hi) >> 1;
       if (Z(mid).y - pi0 > p.nearby) hi = mid; else lo = mid + 1;
     }
-    Z(i).x = (double)lo;
+    if (par) { jump[i] = lo; mark[i] = (i == 0) ? 1 : 0; } else Z(i).x = (double)lo;
   }
   __syncthreads();
   clk.mark(5);
-  if (tid == 0) {
+  if (par) {
+    // 5b by pointer jumping.  Before round r: jump = nxt^(2^r), and the first 2^r interval starts are marked.  A marked peak marks
+    // where its pointer leads (marks only ever land on interval starts, so marks seen within the same round are harmless), then every
+    // pointer doubles.  Done when 2^(r+1) hops from peak 0 leave the list.
+    while (true) {
+      int jn[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = tid + T * q;
+        if (i < K) {
+          const int j = jump[i];
+          if (j < K) { if (mark[i]) mark[j] = 1; jn[q] = jump[j]; } else jn[q] = K;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int i = tid + T * q; if (i < K) jump[i] = jn[q]; }
+      __syncthreads();
+      if (jump[0] >= K) break; // the same LDS word for every thread: uniform
+    }
+    // the marked peaks, in index order, are the interval starts
+    const int c = (K + T - 1) / T;
+    const int a0 = min(K, tid * c), a1 = min(K, a0 + c);
+    int cntm = 0;
+    for (int i = a0; i < a1; ++i) cntm += mark[i];
+    block_exclusive_scan(scan, cntm, tid);
+    int posm = scan[tid];
+    for (int i = a0; i < a1; ++i) if (mark[i]) Z(Mh + posm++).x = (double)i;
+    if (tid == 0) Z(Mh + scan[T]).x = (double)K; // R <= K <= Mh - 1, so slot Mh + R exists; scan[T] = R stays for 5c
+  } else if (tid == 0) {
     int R = 0;
     for (int i = 0; i < K; i = (int)Z(i).x) Z(Mh + R++).x = (double)i;
-    Z(Mh + R).x = (double)K;   // R <= K <= Mh - 1, so slot Mh + R exists
+    Z(Mh + R).x = (double)K;
     scan[T] = R;
   }
   __syncthreads();
@@ -295,7 +339,7 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   // ---- 6. shift / harmonize / autotune on the reduced list ---------------------------------------------------------
   // The autotune function (divisions, scale / chord searches) is evaluated for all items at once; one lane then runs the
   // order-dependent merge of algo.cpp:191-229 over the precomputed values, and the harmonize steps when they are enabled.
-  int *pub = reinterpret_cast<int *>(z); // [0] = A, [1] = which list holds the result, [2] = Rn, [3] = input list, [4] = err   (z is free now)
+  int *pub = reinterpret_cast<int *>(z); // [0] = A, [1] = which list holds the result, [2] = Rn, [3] = input list, [4] = err, [5] = merge fallback, [6] = kept   (z is free now)
   if (tid == 0) {
     int err = Rk > cap ? 1 : 0;
     int Rn = min(Rk, cap);
@@ -325,33 +369,78 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
     }
   }
   __syncthreads();
-  if (tid == 0) {
-    int err = pub[4];
+  // The merge half: consecutive kept items whose autotuned pitch lies within 1e-4 of the run's first one pool their volumes
+  // (algo.cpp:211-226).  In parallel: compact the kept items, flag run starts by comparing neighbours, sum every run from its start in
+  // index order.  That equals the sequential rule whenever pitches do not descend and neighbours closer than 1e-4 are equal (autotuned
+  // pitches are table values; untuned neighbours are > nearby apart); anything else falls back to the one-lane loop.
+  {
+    int *mscan = reinterpret_cast<int *>(z) + 16; // block scan area in the idle FFT buffer (the lists are live here)
     const int Rn = pub[2];
     double2 *cur = pub[3] ? listB : listA, *oth = pub[3] ? listA : listB;
-    // the merge half: equal (within 1e-4) consecutive autotuned pitches pool their volumes.  Output overwrites cur (A <= i).
-    int A = 0;
-    double2 last = make_double2(0.0, 0.0);
-    bool have = false;
-    for (int i0 = 0; i0 < Rn; i0 += 4) {
-      double2 e[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) e[q] = (i0 + q < Rn) ? oth[i0 + q] : make_double2(0.0, -1.0);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (!(e[q].y >= 0.0)) continue;
-        if (have && fabs(last.x - e[q].x) < (double)0.0001f) last.y += e[q].y;
-        else { if (have) cur[A++] = last; last = e[q]; have = true; }
+    const bool parm = Rn <= 4 * T;
+    int A_par = 0;
+    if (parm) {
+      const int c = (Rn + T - 1) / T;
+      const int a0 = min(Rn, tid * c), a1 = min(Rn, a0 + c);
+      int cntk = 0;
+      for (int i = a0; i < a1; ++i) cntk += (oth[i].y >= 0.0) ? 1 : 0;
+      block_exclusive_scan(mscan, cntk, tid);
+      int pk = mscan[tid];
+      const int nk = mscan[T];
+      for (int i = a0; i < a1; ++i) { const double2 e = oth[i]; if (e.y >= 0.0) cur[pk++] = e; } // cur was consumed before the barrier above
+      if (tid == 0) { pub[5] = 0; pub[6] = nk; }
+      __syncthreads();
+      const int c2 = (nk + T - 1) / T;
+      const int b0 = min(nk, tid * c2), b1 = min(nk, b0 + c2);
+      int cntb = 0;
+      bool bad = false;
+      for (int j = b0; j < b1; ++j) {
+        if (j == 0) { ++cntb; continue; }
+        const double tp = cur[j - 1].x, tj = cur[j].x;
+        const bool joins = fabs(tp - tj) < (double)0.0001f;
+        if (!joins) ++cntb;
+        if (tj < tp || (joins && tj != tp)) bad = true;
       }
+      if (bad) atomicOr(&pub[5], 1);
+      block_exclusive_scan(mscan, cntb, tid); // its barriers also publish pub[5]
+      if (!pub[5]) {
+        int pb = mscan[tid];
+        A_par = mscan[T];
+        for (int j = b0; j < b1; ++j) {
+          if (j > 0 && fabs(cur[j - 1].x - cur[j].x) < (double)0.0001f) continue; // not a run start
+          double2 e = cur[j];
+          for (int q = j + 1; q < nk && fabs(cur[q - 1].x - cur[q].x) < (double)0.0001f; ++q) e.y += cur[q].y;
+          oth[pb++] = e; // the per-item results in oth are dead on this path
+        }
+      }
+      __syncthreads();
     }
-    if (have) cur[A++] = last;
-    shift_list(cur, A, p.shift_post);
-    A = harmonize_list(cur, oth, A, cap, p.harm_post, &err);
-    if (A > p.maxr) { err = 1; A = p.maxr; }
-    if (err) atomicOr(b.error_flags, RA_ERR_OVERFLOW);
-    pub[0] = A;
-    pub[1] = (cur == listA) ? 0 : 1;
-    b.pl_count[(size_t)s * b.frames_cap + fb] = A;
+    if (tid == 0) {
+      int err = pub[4];
+      int A = 0;
+      double2 *res = cur, *spare = oth;
+      if (parm && !pub[5]) { A = A_par; res = oth; spare = cur; }
+      else { // one lane, in order; the output overwrites cur (A <= i)
+        double2 last = make_double2(0.0, 0.0);
+        bool have = false;
+        const double2 *src = parm ? cur : oth;   // parm: already compacted into cur (all kept); else the per-item results
+        const int ns = parm ? pub[6] : Rn;
+        for (int i = 0; i < ns; ++i) {
+          const double2 e = src[i];
+          if (!(e.y >= 0.0)) continue;
+          if (have && fabs(last.x - e.x) < (double)0.0001f) last.y += e.y;
+          else { if (have) cur[A++] = last; last = e; have = true; }
+        }
+        if (have) cur[A++] = last;
+      }
+      shift_list(res, A, p.shift_post);
+      A = harmonize_list(res, spare, A, cap, p.harm_post, &err);
+      if (A > p.maxr) { err = 1; A = p.maxr; }
+      if (err) atomicOr(b.error_flags, RA_ERR_OVERFLOW);
+      pub[0] = A;
+      pub[1] = (res == listA) ? 0 : 1;
+      b.pl_count[(size_t)s * b.frames_cap + fb] = A;
+    }
   }
   __syncthreads();
   clk.mark(8);
@@ -364,7 +453,7 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
       b.pl_pitch[base + i] = pv.x;
       b.pl_vol[base + i] = pv.y;
       // order_pitches_by_perceived_loudness key, lib.cpp:1717-1727 (a float vector, algo.cpp:380-395)
-      b.pl_key[base + i] = (float)(pv.y / (double)equal_loudness_db(b.loud_pitches, b.loud_elv, pv.x));
+      b.pl_key[base + i] = (float)(pv.y / (double)equal_loudness_db(lds_loud_pitches, lds_loud_elv, pv.x));
     }
   }
   clk.mark(9);
@@ -398,7 +487,7 @@ size_t ra_analysis_lds_bytes(const RaParams &p) {
   size_t m = (size_t)ra_zpad_size(p.M);
   size_t lists = 2 * (size_t)ra_list_capacity(p) * sizeof(double2);
   size_t scan = (RA_ANALYSIS_THREADS + 8) * sizeof(int);
-  return m * sizeof(double2) + (lists > scan ? lists : scan);
+  return m * sizeof(double2) + (lists > scan ? lists : scan) + 29 * (sizeof(double) + sizeof(float)) + 12;
 }
 
 void ra_launch_analysis(const RaParams &p, const RaBuffers &b, const float *d_voice, int64_t t0, int64_t n, int64_t f_lo, int64_t fb0, int64_t nfb_chunk,
