@@ -155,6 +155,15 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   int *scan = reinterpret_cast<int *>(listA);                   // [T+1], aliases listA: consumed (K read) before the lists are written
 
   RaPhaseClock clk(b.dbg_clk, tid == 0);
+  // twiddles W^k, W^(M-k) of the real-spectrum split (step 3) for the pairs k0, k0 + T: fetched one trip ahead, the first trip's before the FFT
+  double2 sw[4] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
+  auto split_twiddles = [&](int k0) {
+    const int Mh1 = M >> 1;
+    if (k0 > Mh1) return;
+    const int k1 = k0 + T, kb = (k1 <= Mh1) ? k1 : k0;
+    sw[0] = b.tw_full[k0]; sw[1] = b.tw_full[(M - k0) % M]; sw[2] = b.tw_full[kb]; sw[3] = b.tw_full[(M - kb) % M];
+  };
+  split_twiddles(tid);
   // ---- 1 + 2. weighted window -> M point complex FFT of the packed sequence (x[2k], x[2k+1]) ------------------------
   // the first fused pass reads its (bit-reversed) inputs straight from HBM/L2: the window is 4 N bytes, touched once
   {
@@ -189,13 +198,14 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
       return x.x * x.x + x.y * x.y;
     };
     const int Mh1 = M >> 1;
-    for (int k0 = tid; k0 <= Mh1; k0 += 2 * T) { // two pairs per trip, their eight loads in flight together
+    for (int k0 = tid; k0 <= Mh1; k0 += 2 * T) { // two pairs per trip, their loads in flight together; the twiddles were fetched a trip ahead
       const int k1 = k0 + T;
       const bool has1 = k1 <= Mh1;
       const int ka = k0, kb = has1 ? k1 : k0;
       const int kma = (M - ka) % M, kmb = (M - kb) % M; // partner (k = 0 pairs with itself, k = M/2 too)
       const double2 za = Z(ka), zma = Z(kma), zb = Z(kb), zmb = Z(kmb);
-      const double2 wa = b.tw_full[ka], wma = b.tw_full[kma], wb = b.tw_full[kb], wmb = b.tw_full[kmb];
+      const double2 wa = sw[0], wma = sw[1], wb = sw[2], wmb = sw[3];
+      split_twiddles(k0 + 2 * T);
       const double sa = bin(za, zma, wa), sma = bin(zma, za, wma);
       const double sb = bin(zb, zmb, wb), smb = bin(zmb, zb, wmb);
       // the slots of a pair are private to this thread: safe to overwrite now
@@ -377,9 +387,35 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
     int *mscan = reinterpret_cast<int *>(z) + 16; // block scan area in the idle FFT buffer (the lists are live here)
     const int Rn = pub[2];
     double2 *cur = pub[3] ? listB : listA, *oth = pub[3] ? listA : listB;
-    const bool parm = Rn <= 4 * T;
+    const bool parm = Rn <= 4 * T, wave_local = Rn <= 64;
     int A_par = 0;
-    if (parm) {
+    if (wave_local) {
+      // the usual case (tens of items): wave 0 alone, one item per lane, ballots instead of block scans, no barriers
+      // (a wave's LDS operations execute in order)
+      if (tid < 64) {
+        const unsigned long long lower = (tid == 0) ? 0ull : (~0ull >> (64 - tid));
+        const double2 e0 = (tid < Rn) ? oth[tid] : make_double2(0.0, -1.0);
+        const bool keep = e0.y >= 0.0;
+        const unsigned long long km = __ballot(keep);
+        const int nk = __popcll(km);
+        if (keep) cur[__popcll(km & lower)] = e0;
+        const bool in = tid < nk;
+        const double tj = in ? cur[tid].x : 0.0, tp = (in && tid > 0) ? cur[tid - 1].x : 0.0;
+        const bool joins = in && tid > 0 && fabs(tp - tj) < (double)0.0001f;
+        const bool bad = in && tid > 0 && (tj < tp || (joins && tj != tp));
+        const unsigned long long sm = __ballot(in && !joins);
+        const bool any_bad = __ballot(bad) != 0ull;
+        if (tid == 0) { pub[5] = any_bad ? 1 : 0; pub[6] = nk; }
+        if (!any_bad) {
+          A_par = __popcll(sm);
+          if (in && !joins) {
+            double2 e = cur[tid];
+            for (int q = tid + 1; q < nk && !((sm >> q) & 1ull); ++q) e.y += cur[q].y;
+            oth[__popcll(sm & lower)] = e; // the per-item results in oth are dead on this path (all read above)
+          }
+        }
+      }
+    } else if (parm) {
       const int c = (Rn + T - 1) / T;
       const int a0 = min(Rn, tid * c), a1 = min(Rn, a0 + c);
       int cntk = 0;

@@ -76,6 +76,47 @@ __device__ inline void ra_fft_pass(double2 *z, int M, int log2M, int log2h, cons
   __syncthreads();
 }
 
+// ---- the same passes with the twiddle loads of pass n + 1 issued before pass n computes (one group per thread) -----------------------
+// The twiddles of a pass depend only on the thread's group index, so their (L2) latency can hide behind the previous pass instead of
+// sitting between two barriers.
+template <int S>
+__device__ inline void ra_fft_load_tw(double2 (&w)[8], int M, int log2M, int log2h, const double2 *__restrict__ tw_half, int g) {
+  const int h = 1 << log2h, r = g & (h - 1);
+  if (g >= (M >> S)) return;
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+#pragma unroll
+    for (int q = 0; q < (1 << s); ++q) w[(1 << s) - 1 + q] = tw_half[(r + q * h) << (log2M - 1 - s - log2h)];
+  }
+}
+template <int S>
+__device__ inline void ra_fft_pass_w(double2 *z, int M, int log2h, int g, const double2 (&w)[8]) {
+  constexpr int R = 1 << S;
+  const int h = 1 << log2h;
+  if (g < (M >> S)) {
+    const int r = g & (h - 1), base = ((g - r) << S) + r;
+    double2 x[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) x[k] = z[ra_zpad(base + k * h)];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        if (k & (1 << s)) continue;
+        const double2 ww = w[(1 << s) - 1 + (k & ((1 << s) - 1))];
+        const double2 u = x[k], y = x[k | (1 << s)];
+        const double vr = y.x * ww.x - y.y * ww.y;
+        const double vi = y.x * ww.y + y.y * ww.x;
+        x[k] = make_double2(u.x + vr, u.y + vi);
+        x[k | (1 << s)] = make_double2(u.x - vr, u.y - vi);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) z[ra_zpad(base + k * h)] = x[k];
+  }
+  __syncthreads();
+}
+
 // forward transform of the packed sequence load(0..M-1) into z (ra_zpad indexing), M = 1 << log2M
 template <typename LoadFn>
 __device__ inline void ra_fft_fused(double2 *z, int M, int log2M, const double2 *__restrict__ tw_half, int tid, int T, LoadFn load) {
@@ -84,6 +125,30 @@ __device__ inline void ra_fft_fused(double2 *z, int M, int log2M, const double2 
   if (log2M == 0) {
     if (tid == 0) z[0] = load(0);
     __syncthreads();
+    return;
+  }
+  if (log2M >= 3 && (M >> 3) <= T) { // one group per thread in every pass: software-pipelined twiddles
+    double2 wn[8], w[8];
+    done = 3;
+    int Sn = min(3, log2M - done);
+    if (Sn == 3) ra_fft_load_tw<3>(wn, M, log2M, done, tw_half, tid);
+    else if (Sn == 2) ra_fft_load_tw<2>(wn, M, log2M, done, tw_half, tid);
+    else if (Sn == 1) ra_fft_load_tw<1>(wn, M, log2M, done, tw_half, tid);
+    ra_fft_pass<3, true>(z, M, log2M, 0, tw_half, tid, T, load);
+    while (done < log2M) {
+      const int S = Sn, next = done + S;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) w[q] = wn[q];
+      Sn = min(3, log2M - next);
+      if (Sn == 3) ra_fft_load_tw<3>(wn, M, log2M, next, tw_half, tid);
+      else if (Sn == 2) ra_fft_load_tw<2>(wn, M, log2M, next, tw_half, tid);
+      else if (Sn == 1) ra_fft_load_tw<1>(wn, M, log2M, next, tw_half, tid);
+      // a final pass of fewer than 3 stages has more groups than threads: it takes the generic pass (twiddles loaded inside)
+      if (S == 3) ra_fft_pass_w<3>(z, M, done, tid, w);
+      else if (S == 2) { if ((M >> 2) <= T) ra_fft_pass_w<2>(z, M, done, tid, w); else ra_fft_pass<2, false>(z, M, log2M, done, tw_half, tid, T, none); }
+      else { if ((M >> 1) <= T) ra_fft_pass_w<1>(z, M, done, tid, w); else ra_fft_pass<1, false>(z, M, log2M, done, tw_half, tid, T, none); }
+      done = next;
+    }
     return;
   }
   if (log2M >= 3) { ra_fft_pass<3, true>(z, M, log2M, 0, tw_half, tid, T, load); done = 3; }
