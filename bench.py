@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--stride", type=int, default=1024)
     ap.add_argument("--partials", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stream-ordered", action="store_true", help="issue every block with ra_process_device (no overlap between consecutive blocks)")
     ap.add_argument("--cpu-streams", type=int, default=0, help="streams in the CPU baseline sample (0 = all)")
     args = ap.parse_args()
 
@@ -155,17 +156,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Steps are consecutive blocks of the same streams.  They are issued like an offline job issues them (ra_process_device_async): the
+    # caller's stream is not made to wait between blocks, so block k + 1's analysis and tracking overlap block k's rendering; every block
+    # still does all of its work inside the timed region, which ends with a join + device synchronisation.  --stream-ordered issues each
+    # block with ra_process_device instead (the stream waits for every block: nothing of block k + 1 starts before block k is done).
     def step():
-        ctx.process_device(voice.data_ptr(), 0, n, out.data_ptr())
+        ctx.process_device(voice.data_ptr(), 0, n, out.data_ptr(), overlap=not args.stream_ordered)
 
     for _ in range(args.warmup):
         step()
+    ctx.join()
     ctx.synchronize()
     ctx.set_profiling(True)   # HIP events on the launch stream around every kernel (ra_set_profiling)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    ctx.join()
     barrier()
     dt = time.perf_counter() - t0
     ctx.synchronize()         # raises on device-side error flags
@@ -212,7 +219,7 @@ def main():
             "metric": "audio frames/sec (48 kHz, 4096-pt FFT, 64 partials) per GPU; CPU ref x",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic", "issue": "stream-ordered" if args.stream_ordered else "overlapped blocks (ra_process_device_async)",
             "config": {"workload": f"configs[1]: {S} mono streams/GPU x {args.seconds:g} s @ 48 kHz, window {N} (Gaussian 4 sigma) / FFT {N}, "
                                    f"stride {H} (75% overlap), {P} partials, analysis_volume 1, stereo_spread 0, post none",
                        "streams_per_gpu": S, "frames_per_stream_per_step": n, "sharding": f"streams x{world}, no collective"},

@@ -61,7 +61,8 @@ EVENT_DTYPE = np.dtype([("sample", "<i8"), ("type", "<i4"), ("channel", "<i4"), 
 # every symbol include/resynth_amd.h declares
 EXPORTED_SYMBOLS = [
     "ra_last_error", "ra_device_count", "ra_default_config", "ra_even_window_size_frames", "ra_window_center_stride_frames",
-    "ra_create", "ra_destroy", "ra_reset", "ra_set_hip_stream", "ra_process_device", "ra_process_host", "ra_synchronize",
+    "ra_create", "ra_destroy", "ra_reset", "ra_set_hip_stream", "ra_process_device", "ra_process_device_async", "ra_join", "ra_process_host",
+    "ra_synchronize",
     "ra_feed", "ra_compute", "ra_get_stats", "ra_get_events", "ra_get_frame_pitches", "ra_resynth_notes", "ra_sqmag",
     "ra_set_profiling", "ra_get_kernel_ms", "ra_get_kernel_launches", "ra_render_note",
 ]
@@ -83,6 +84,8 @@ def lib():
         L.ra_reset.argtypes = [C.c_void_p]
         L.ra_set_hip_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.ra_process_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.ra_process_device_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.ra_join.argtypes = [C.c_void_p]
         L.ra_process_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.ra_synchronize.argtypes = [C.c_void_p]
         L.ra_feed.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
@@ -167,9 +170,16 @@ class Context:
         _check(lib().ra_process_host(self._h, _p(v), _p(c), n, _p(out)))
         return out
 
-    def process_device(self, d_voice, d_carrier, n_frames, d_out):
-        """Raw device pointers (ints). Asynchronous; call synchronize()."""
-        _check(lib().ra_process_device(self._h, C.c_void_p(d_voice or 0), C.c_void_p(d_carrier or 0), int(n_frames), C.c_void_p(d_out)))
+    def process_device(self, d_voice, d_carrier, n_frames, d_out, overlap=False):
+        """Raw device pointers (ints), ordered on the context's stream; call synchronize() before reading on the host.
+        overlap=True (ra_process_device_async): the stream is not made to wait for the block, so the next block's analysis overlaps
+        this block's rendering; the output may only be read after join() / synchronize()."""
+        f = lib().ra_process_device_async if overlap else lib().ra_process_device
+        _check(f(self._h, C.c_void_p(d_voice or 0), C.c_void_p(d_carrier or 0), int(n_frames), C.c_void_p(d_out)))
+
+    def join(self):
+        """Makes the context's stream wait for every block issued so far (no host synchronisation)."""
+        _check(lib().ra_join(self._h))
 
     def synchronize(self):
         _check(lib().ra_synchronize(self._h))

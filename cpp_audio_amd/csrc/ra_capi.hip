@@ -49,6 +49,18 @@ struct ra_context {
   hipStream_t pipe_stream[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_voc = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_chunk[3][12] = {};
+  // Per-block scratch (pitch lists, commands, hop states) exists twice: block k + 1 may run its analysis / tracking / propagation while
+  // block k is still rendering (ra_process_device_async).  A set is reused two blocks later; the events say when its last readers are done.
+  struct Scratch {
+    int64_t frames_cap = 0, seg_cap = 0;
+    double *pl_pitch = nullptr, *pl_vol = nullptr; float *pl_key = nullptr; int32_t *pl_count = nullptr;
+    RaCmd *cmd = nullptr; int32_t *cmd_non = nullptr;
+    double *seg_sd = nullptr; int32_t *seg_si = nullptr;
+    hipEvent_t ev_track_done = nullptr, ev_prop_done = nullptr, ev_render_done = nullptr;
+    bool used = false;
+  } scr[2];
+  int parity = 0;
+  bool pending_join = false; // asynchronous blocks are in flight on the internal streams; the caller's stream has not been made to wait yet
 };
 
 namespace {
@@ -428,27 +440,32 @@ int init_state(ra_context *c) {
 int ensure_scratch(ra_context *c, int64_t nfb, int64_t n, int n_chunks) {
   RaParams &p = c->p;
   RaBuffers &b = c->b;
+  ra_context::Scratch &sc = c->scr[c->parity];
   int r;
-  if (nfb > b.frames_cap) {
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    dev_free(c, b.pl_pitch); dev_free(c, b.pl_vol); dev_free(c, b.pl_key); dev_free(c, b.pl_count); dev_free(c, b.cmd); dev_free(c, b.cmd_non);
+  if (nfb > sc.frames_cap) {
+    HIP_TRY(hipDeviceSynchronize()); // rare (first block, or a longer block than ever before): nothing may still read the old buffers
+    dev_free(c, sc.pl_pitch); dev_free(c, sc.pl_vol); dev_free(c, sc.pl_key); dev_free(c, sc.pl_count); dev_free(c, sc.cmd); dev_free(c, sc.cmd_non);
     size_t S = p.n_streams, F = static_cast<size_t>(nfb);
-    b.frames_cap = nfb;
-    if ((r = dev_alloc(c, &b.pl_pitch, S * F * p.maxr, false))) return r;
-    if ((r = dev_alloc(c, &b.pl_vol, S * F * p.maxr, false))) return r;
-    if ((r = dev_alloc(c, &b.pl_key, S * F * p.maxr, false))) return r;
-    if ((r = dev_alloc(c, &b.pl_count, S * F))) return r;
-    if ((r = dev_alloc(c, &b.cmd, S * F * p.Ppad, false))) return r;
-    if ((r = dev_alloc(c, &b.cmd_non, S * F))) return r;
+    sc.frames_cap = nfb;
+    if ((r = dev_alloc(c, &sc.pl_pitch, S * F * p.maxr, false))) return r;
+    if ((r = dev_alloc(c, &sc.pl_vol, S * F * p.maxr, false))) return r;
+    if ((r = dev_alloc(c, &sc.pl_key, S * F * p.maxr, false))) return r;
+    if ((r = dev_alloc(c, &sc.pl_count, S * F))) return r;
+    if ((r = dev_alloc(c, &sc.cmd, S * F * p.Ppad, false))) return r;
+    if ((r = dev_alloc(c, &sc.cmd_non, S * F))) return r;
+    HIP_TRY(hipStreamSynchronize(c->stream)); // the zero fills above ran on the caller's stream
   }
-  if (c->cfg.reference_order != 1 && nfb + n_chunks > b.seg_cap) {
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    dev_free(c, b.seg_sd); dev_free(c, b.seg_si);
+  if (c->cfg.reference_order != 1 && nfb + n_chunks > sc.seg_cap) {
+    HIP_TRY(hipDeviceSynchronize());
+    dev_free(c, sc.seg_sd); dev_free(c, sc.seg_si);
     size_t S = p.n_streams, G = static_cast<size_t>(nfb + kMaxChunks);
-    b.seg_cap = nfb + kMaxChunks;
-    if ((r = dev_alloc(c, &b.seg_sd, S * G * SD_COUNT * p.Ppad, false))) return r;
-    if ((r = dev_alloc(c, &b.seg_si, S * G * SI_COUNT * p.Ppad, false))) return r;
+    sc.seg_cap = nfb + kMaxChunks;
+    if ((r = dev_alloc(c, &sc.seg_sd, S * G * SD_COUNT * p.Ppad, false))) return r;
+    if ((r = dev_alloc(c, &sc.seg_si, S * G * SI_COUNT * p.Ppad, false))) return r;
   }
+  b.frames_cap = sc.frames_cap; b.seg_cap = sc.seg_cap;
+  b.pl_pitch = sc.pl_pitch; b.pl_vol = sc.pl_vol; b.pl_key = sc.pl_key; b.pl_count = sc.pl_count;
+  b.cmd = sc.cmd; b.cmd_non = sc.cmd_non; b.seg_sd = sc.seg_sd; b.seg_si = sc.seg_si;
   if (p.voc_enabled) {
     size_t S = p.n_streams;
     if (n > b.mix_cap) {
@@ -498,7 +515,6 @@ int resolve_timing(ra_context *c) {
     c->ev_pool.push_back(t.a);
     c->ev_pool.push_back(t.b);
   }
-  if (!c->timed.empty()) ++c->kernel_calls;
   c->timed.clear();
   return RA_OK;
 }
@@ -515,6 +531,18 @@ int timed_launch(ra_context *c, int stage, hipStream_t st, F &&launch) {
   launch();
   HIP_TRY(hipEventRecord(ev[1], st));
   c->timed.push_back({stage, ev[0], ev[1]});
+  if (c->timed.size() > 8192) return resolve_timing(c); // bounds the event pool when nobody reads the timers (waits for those launches)
+  return RA_OK;
+}
+
+// makes the caller's stream wait for everything the internal streams still hold (asynchronous blocks); no host synchronisation
+int join_streams(ra_context *c) {
+  if (!c->pending_join || !c->pipe_ready) { c->pending_join = false; return RA_OK; }
+  for (int i = 0; i < 4; ++i) {
+    HIP_TRY(hipEventRecord(c->ev_join[i], c->pipe_stream[i]));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join[i], 0));
+  }
+  c->pending_join = false;
   return RA_OK;
 }
 
@@ -522,7 +550,7 @@ int timed_launch(ra_context *c, int stage, hipStream_t st, F &&launch) {
 // streams chained by events.  Tracking and propagation are dependency chains over frames that occupy a few hundred
 // wavefronts; cutting the block lets the throughput kernels (analysis of later chunks, render of earlier ones) fill the
 // rest of the chip meanwhile.  Results do not depend on the cut (each chunk continues the carried state exactly).
-int process_block(ra_context *c, const float *d_voice, const float *d_carrier, int64_t n, float *d_out, double *d_out_d) {
+int process_block(ra_context *c, const float *d_voice, const float *d_carrier, int64_t n, float *d_out, double *d_out_d, bool async = false) {
   if (n <= 0) return RA_OK;
   HIP_TRY(hipSetDevice(c->device));
   RaParams &p = c->p;
@@ -533,11 +561,15 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
   if (c->cfg.reference_order != 1 && nfb >= 64) n_chunks = static_cast<int>(std::min<int64_t>(kMaxChunks, nfb / 48 + 2));
   static const int forced_chunks = std::getenv("RA_PIPELINE_CHUNKS") ? std::atoi(std::getenv("RA_PIPELINE_CHUNKS")) : 0; // tuning aid
   if (forced_chunks > 0 && c->cfg.reference_order != 1 && nfb >= forced_chunks) n_chunks = std::min(forced_chunks, kMaxChunks);
-  int r = ensure_scratch(c, nfb, n, n_chunks);
-  if (r) return r;
+  // blocks that cannot overlap their predecessor: single-chunk / reference-order blocks (they run on the caller's stream) and the vocoder
+  // (its histories are rolled on the render stream): they first wait for whatever is still in flight
+  int r;
+  if (n_chunks == 1 || p.voc_enabled) { if ((r = join_streams(c))) return r; async = false; }
+  c->parity ^= 1;
+  if ((r = ensure_scratch(c, nfb, n, n_chunks))) return r;
+  ra_context::Scratch &sc = c->scr[c->parity];
   c->b.dbg_sqmag = c->dbg_sqmag;
   c->b.dbg_clk = c->dbg_clk;
-  if (c->profiling && (r = resolve_timing(c))) return r;
   const RaBuffers &b = c->b;
   hipStream_t user = c->stream;
 
@@ -578,8 +610,20 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
     if (prio_mode == 0) sA = user;
     static const bool one_queue = std::getenv("RA_PIPELINE_SERIAL") != nullptr; // tuning aid: same chunks, no overlap
     if (one_queue) sA = sT = sP = sR = user;
+    if (sA == user) { if ((r = join_streams(c))) return r; async = false; } // tuning modes that use the caller's stream cannot overlap blocks
     HIP_TRY(hipEventRecord(c->ev_fork, user));
     for (int i = 0; i < 4; ++i) HIP_TRY(hipStreamWaitEvent(c->pipe_stream[i], c->ev_fork, 0));
+    // this scratch set was last used two blocks ago: its writers here wait for its readers there (normally long done)
+    if (!sc.ev_track_done) {
+      HIP_TRY(hipEventCreateWithFlags(&sc.ev_track_done, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&sc.ev_prop_done, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&sc.ev_render_done, hipEventDisableTiming));
+    }
+    if (sc.used) {
+      HIP_TRY(hipStreamWaitEvent(sA, sc.ev_track_done, 0));  // analysis rewrites the pitch lists tracking read
+      HIP_TRY(hipStreamWaitEvent(sT, sc.ev_prop_done, 0));   // tracking rewrites the commands propagation read
+      HIP_TRY(hipStreamWaitEvent(sP, sc.ev_render_done, 0)); // propagation rewrites the hop states the render read
+    }
     if (p.voc_enabled) { // independent of the analysis chain: runs beside it, only the render waits for the mix
       timed_launch(c, ST_VOCODER, sR, [&] { ra_launch_vocoder(p, b, d_voice, d_carrier, t0, n, sR); });
     }
@@ -641,13 +685,18 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
       HIP_TRY(hipStreamWaitEvent(sR, c->ev_chunk[2][i], 0));
       timed_launch(c, ST_RENDER, sR, [&] { ra_launch_synth_render(p, b, sp, d_out, d_out_d, sR); });
     }
-    for (int i = 0; i < 4; ++i) {
-      HIP_TRY(hipEventRecord(c->ev_join[i], c->pipe_stream[i]));
-      HIP_TRY(hipStreamWaitEvent(user, c->ev_join[i], 0));
-    }
+    // the window history for the next block: after this block's last analysis read of it, before the next block's first (same stream)
+    timed_launch(c, ST_HISTORY, sA, [&] { ra_launch_roll_history(p, b, d_voice, n, sA); });
+    HIP_TRY(hipEventRecord(sc.ev_track_done, sT));
+    HIP_TRY(hipEventRecord(sc.ev_prop_done, sP));
+    HIP_TRY(hipEventRecord(sc.ev_render_done, sR));
+    sc.used = true;
+    c->pending_join = true;
+    if (!async && (r = join_streams(c))) return r;
   }
-  timed_launch(c, ST_HISTORY, user, [&] { ra_launch_roll_history(p, b, d_voice, n, user); });
+  if (n_chunks == 1) timed_launch(c, ST_HISTORY, user, [&] { ra_launch_roll_history(p, b, d_voice, n, user); });
   HIP_TRY(hipGetLastError());
+  if (c->profiling) ++c->kernel_calls;
   c->last_f_lo = f_lo; c->last_nfb = nfb; c->last_n = n; c->last_t0 = t0;
   c->t += n;
   c->frames_fired += nfb;
@@ -750,7 +799,7 @@ int ra_create(const ra_config *cfg, int32_t n_streams, int32_t device, ra_contex
 void ra_destroy(ra_context *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
+  (void)hipDeviceSynchronize(); // asynchronous blocks may still be running on the internal streams
   if (c->dbg_clk) { // tuning aid: ticks of the 100 MHz s_memtime counter per kernel phase, summed over workgroups
     unsigned long long h[64];
     if (hipMemcpy(h, c->dbg_clk, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -768,18 +817,21 @@ void ra_destroy(ra_context *c) {
     for (auto e : c->ev_join) (void)hipEventDestroy(e);
     for (auto &row : c->ev_chunk) for (auto e : row) if (e) (void)hipEventDestroy(e);
   }
+  for (auto &sc : c->scr) for (hipEvent_t e : {sc.ev_track_done, sc.ev_prop_done, sc.ev_render_done}) if (e) (void)hipEventDestroy(e);
   delete c;
 }
 
 int ra_reset(ra_context *c) {
   if (!c) return fail(RA_EINVAL, "null context");
   HIP_TRY(hipSetDevice(c->device));
+  { int jr = join_streams(c); if (jr) return jr; }
   return init_state(c);
 }
 
 int ra_set_hip_stream(ra_context *c, void *hip_stream) {
   if (!c) return fail(RA_EINVAL, "null context");
   HIP_TRY(hipSetDevice(c->device));
+  { int jr = join_streams(c); if (jr) return jr; }
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->stream = static_cast<hipStream_t>(hip_stream);
   return RA_OK;
@@ -822,9 +874,23 @@ int ra_process_device(ra_context *c, const float *d_voice, const float *d_carrie
   return process_block(c, d_voice, d_carrier, n_frames, d_out, nullptr);
 }
 
+int ra_process_device_async(ra_context *c, const float *d_voice, const float *d_carrier, int64_t n_frames, float *d_out) {
+  if (!c) return fail(RA_EINVAL, "null context");
+  if (n_frames < 0) return fail(RA_EINVAL, "n_frames < 0");
+  if (!d_out && n_frames > 0) return fail(RA_EINVAL, "null output");
+  return process_block(c, d_voice, d_carrier, n_frames, d_out, nullptr, true);
+}
+
+int ra_join(ra_context *c) {
+  if (!c) return fail(RA_EINVAL, "null context");
+  HIP_TRY(hipSetDevice(c->device));
+  return join_streams(c);
+}
+
 int ra_synchronize(ra_context *c) {
   if (!c) return fail(RA_EINVAL, "null context");
   HIP_TRY(hipSetDevice(c->device));
+  { int jr = join_streams(c); if (jr) return jr; }
   HIP_TRY(hipStreamSynchronize(c->stream));
   int32_t flags = 0;
   HIP_TRY(hipMemcpy(&flags, c->b.error_flags, sizeof(flags), hipMemcpyDeviceToHost));
@@ -839,6 +905,7 @@ int ra_process_host(ra_context *c, const float *h_voice, const float *h_carrier,
   if (n == 0) return RA_OK;
   if (!h_out) return fail(RA_EINVAL, "null output");
   HIP_TRY(hipSetDevice(c->device));
+  { int jr = join_streams(c); if (jr) return jr; }
   int r = ensure_staging(c, n);
   if (r) return r;
   size_t S = c->p.n_streams;
@@ -887,6 +954,7 @@ int ra_compute(ra_context *c, int32_t stream, double *h_buffer, int32_t n) {
 int ra_get_stats(ra_context *c, ra_stats *st) {
   if (!c || !st) return fail(RA_EINVAL, "null argument");
   HIP_TRY(hipSetDevice(c->device));
+  { int jr = join_streams(c); if (jr) return jr; }
   HIP_TRY(hipStreamSynchronize(c->stream));
   std::vector<RaTrackState> ts(c->p.n_streams);
   HIP_TRY(hipMemcpy(ts.data(), c->b.track, ts.size() * sizeof(RaTrackState), hipMemcpyDeviceToHost));
@@ -902,6 +970,7 @@ int64_t ra_get_events(ra_context *c, int32_t stream, ra_event *h_events, int64_t
   if (!c) return fail(RA_EINVAL, "null context");
   if (stream < 0 || stream >= c->p.n_streams) return fail(RA_EINVAL, "stream out of range");
   HIP_TRY(hipSetDevice(c->device));
+  { int jr = join_streams(c); if (jr) return jr; }
   HIP_TRY(hipStreamSynchronize(c->stream));
   const RaParams &p = c->p;
   int64_t nfb = c->last_nfb;
@@ -940,6 +1009,7 @@ int64_t ra_get_frame_pitches(ra_context *c, int32_t stream, int64_t *h_fire, int
   if (!c) return fail(RA_EINVAL, "null context");
   if (stream < 0 || stream >= c->p.n_streams) return fail(RA_EINVAL, "stream out of range");
   HIP_TRY(hipSetDevice(c->device));
+  { int jr = join_streams(c); if (jr) return jr; }
   HIP_TRY(hipStreamSynchronize(c->stream));
   const RaParams &p = c->p;
   int64_t nfb = c->last_nfb;

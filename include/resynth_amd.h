@@ -153,6 +153,17 @@ int ra_process_host(ra_context *ctx, const float *h_voice, const float *h_carrie
 int ra_synchronize(ra_context *ctx);
 
 /*
+ * Streaming variant for back-to-back blocks: like ra_process_device, but the caller's stream is NOT made to wait for the block.
+ * The next block's analysis / tracking / state propagation then overlap this block's rendering (per-block scratch exists twice; every
+ * stage still runs its blocks in order, so results are identical to the synchronous calls).  Contract: inputs stay untouched and
+ * `d_out` is not read until ra_join (which makes the caller's stream wait for all blocks issued so far, without blocking the host)
+ * or ra_synchronize.  Every other entry point joins first.  This is how an offline job (the reference's block loop,
+ * source/rt.resynth.lib.cpp:1204-1234) keeps the GPU full across block boundaries.
+ */
+int ra_process_device_async(ra_context *ctx, const float *d_voice, const float *d_carrier, int64_t n_frames, float *d_out);
+int ra_join(ra_context *ctx);
+
+/*
  * The reference's block-compute boundary: ComputeFunc = bool(double* buffer, int nFrames)
  * (include/simple_audio_context.h:24-26), as registered by ImplCRTP::initialize (gen.crtp.h:258-264) and
  * Vocoder::initialize (vocoder.cpp:760-815).  ra_feed pushes the n input frames those computes will consume

@@ -373,3 +373,31 @@ def test_full_size_properties(api, oracle, sig):
     for s in (0, 101, 255):
         ref, _, _ = oracle.run_offline(oracle.default_config(**dict(PARITY_KW, seed=1234 + s)), hv[s])
         assert rms(first[s].cpu().numpy(), ref) <= RMS_TOL
+
+
+def test_overlapped_blocks_equal_stream_ordered_blocks(api, sig):
+    # ra_process_device_async: block k + 1's analysis / tracking / propagation overlap block k's render (double-buffered scratch);
+    # every stage still runs its blocks in order, so the bits equal those of the synchronous calls
+    import torch
+    S, n, nb = 6, 160000, 4                      # 160 k frames -> 152 analysis frames per block -> the chunked pipeline is used
+    x = torch.from_numpy(sig.make_streams(S, n * nb)).cuda()
+    cfg = api.default_config(**PARITY_KW)
+    outs = []
+    for overlap in (False, True):
+        out = torch.zeros(nb, S, n, 2, dtype=torch.float32, device="cuda")
+        with api.Context(cfg, S, 0) as ctx:
+            ctx.set_hip_stream(torch.cuda.current_stream().cuda_stream)
+            for k in range(nb):
+                blk = x[:, k * n:(k + 1) * n].contiguous()
+                ctx.process_device(blk.data_ptr(), 0, n, out[k].data_ptr(), overlap=overlap)
+                if overlap:
+                    keep = blk                   # inputs must stay alive until the join
+                    outs_keep = outs_keep + [keep] if k else [keep]
+            if overlap:
+                ctx.join()
+            ctx.synchronize()
+            st = ctx.stats()
+            assert st.error_flags == 0
+        outs.append(out.cpu().numpy())
+    assert np.sqrt(np.mean(outs[0].astype(np.float64) ** 2)) > 1e-3
+    assert np.array_equal(outs[0], outs[1])
