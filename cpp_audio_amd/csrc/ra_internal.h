@@ -73,7 +73,8 @@ enum {
   SD_COUNT
 };
 enum { SI_ENV_STATE, SI_ENV_COUNTER, SI_ENV_RELDELAY, SI_ENV_AHDSTATE, SI_ENV_AHDCOUNTER, SI_ENV_MINCH, SI_ENV_NEXTMINCH, SI_FLAGS, SI_COUNT };
-enum { FL_HAS_FRES = 1, FL_HAS_VOL = 2, FL_HAS_TARGET = 4 };
+enum { FL_HAS_FRES = 1, FL_HAS_VOL = 2, FL_HAS_TARGET = 4,
+       FL_STEPPED0 = 8 }; // hop-start states only (seg_si): the propagate kernel already took this hop's first step for the channel
 enum { ENV_SOON = 0, ENV_PRESSED = 1, ENV_RELEASED = 2, ENV_DONE1 = 3, ENV_DONE2 = 4 }; // audioelement.h:157-163
 
 enum { RA_ERR_OVERFLOW = 1, RA_ERR_BOOKKEEPING = 2 };

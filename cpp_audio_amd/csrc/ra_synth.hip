@@ -126,6 +126,7 @@ struct Regime {
   double dv;                        // envelope value increment per step
   double base, slope, alpha, beta;  // glide: inc = base + slope * cur ; cur' = alpha * cur + beta  (steady: slope 0, alpha 1, beta 0)
   double rf;                        // hi: running reciprocal of the increment (refined by Newton steps as the glide moves)
+  double f_end;                     // the increment a glide clamps to
   int steps_left;                   // envelope steps before its next transition
   int pending;                      // steps taken since the envelope counters were last brought up to date
   bool active, gliding, irregular;  // irregular: the next step must be the general one
@@ -133,10 +134,11 @@ struct Regime {
   bool kvar;                        // the glide passes below the volume filter's maximum increment: its coefficient follows the increment
 };
 
-__device__ inline void regime_setup(const Chan &c, const SynConst &k, double inv_dur, Regime &r) {
+// envelope half of the regime: ramp increment and distance to the next stage change
+__device__ inline void regime_env(const Chan &c, const SynConst &k, Regime &r) {
   r.pending = 0;
   r.active = rt_active(c);
-  r.dv = 0; r.base = c.inc; r.slope = 0; r.alpha = 1; r.beta = 0; r.steps_left = 0x7fffffff; r.gliding = false; r.irregular = false; r.hi = false; r.kvar = false; r.rf = 0;
+  r.dv = 0; r.steps_left = 0x7fffffff;
   if (!r.active) return;
   r.steps_left = env_regular_steps(c, k.ep);
   switch (c.state) {
@@ -149,28 +151,38 @@ __device__ inline void regime_setup(const Chan &c, const SynConst &k, double inv
     case ENV_RELEASED: r.dv = -c.top / (double)max(c.minch, k.ep.R); break;
     default: break;
   }
+}
+
+// The render kernel never takes the general step: the first step of a note (no filter state, no increment yet) is taken by the
+// propagate kernel before it stores the hop's start state (FL_STEPPED0), envelope stage changes and glide ends have lean forms below,
+// and a filter coefficient that the next step would recompute (BaseVolumeAdjusted::step, audioelement.h:1195-1216) is recomputed here.
+// `irregular` is left for states the path cannot produce (non-positive increments, an unstarted control): they raise RA_ERR_BOOKKEEPING.
+__device__ inline void regime_setup(Chan &c, const SynConst &k, double inv_dur, Regime &r) {
+  regime_env(c, k, r);
+  r.base = c.inc; r.slope = 0; r.alpha = 1; r.beta = 0; r.gliding = false; r.irregular = false; r.hi = false; r.kvar = false; r.rf = 0; r.f_end = c.inc;
+  if (!r.active) return;
   if (!(c.flags & FL_HAS_VOL) || !(c.flags & FL_HAS_FRES)) { r.irregular = true; return; }
   const bool steady = c.fres == c.to;
   const double f_end = c.from + (c.to - c.from) * (k.dur / k.dur);
   const bool clamped = !steady && c.cur == k.dur && c.fres == f_end;
   double lo;
-  if (steady || clamped) { r.base = c.fres; lo = fabs(c.fres); }
+  if (steady || clamped) { r.base = c.fres; r.f_end = c.fres; lo = fabs(c.fres); }
   else {
-    if (c.to == c.from) { r.irregular = true; return; }
+    if (c.to == c.from || c.from <= 0. || c.to <= 0.) { r.irregular = true; return; } // increments are positive for every event the path produces
     r.gliding = true;
+    r.f_end = f_end;
     r.slope = (c.to - c.from) * inv_dur;
     r.base = c.from;
     r.alpha = 1.0 + c.C * r.slope;
     r.beta = c.C * (c.from + 0.5 * r.slope);
     lo = fmin(fabs(c.from + r.slope * c.cur), fabs(f_end));
-    if (c.from <= 0. || c.to <= 0.) { r.irregular = true; return; } // increments are positive for every event the path produces
     r.hi = fmax(c.from, c.to) > 0.25;
     if (r.hi) r.rf = 1.0 / (c.from + r.slope * c.cur);
   }
-  if (c.vol != c.target) { // the volume filter's coefficient is constant over the stretch, or follows a (positive) glide step by step
-    double want = fmin(k.max_filter_inc, lo);
-    if (r.gliding && lo < k.max_filter_inc) { if (c.from > 0. && c.to > 0.) r.kvar = true; else r.irregular = true; }
-    else if (!(c.finit == want)) r.irregular = true;
+  if (c.vol != c.target) { // the volume filter's coefficient is constant over the stretch, or follows the glide step by step
+    const double want = fmin(k.max_filter_inc, lo);
+    if (r.gliding && lo < k.max_filter_inc) r.kvar = true;
+    else if (c.finit != want) { c.finit = want; const double a = M_PI * want; c.k = a / (1.0 + a); }
   }
 }
 
@@ -263,24 +275,15 @@ __device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, dou
   }
 }
 
-// One sample of a lane at a transition: bring the envelope counters up to date, take the general step, re-derive the regime.
-// (Inlined: an out-of-line version on private copies, with or without a register budget of its own, measured 1.5 - 3x slower.)
-__device__ inline double transition_step(Chan &c, Regime &r, const SynConst &k, double inv_dur) {
-  double v = 0.0;
-  if (r.pending) env_jump(c, k.ep, r.pending);
-  chan_step_fast(c, k.ep, k.dur, inv_dur, k.max_filter_inc);
-  if (rt_active(c)) v = c.vol * ((c.alias * c.cim) * c.value);
-  regime_setup(c, k, inv_dur, r);
-  return v;
-}
-
 template <bool MONO>
 __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &k, const RaParams &p, int s, int l, int64_t t, int64_t seg_end,
                                          int64_t t0, int64_t n, const double *__restrict__ mix, float *__restrict__ out, double *__restrict__ out_d,
-                                         RaPhaseClock &clk) {
+                                         int32_t *b_error_flags, RaPhaseClock &clk) {
   const int Ppad = p.Ppad;
   const double inv_dur = 1.0 / k.dur;
   const double lim = k.dur - 0.5; // a glide step that finds cur > lim clamps (InterpolatedFreq::step, audioelement.h:2768-2770)
+  bool stepped0 = (c.flags & FL_STEPPED0) != 0; // this hop's first step was taken by the propagate kernel: sample 0 only reads the state
+  c.flags &= ~FL_STEPPED0;
   Regime r;
   regime_setup(c, k, inv_dur, r);
   clk.mark(21);
@@ -292,19 +295,32 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
   double gLm = 0.0, gRm = 0.0;
   if (MONO) { const double ang = (0.25 * M_PI) * (0.0 + 1.); gLm = cos(ang); gRm = sin(ang); } // stereo(0), stereo.h:18-27, as at note-on
 
-  // the common step of a lane inside a regular stretch; (cd, sd) = per-step rotation of the oscillator's rotation (glides only)
-  auto fast_step = [&](double cd, double sd) -> double {
+  // One checked step (tiles in which some lane meets a transition).  An envelope stage change runs the envelope's own state machine
+  // (its counters are first brought up to date) and re-derives the envelope half of the regime; a glide that has reached its end clamps
+  // (InterpolatedFreq::step, audioelement.h:2768-2785) and the lane turns steady; everything else is the regular recurrence with the
+  // exact per-step rotation update pi (inc_i - inc_{i-1}).
+  auto checked_step = [&]() -> double {
+    const bool env_now = r.steps_left == 0;
+    if (env_now) {
+      if (r.pending) env_jump(c, k.ep, r.pending);
+      env_step(c, k.ep);
+      regime_env(c, k, r);
+      if (!r.active) return 0.0; // the envelope ended on this step: the element is skipped from here on (gen.crtp.h:356-362)
+    }
     if (r.gliding) {
-      const double f = fma(r.slope, c.cur, r.base);
-      c.fres = f;
-      c.cur = fma(r.alpha, c.cur, r.beta);
+      const bool ended = c.cur > lim;
+      const double f = ended ? r.f_end : fma(r.slope, c.cur, r.base);
+      c.cur = ended ? k.dur : fma(r.alpha, c.cur, r.beta);
+      const double d = M_PI * (f - c.inc), d2 = d * d;
+      const double sd = d * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0), cd = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
       const double mr = fma(c.mre, cd, -(c.mim * sd)), mi = fma(c.mre, sd, c.mim * cd);
-      c.mre = mr; c.mim = mi; c.inc = f;
+      c.mre = mr; c.mim = mi; c.inc = f; c.fres = f;
       if (r.hi) { c.alias = alias_mult(f); r.rf = 1.0 / f; }
-      if (r.kvar && c.y != c.target) {
+      if ((r.kvar || ended) && c.y != c.target) {
         const double w = fmin(k.max_filter_inc, fabs(f));
         if (w != c.finit) { c.finit = w; const double a = M_PI * w; c.k = a / (1.0 + a); }
       }
+      if (ended) { r.gliding = false; r.hi = false; r.kvar = false; r.base = f; r.slope = 0; r.alpha = 1; r.beta = 0; }
     }
     const double re = fma(c.cre, c.mre, -(c.cim * c.mim));
     const double im = fma(c.cre, c.mim, c.cim * c.mre);
@@ -312,17 +328,17 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
     c.cre = re * g; c.cim = im * g;
     c.y = fma(c.k, c.target - c.y, c.y);
     c.vol = c.y;
-    c.value += r.dv;
-    ++r.pending; --r.steps_left;
+    if (!env_now) { c.value += r.dv; ++r.pending; --r.steps_left; }
     return c.vol * ((c.alias * c.cim) * c.value);
   };
+  if (__any(r.active && r.irregular)) atomicOr(b_error_flags, RA_ERR_BOOKKEEPING); // see regime_setup
 
   while (t < seg_end) {
     const int m = (int)min((int64_t)TD, seg_end - t);
     // a tile is clean for a lane if no transition can fall inside it: then the loop needs no per-sample checks
     double step0 = 0.0;
     if (r.active && r.gliding) step0 = fma(r.alpha - 1.0, c.cur, r.beta); // cur increment of the tile's first step
-    const bool clean = !r.active || (!r.irregular && r.steps_left >= TD &&
+    const bool clean = !r.active || (!stepped0 && r.steps_left >= TD &&
                                      (!r.gliding || (fabs(r.alpha - 1.0) < 1e-2 && c.cur + (TD - 1) * fabs(step0) * 1.1 <= lim)));
     if (m == TD && __all(clean)) {
       const bool any_glide = __any(r.active && r.gliding);
@@ -362,23 +378,11 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
     } else {
       for (int i = 0; i < m; ++i) {
         double v = 0.0;
-        const bool irr = r.active && (r.irregular || r.steps_left == 0 || (r.gliding && c.cur > lim));
-        if (__any(irr)) {
-          if (irr) {
-            v = transition_step(c, r, k, inv_dur);
-          }
+        if (r.active) {
+          if (stepped0) v = c.vol * ((c.alias * c.cim) * c.value); // already stepped (propagate kernel): StereoPanned::imag of the state as loaded
+          else v = checked_step();
         }
-        if (!irr && r.active) {
-          // exact per-step rotation update here (the lane may have just left a transition)
-          double cdi = 1.0, sdi = 0.0;
-          if (r.gliding) {
-            const double d = M_PI * (fma(r.slope, c.cur, r.base) - c.inc);
-            const double d2 = d * d;
-            sdi = d * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
-            cdi = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
-          }
-          v = fast_step(cdi, sdi);
-        }
+        stepped0 = false;
         if (MONO) mine[i] = v; else { mine[i] = c.gL * v; mine[TD + i] = c.gR * v; }
       }
       clk.lap<1>();
@@ -538,9 +542,18 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) RA_PROP_OCC ra_synth_propagat
   for (int64_t i = 0; i <= sp.nfb; ++i) {
     const int64_t seg_end = (i < sp.nfb) ? ra_fire_sample(p.N, p.H, sp.f_lo + sp.fb0 + i) : sp.ct1;
     const size_t seg = (size_t)s * b.seg_cap + sp.seg0 + i;
+    // The first step of a note has no closed form (no filter state, no increment yet): it is taken here, before the hop's start state
+    // is stored, so that the render kernel never needs the general step; the render outputs that sample from the stored state.
+    int64_t len = seg_end - t;
+    if (p.render_mode == 0 && len > 0 && rt_active(c) && (!(c.flags & FL_HAS_VOL) || !(c.flags & FL_HAS_FRES))) {
+      chan_step_phase(c, k.ep, k.dur, 1.0 / k.dur, k.max_filter_inc);
+      c.flags |= FL_STEPPED0;
+      --len;
+    }
     store_chan(c, b.seg_sd + seg * SD_COUNT * Ppad, b.seg_si + seg * SI_COUNT * Ppad, Ppad, l);
+    c.flags &= ~FL_STEPPED0;
     clk.lap<0>();
-    chan_jump_phase(c, k.ep, k.dur, k.max_filter_inc, seg_end - t);
+    chan_jump_phase(c, k.ep, k.dur, k.max_filter_inc, len);
     clk.lap<1>();
     t = seg_end;
     if (i == sp.nfb) break;
@@ -582,7 +595,7 @@ __device__ inline void render_segment(const RaParams &p, const RaBuffers &b, con
     if (p.render_mode == 2) render_range<false>(c, L, k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
     else render_range<true>(c, L, k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
   } else render_range_fast<MONO>(c, reinterpret_cast<double *>(ra_smem_syn) + (size_t)wy * Ppad * (MONO ? TROW_MONO : TROW), k, p, s, l, seg_begin, seg_end,
-                                 sp.t0, sp.n, mix, out, out_d, clk);
+                                 sp.t0, sp.n, mix, out, out_d, b.error_flags, clk);
   if (clk.dst) { // workgroup lifetime: maximum and a histogram in steps of 200 k ticks
     const unsigned long long d = __builtin_readcyclecounter() - wg_t0;
     atomicMax(clk.dst + 39, d);
