@@ -220,9 +220,10 @@ constexpr int TROW_MONO = TD + 1; // stereo_spread 0: every channel has the same
 #define RA_PRAGMA(x) _Pragma(#x)
 #define RA_UNROLL(n) RA_PRAGMA(unroll n)
 template <bool GLIDE, bool HI, bool KVAR, bool MONO>
-__device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, double cd0, double sd0, double cd, double sd, double *mine) {
+__device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, double cd0, double sd0, double cd, double sd, double al_da, double al_dda,
+                                  double *mine) {
   double cur = c.cur, mre = c.mre, mim = c.mim, cre = c.cre, cim = c.cim, y = c.y, value = c.value, alias = c.alias, f = c.inc;
-  double kk = c.k, fin = c.finit, rr = 0.0, rf = r.rf;
+  double kk = c.k, fin = c.finit, rr = 0.0, a_used = c.alias;
   const double target = c.target;
   if (KVAR) rr = 1.0 / (1.0 + M_PI * c.finit);
   double va = alias * value;
@@ -233,14 +234,11 @@ __device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, dou
       cur = fma(r.alpha, cur, r.beta);
       const double mr = fma(mre, rc, -(mim * rs)), mi = fma(mre, rs, mim * rc);
       mre = mr; mim = mi;
-      if (HI) { // freqAliasingMultiplicator (audioelement.h:466-483) without its division: 1 / inc follows the glide by two Newton steps
-        // (lanes that are not hi carry rf = 0, which stays 0); (1 / inc - 1) / 3, 1 above 4 and 0 below 1 as in the function's branches
-        rf = rf * fma(-f, rf, 2.0);
-        rf = rf * fma(-f, rf, 2.0);
-        double a = fma(rf, 1. / 3., -1. / 3.);
-        a = rf > 4. ? 1. : a;
-        a = rf < 1. ? 0. : a;
-        alias = r.hi ? a : alias;
+      if (HI) { // freqAliasingMultiplicator (audioelement.h:466-483) along the glide: second-order forward differences from the tile's first
+        // increment (set up by the caller; third-order remainder < 1e-10), zero differences for lanes whose gain does not move
+        a_used = alias;
+        alias += al_da;
+        al_da += al_dda;
       }
       if (KVAR) { // BaseVolumeAdjusted::step, audioelement.h:1195-1216: k = a / (1 + a), a = pi min(max increment, |inc|); 1 / (1 + a) by Newton
         if (r.kvar && y != target) {
@@ -256,7 +254,7 @@ __device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, dou
     const double re = fma(cre, mre, -(cim * mim)), im = fma(cre, mim, cim * mre);
     cre = re; cim = im;
     y = fma(kk, target - y, y);
-    if (HI) { value += r.dv; return y * ((alias * cim) * value); }
+    if (HI) { value += r.dv; return y * ((a_used * cim) * value); }
     va += dva;
     return y * (cim * va); // the anti-aliasing gain is constant here: folded into the envelope ramp
   };
@@ -268,10 +266,9 @@ __device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, dou
   c.cre = cre * g; c.cim = cim * g;
   c.y = y; c.vol = y; c.value = HI ? value : fma((double)TD, r.dv, value);
   if (GLIDE) {
-    c.mre = mre; c.mim = mim; c.cur = cur; c.alias = alias;
+    c.mre = mre; c.mim = mim; c.cur = cur; c.alias = HI ? a_used : alias;
     if (r.gliding) { c.fres = f; c.inc = f; }
     if (KVAR) { c.k = kk; c.finit = fin; }
-    if (HI) r.rf = rf;
   }
 }
 
@@ -338,12 +335,32 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
     // a tile is clean for a lane if no transition can fall inside it: then the loop needs no per-sample checks
     double step0 = 0.0;
     if (r.active && r.gliding) step0 = fma(r.alpha - 1.0, c.cur, r.beta); // cur increment of the tile's first step
-    const bool clean = !r.active || (!stepped0 && r.steps_left >= TD &&
-                                     (!r.gliding || (fabs(r.alpha - 1.0) < 1e-2 && c.cur + (TD - 1) * fabs(step0) * 1.1 <= lim)));
+    bool clean = !r.active || (!stepped0 && r.steps_left >= TD &&
+                               (!r.gliding || (fabs(r.alpha - 1.0) < 1e-2 && c.cur + (TD - 1) * fabs(step0) * 1.1 <= lim)));
+    // Anti-aliasing gain of a glide above fs/8, (1 / inc - 1) / 3 between inc = 1/4 and 1 (freqAliasingMultiplicator, audioelement.h:466-483):
+    // over a tile it is followed by its value and first two forward differences at the tile's first increment (1 / inc from the running
+    // reciprocal, two Newton steps).  A tile in which the increment crosses 1/4 or 1 is not clean (the checked step evaluates the function).
+    double al0 = c.alias, al_da = 0.0, al_dda = 0.0;
+    if (clean && r.active && r.gliding && r.hi) {
+      const double f0 = fma(r.slope, c.cur, r.base), df = r.slope * step0, f7 = fma((double)(TD - 1), df, f0);
+      const double flo = f0 < f7 ? f0 : f7, fhi = f0 < f7 ? f7 : f0;
+      double rf = r.rf * fma(-f0, r.rf, 2.0);
+      rf = rf * fma(-f0, rf, 2.0);
+      r.rf = rf;
+      if (fhi <= 0.25) al0 = 1.0;
+      else if (flo >= 1.0) al0 = 0.0;
+      else if (flo >= 0.25 && fhi <= 1.0) {
+        const double r2 = rf * rf, q = (r2 * rf) * (1. / 3.) * (df * df); // half the second derivative times df^2
+        al0 = fma(rf, 1. / 3., -1. / 3.);
+        al_da = fma(-(r2 * (1. / 3.)), df, q);
+        al_dda = 2.0 * q;
+      } else clean = false;
+    }
     if (m == TD && __all(clean)) {
       const bool any_glide = __any(r.active && r.gliding);
       if (r.active) {
-        if (!any_glide) { clk.tally<0>(); clean_tile<false, false, false, MONO>(c, r, k.max_filter_inc, 1.0, 0.0, 1.0, 0.0, mine); }
+        c.alias = al0; // (its own value for lanes whose gain does not move)
+        if (!any_glide) { clk.tally<0>(); clean_tile<false, false, false, MONO>(c, r, k.max_filter_inc, 1.0, 0.0, 1.0, 0.0, 0.0, 0.0, mine); }
         else {
           // Rotation of `mult` per step while gliding: pi (inc_i - inc_{i-1}).  The tile's first step turns by d0 = pi (inc_0 - inc),
           // whatever the oscillator's increment currently is (0 right after a note change); the later steps turn by
@@ -360,9 +377,9 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
             cd = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
           }
           if (__any(r.active && r.kvar)) clk.tally<3>(); else if (__any(r.active && r.gliding && r.hi)) clk.tally<2>(); else clk.tally<1>();
-          if (__any(r.active && r.kvar)) clean_tile<true, true, true, MONO>(c, r, k.max_filter_inc, cd0, sd0, cd, sd, mine);
-          else if (__any(r.active && r.gliding && r.hi)) clean_tile<true, true, false, MONO>(c, r, k.max_filter_inc, cd0, sd0, cd, sd, mine);
-          else clean_tile<true, false, false, MONO>(c, r, k.max_filter_inc, cd0, sd0, cd, sd, mine);
+          if (__any(r.active && r.kvar)) clean_tile<true, true, true, MONO>(c, r, k.max_filter_inc, cd0, sd0, cd, sd, al_da, al_dda, mine);
+          else if (__any(r.active && r.gliding && r.hi)) clean_tile<true, true, false, MONO>(c, r, k.max_filter_inc, cd0, sd0, cd, sd, al_da, al_dda, mine);
+          else clean_tile<true, false, false, MONO>(c, r, k.max_filter_inc, cd0, sd0, cd, sd, 0.0, 0.0, mine);
           // over the m' = TD - 1 later steps the even spread runs ahead of the exact (linearly growing) rotation by b (j+1)(m'-1-j)/2
           // at step j, b = pi slope step0 (alpha - 1); the oscillator has integrated that: take the sum b (m'-1) m' (m'+1) / 12 back out
           const double dl = (M_PI * r.slope) * step0 * (r.alpha - 1.0) * ((TD - 2) * (TD - 1) * TD * (1.0 / 12.0));
