@@ -150,6 +150,11 @@ def main():
                              carrier_volume=0.0, seed=1234 + 100003 * rank)
     ctx = api.Context(cfg, S, local_rank)
     ctx.set_hip_stream(torch.cuda.current_stream().cuda_stream)
+    # set-up, not a step: a 2 s block makes HIP load the code objects and creates the context's internal streams and events, then the
+    # streams are put back to their initial state; the per-block scratch (GBs) is still allocated by the first warm-up step
+    ctx.process_device(voice.data_ptr(), 0, min(n, 2 * sr), out.data_ptr())
+    ctx.synchronize()
+    ctx.reset()
 
     def barrier():
         if world > 1:

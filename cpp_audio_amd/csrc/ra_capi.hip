@@ -440,29 +440,32 @@ int init_state(ra_context *c) {
 int ensure_scratch(ra_context *c, int64_t nfb, int64_t n, int n_chunks) {
   RaParams &p = c->p;
   RaBuffers &b = c->b;
-  ra_context::Scratch &sc = c->scr[c->parity];
   int r;
-  if (nfb > sc.frames_cap) {
-    HIP_TRY(hipDeviceSynchronize()); // rare (first block, or a longer block than ever before): nothing may still read the old buffers
-    dev_free(c, sc.pl_pitch); dev_free(c, sc.pl_vol); dev_free(c, sc.pl_key); dev_free(c, sc.pl_count); dev_free(c, sc.cmd); dev_free(c, sc.cmd_non);
-    size_t S = p.n_streams, F = static_cast<size_t>(nfb);
-    sc.frames_cap = nfb;
-    if ((r = dev_alloc(c, &sc.pl_pitch, S * F * p.maxr, false))) return r;
-    if ((r = dev_alloc(c, &sc.pl_vol, S * F * p.maxr, false))) return r;
-    if ((r = dev_alloc(c, &sc.pl_key, S * F * p.maxr, false))) return r;
-    if ((r = dev_alloc(c, &sc.pl_count, S * F))) return r;
-    if ((r = dev_alloc(c, &sc.cmd, S * F * p.Ppad, false))) return r;
-    if ((r = dev_alloc(c, &sc.cmd_non, S * F))) return r;
-    HIP_TRY(hipStreamSynchronize(c->stream)); // the zero fills above ran on the caller's stream
+  // both sets grow together (on the first block, or for a longer block than ever before): an allocation must not land in the second block
+  for (ra_context::Scratch &sc : c->scr) {
+    if (nfb > sc.frames_cap) {
+      HIP_TRY(hipDeviceSynchronize()); // nothing may still read the old buffers
+      dev_free(c, sc.pl_pitch); dev_free(c, sc.pl_vol); dev_free(c, sc.pl_key); dev_free(c, sc.pl_count); dev_free(c, sc.cmd); dev_free(c, sc.cmd_non);
+      size_t S = p.n_streams, F = static_cast<size_t>(nfb);
+      sc.frames_cap = nfb;
+      if ((r = dev_alloc(c, &sc.pl_pitch, S * F * p.maxr, false))) return r;
+      if ((r = dev_alloc(c, &sc.pl_vol, S * F * p.maxr, false))) return r;
+      if ((r = dev_alloc(c, &sc.pl_key, S * F * p.maxr, false))) return r;
+      if ((r = dev_alloc(c, &sc.pl_count, S * F))) return r;
+      if ((r = dev_alloc(c, &sc.cmd, S * F * p.Ppad, false))) return r;
+      if ((r = dev_alloc(c, &sc.cmd_non, S * F))) return r;
+      HIP_TRY(hipStreamSynchronize(c->stream)); // the zero fills above ran on the caller's stream
+    }
+    if (c->cfg.reference_order != 1 && nfb + n_chunks > sc.seg_cap) {
+      HIP_TRY(hipDeviceSynchronize());
+      dev_free(c, sc.seg_sd); dev_free(c, sc.seg_si);
+      size_t S = p.n_streams, G = static_cast<size_t>(nfb + kMaxChunks);
+      sc.seg_cap = nfb + kMaxChunks;
+      if ((r = dev_alloc(c, &sc.seg_sd, S * G * SD_COUNT * p.Ppad, false))) return r;
+      if ((r = dev_alloc(c, &sc.seg_si, S * G * SI_COUNT * p.Ppad, false))) return r;
+    }
   }
-  if (c->cfg.reference_order != 1 && nfb + n_chunks > sc.seg_cap) {
-    HIP_TRY(hipDeviceSynchronize());
-    dev_free(c, sc.seg_sd); dev_free(c, sc.seg_si);
-    size_t S = p.n_streams, G = static_cast<size_t>(nfb + kMaxChunks);
-    sc.seg_cap = nfb + kMaxChunks;
-    if ((r = dev_alloc(c, &sc.seg_sd, S * G * SD_COUNT * p.Ppad, false))) return r;
-    if ((r = dev_alloc(c, &sc.seg_si, S * G * SI_COUNT * p.Ppad, false))) return r;
-  }
+  ra_context::Scratch &sc = c->scr[c->parity];
   b.frames_cap = sc.frames_cap; b.seg_cap = sc.seg_cap;
   b.pl_pitch = sc.pl_pitch; b.pl_vol = sc.pl_vol; b.pl_key = sc.pl_key; b.pl_count = sc.pl_count;
   b.cmd = sc.cmd; b.cmd_non = sc.cmd_non; b.seg_sd = sc.seg_sd; b.seg_si = sc.seg_si;
