@@ -43,6 +43,7 @@ class RaConfig(C.Structure):
         ("analysis_volume", C.c_float), ("analysis_input_gain", C.c_float),
         ("phase_policy", C.c_int32), ("seed", C.c_uint64),
         ("max_pitches_per_frame", C.c_int32), ("reference_order", C.c_int32),
+        ("analysis_output_feedback_gain", C.c_float), ("output_delay_seconds", C.c_float),
     ]
 
 

@@ -10,6 +10,7 @@
 // as an M = L/2 point complex FFT in LDS (fp64, like the reference), |X|^2 overwrites the same LDS slots,
 // peaks are compacted in bin order and only the short autotuned pitch list goes back to HBM.
 #include "ra_fft.cuh"
+#include <algorithm>
 
 extern __shared__ __align__(16) unsigned char ra_smem[];
 
@@ -173,6 +174,8 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
     const int h = N / 2;
     // branch-free so that the 16 sample / 16 window loads of a thread are all in flight together
     const float *vs0 = vs ? vs : hist; // never dereferenced past the block when voice is null (the select below picks 0)
+    const bool fb_on = p.fb_gain != 0.f;
+    const float *fbh = fb_on ? b.fb_hist + (size_t)s * b.fb_hist_len : nullptr, *fbb = fb_on ? b.fb_block + (size_t)s * n : nullptr;
     auto sample = [&](int i) -> double {
       const int ic = min(i, N - 1);
       const int64_t a = start + ic;
@@ -181,6 +184,12 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
       if (!(a < t0) && !vs) v = 0.f;
       float sum = 0.f;
       sum += p.input_gain * v; // analyze_until_input_starvation, lib.cpp:1626,1636 (float)
+      if (fb_on) { // + feedback gain * the mono output fb_sz + 1 frames earlier (the aggregator pairs input a with output a - 1; lib.cpp:1637-1650)
+        const int64_t j = a - 1 - p.fb_sz;
+        float o = 0.f;
+        if (a >= (int64_t)p.fb_sz + 2) o = (j >= t0) ? fbb[j - t0] : fbh[b.fb_hist_len - (t0 - j)];
+        sum += p.fb_gain * o;
+      }
       double x = (double)sum;  // PeriodicFFT::feed stores the float as FPT = double (periodicfft.cpp:61)
       const int j = (ic >= h) ? (ic - h) : (h - 1 - ic);
       const double w = b.half_window[j];
@@ -517,7 +526,34 @@ __global__ void ra_roll_history_kernel(RaParams p, RaBuffers b, const float *__r
   }
 }
 
+// keeps the mono output of the last fb_hist_len frames for the next block's feedback term: new[i] = concat(hist, block)[n + i]
+__global__ void ra_roll_feedback_kernel(RaBuffers b, int64_t n) {
+  const int s = blockIdx.y;
+  const int64_t Hn = b.fb_hist_len;
+  float *hist = b.fb_hist + (size_t)s * Hn;
+  const float *blk = b.fb_block + (size_t)s * n;
+  if (n >= Hn) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < Hn; i += (int64_t)gridDim.x * blockDim.x) hist[i] = blk[n - Hn + i];
+  } else { // one workgroup per stream (grid.x == 1): shift by n in passes that never overwrite unread data (ascending, src index > dst index)
+    for (int64_t base = 0; base < Hn; base += blockDim.x) {
+      const int64_t i = base + threadIdx.x;
+      float v = 0.f;
+      if (i < Hn) { const int64_t src = i + n; v = (src < Hn) ? hist[src] : blk[src - Hn]; }
+      __syncthreads();
+      if (i < Hn) hist[i] = v;
+      __syncthreads();
+    }
+  }
+}
+
 } // namespace
+
+void ra_launch_roll_feedback(const RaParams &p, const RaBuffers &b, int64_t n, hipStream_t st) {
+  if (n <= 0 || !b.fb_hist) return;
+  const bool whole = n >= b.fb_hist_len;
+  dim3 grid(whole ? (unsigned)std::min<int64_t>((b.fb_hist_len + 255) / 256, 1024) : 1u, (unsigned)p.n_streams);
+  hipLaunchKernelGGL(ra_roll_feedback_kernel, grid, dim3(256), 0, st, b, n);
+}
 
 size_t ra_analysis_lds_bytes(const RaParams &p) {
   size_t m = (size_t)ra_zpad_size(p.M);

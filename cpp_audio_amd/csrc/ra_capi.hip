@@ -173,6 +173,8 @@ int validate(const ra_config &c, int32_t n_streams) {
   if (c.vocoder_count_bands < 1 || c.vocoder_count_bands > 50) return fail(RA_EINVAL, "vocoder_count_bands must be in 1..50");
   if (c.window_kind < 0 || c.window_kind > 2) return fail(RA_EINVAL, "unknown window_kind");
   if (c.autotune_factor < 0) return fail(RA_EINVAL, "autotune_factor must be >= 0");
+  if (c.analysis_output_feedback_gain != 0.f && c.reference_order != 0) return fail(RA_EINVAL, "analysis_output_feedback_gain needs reference_order 0");
+  if (c.analysis_output_feedback_gain != 0.f && !(c.output_delay_seconds >= 0.f && c.output_delay_seconds <= 60.f)) return fail(RA_EINVAL, "output_delay_seconds must be in 0..60");
   return RA_OK;
 }
 
@@ -318,6 +320,8 @@ int build_tables(ra_context *c) {
   p.vol_car = cfg.carrier_volume;
   p.vol_voc = cfg.vocoder_volume;
   p.render_mode = cfg.reference_order >= 2 ? cfg.reference_order : 0;
+  p.fb_gain = cfg.analysis_output_feedback_gain;
+  p.fb_sz = std::max(0, static_cast<int>(0.5f + cfg.output_delay_seconds * cfg.sample_rate)); // lib.cpp:1638-1639
   p.voc_enabled = (cfg.voice_volume != 0.f || cfg.carrier_volume != 0.f || cfg.vocoder_volume != 0.f) ? 1 : 0;
 
   RaBuffers &b = c->b;
@@ -384,6 +388,10 @@ int alloc_state(ra_context *c) {
   if ((r = dev_alloc(c, &b.sd, S * SD_COUNT * p.Ppad))) return r;
   if ((r = dev_alloc(c, &b.si, S * SI_COUNT * p.Ppad))) return r;
   if ((r = dev_alloc(c, &b.error_flags, 1))) return r;
+  if (p.fb_gain != 0.f) { // the mono output of the fb_sz + N + 2 frames before the block: what the block's first windows look back at
+    b.fb_hist_len = (int64_t)p.fb_sz + p.N + 2;
+    if ((r = dev_alloc(c, &b.fb_hist, S * b.fb_hist_len))) return r;
+  }
   if (p.voc_enabled) {
     if ((r = dev_alloc(c, &b.voc_mod_hist, S * p.voc_Wm))) return r;
     if ((r = dev_alloc(c, &b.voc_car_hist, S * 2 * p.voc_S))) return r;
@@ -399,6 +407,7 @@ int init_state(ra_context *c) {
   RaBuffers &b = c->b;
   size_t S = p.n_streams;
   HIP_TRY(hipMemsetAsync(b.hist, 0, S * p.N * sizeof(float), c->stream));
+  if (b.fb_hist) HIP_TRY(hipMemsetAsync(b.fb_hist, 0, S * b.fb_hist_len * sizeof(float), c->stream));
   HIP_TRY(hipMemsetAsync(b.track, 0, S * sizeof(RaTrackState), c->stream));
   HIP_TRY(hipMemsetAsync(b.played, 0, S * p.P * sizeof(RaPlayed), c->stream));
   HIP_TRY(hipMemsetAsync(b.chan_free_at, 0, S * p.P * sizeof(int64_t), c->stream));
@@ -459,8 +468,9 @@ int ensure_scratch(ra_context *c, int64_t nfb, int64_t n, int n_chunks) {
     if (c->cfg.reference_order != 1 && nfb + n_chunks > sc.seg_cap) {
       HIP_TRY(hipDeviceSynchronize());
       dev_free(c, sc.seg_sd); dev_free(c, sc.seg_si);
-      size_t S = p.n_streams, G = static_cast<size_t>(nfb + kMaxChunks);
-      sc.seg_cap = nfb + kMaxChunks;
+      const int64_t extra = std::max<int64_t>(kMaxChunks, n_chunks);
+      size_t S = p.n_streams, G = static_cast<size_t>(nfb + extra);
+      sc.seg_cap = nfb + extra;
       if ((r = dev_alloc(c, &sc.seg_sd, S * G * SD_COUNT * p.Ppad, false))) return r;
       if ((r = dev_alloc(c, &sc.seg_si, S * G * SI_COUNT * p.Ppad, false))) return r;
     }
@@ -469,6 +479,12 @@ int ensure_scratch(ra_context *c, int64_t nfb, int64_t n, int n_chunks) {
   b.frames_cap = sc.frames_cap; b.seg_cap = sc.seg_cap;
   b.pl_pitch = sc.pl_pitch; b.pl_vol = sc.pl_vol; b.pl_key = sc.pl_key; b.pl_count = sc.pl_count;
   b.cmd = sc.cmd; b.cmd_non = sc.cmd_non; b.seg_sd = sc.seg_sd; b.seg_si = sc.seg_si;
+  if (p.fb_gain != 0.f && n > b.fb_block_cap) {
+    HIP_TRY(hipDeviceSynchronize());
+    dev_free(c, b.fb_block);
+    b.fb_block_cap = n;
+    if ((r = dev_alloc(c, &b.fb_block, (size_t)p.n_streams * n, false))) return r;
+  }
   if (p.voc_enabled) {
     size_t S = p.n_streams;
     if (n > b.mix_cap) {
@@ -568,7 +584,9 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
   // blocks that cannot overlap their predecessor: single-chunk / reference-order blocks (they run on the caller's stream) and the vocoder
   // (its histories are rolled on the render stream): they first wait for whatever is still in flight
   int r;
-  if (n_chunks == 1 || p.voc_enabled) { if ((r = join_streams(c))) return r; async = false; }
+  if (p.fb_gain != 0.f) n_chunks = static_cast<int>(std::min<int64_t>(nfb, nfb / ((int64_t)p.fb_sz / p.H + 1) + 1)) + 2; // pieces (only sizes the hop-state buffer)
+  const bool caller_stream_only = n_chunks == 1 || p.fb_gain != 0.f;
+  if (caller_stream_only || p.voc_enabled) { if ((r = join_streams(c))) return r; async = false; }
   c->parity ^= 1;
   if ((r = ensure_scratch(c, nfb, n, n_chunks))) return r;
   ra_context::Scratch &sc = c->scr[c->parity];
@@ -577,7 +595,33 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
   const RaBuffers &b = c->b;
   hipStream_t user = c->stream;
 
-  if (n_chunks == 1) { // everything in order on the caller's stream
+  if (p.fb_gain != 0.f) {
+    // Feedback of the output into the analysis input: the analysis of a piece needs the mono output up to fb_sz + 1 frames before its
+    // last frame fires, i.e. only output of earlier pieces if a piece holds at most fb_sz / H + 1 analysis frames.  The pieces run one
+    // after the other on the caller's stream (no overlap: that is the price of the dependency).
+    const int64_t per = (int64_t)p.fb_sz / p.H + 1;
+    if (p.voc_enabled) timed_launch(c, ST_VOCODER, user, [&] { ra_launch_vocoder(p, b, d_voice, d_carrier, t0, n, user); });
+    // piece 0 holds no frame: it only renders the samples before the block's first frame fires (that frame's window looks back at them)
+    int64_t fb0 = 0, fb1 = 0;
+    int piece = 0;
+    do {
+      RaSpan sp;
+      sp.t0 = t0; sp.n = n; sp.f_lo = f_lo; sp.fb0 = fb0; sp.nfb = fb1 - fb0; sp.seg0 = fb0 + piece;
+      sp.ct0 = (piece == 0) ? t0 : ra_fire_sample(p.N, p.H, f_lo + fb0);
+      sp.ct1 = (fb1 == nfb) ? t0 + n : ra_fire_sample(p.N, p.H, f_lo + fb1);
+      if (sp.nfb > 0) {
+        timed_launch(c, ST_ANALYSIS, user, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, sp.fb0, sp.nfb, nfb, user); });
+        timed_launch(c, ST_TRACK, user, [&] { ra_launch_track(p, b, f_lo, sp.fb0, sp.nfb, user); });
+      }
+      timed_launch(c, ST_PROPAGATE, user, [&] { ra_launch_synth_propagate(p, b, sp, user); });
+      timed_launch(c, ST_RENDER, user, [&] { ra_launch_synth_render(p, b, sp, d_out, d_out_d, user); });
+      fb0 = fb1;
+      fb1 = std::min(nfb, fb0 + per);
+      ++piece;
+    } while (fb0 < nfb);
+    timed_launch(c, ST_HISTORY, user, [&] { ra_launch_roll_feedback(p, b, n, user); });
+    n_chunks = 1; // the window history is rolled on the caller's stream below
+  } else if (n_chunks == 1) { // everything in order on the caller's stream
     RaSpan sp{t0, n, t0, t0 + n, f_lo, 0, nfb, 0};
     timed_launch(c, ST_ANALYSIS, user, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, 0, nfb, nfb, user); });
     timed_launch(c, ST_TRACK, user, [&] { ra_launch_track(p, b, f_lo, 0, nfb, user); });
@@ -766,6 +810,8 @@ int ra_default_config(ra_config *c) { // source/rt.resynth.lib.cpp:943-999
   c->phase_policy = RA_PHASE_HASH;
   c->seed = 0;
   c->max_pitches_per_frame = 512;
+  c->analysis_output_feedback_gain = 0.f;
+  c->output_delay_seconds = 1.f;
   return RA_OK;
 }
 

@@ -34,6 +34,8 @@ struct RaParams {
   // vocoder
   int voc_enabled, voc_S, voc_Wm, voc_Lm, voc_Mm, voc_Lc, voc_Mc, voc_bands;
   float vol_mod, vol_car, vol_voc;
+  float fb_gain;   // output -> analysis feedback (lib.cpp:1626-1652): gain, and the delay in frames
+  int fb_sz;
   int render_mode; // diagnostics: 0 regime renderer, 2 hop-parallel with the reference-order step, 3 with the cheap generic step
 };
 
@@ -111,6 +113,10 @@ struct RaBuffers {
   double *seg_sd;           // [n_streams][seg_cap][SD_COUNT][Ppad] channel state at the start of every segment of the block
   int32_t *seg_si;          // [n_streams][seg_cap][SI_COUNT][Ppad]
   int64_t seg_cap;
+  // ---- output -> analysis feedback (only allocated when its gain is non-zero) ----
+  float *fb_hist;           // [n_streams][fb_hist_len] mono output float(L + R) of the fb_hist_len frames before the current block
+  float *fb_block;          // [n_streams][n] mono output of the current block, written by the render as it goes
+  int64_t fb_hist_len, fb_block_cap;
   double *dbg_sqmag;        // optional [frames][M] tap of |X|^2 (ra_sqmag), normally null
   unsigned long long *dbg_clk; // optional [64] in-kernel phase clocks (env RA_PHASE_CLOCKS=1, printed by ra_destroy), normally null
   // ---- vocoder (only allocated when a vocoder volume is non-zero) ----
@@ -202,6 +208,7 @@ void ra_launch_synth_serial(const RaParams &p, const RaBuffers &b, const RaSpan 
 void ra_launch_synth_propagate(const RaParams &p, const RaBuffers &b, const RaSpan &sp, hipStream_t st);
 void ra_launch_synth_render(const RaParams &p, const RaBuffers &b, const RaSpan &sp, float *d_out, double *d_out_d, hipStream_t st);
 void ra_launch_roll_history(const RaParams &p, const RaBuffers &b, const float *d_voice, int64_t n, hipStream_t st);
+void ra_launch_roll_feedback(const RaParams &p, const RaBuffers &b, int64_t n, hipStream_t st);
 size_t ra_analysis_lds_bytes(const RaParams &p);
 
 // frame f covers input samples [2 + f H, 2 + f H + N) and fires in iteration N + 1 + f H

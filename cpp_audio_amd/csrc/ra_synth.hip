@@ -275,7 +275,7 @@ __device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, dou
 template <bool MONO>
 __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &k, const RaParams &p, int s, int l, int64_t t, int64_t seg_end,
                                          int64_t t0, int64_t n, const double *__restrict__ mix, float *__restrict__ out, double *__restrict__ out_d,
-                                         int32_t *b_error_flags, RaPhaseClock &clk) {
+                                         int32_t *b_error_flags, float *__restrict__ fb_mono, RaPhaseClock &clk) {
   const int Ppad = p.Ppad;
   const double inv_dur = 1.0 / k.dur;
   const double lim = k.dur - 0.5; // a glide step that finds cur > lim clamps (InterpolatedFreq::step, audioelement.h:2768-2770)
@@ -429,12 +429,18 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
             else { o[0] = (float)oL; o[1] = (float)oR; }
           }
           if (out_d) { out_d[((size_t)s * n + rel) * 2] = oL; out_d[((size_t)s * n + rel) * 2 + 1] = oR; }
+          if (fb_mono) fb_mono[rel] = (float)(oL + oR); // what the post processor publishes to the analysis (lib.cpp:1262-1272, pubsub.cpp:92)
         }
-      } else if (l < 16 && fr < m) {
+      } else {
+        const bool w = l < 16 && fr < m;
         const int64_t rel = (t - t0) + fr;
-        if (mix) acc += mix[rel];
-        if (out) out[((size_t)s * n + rel) * 2 + ch] = (float)acc;
-        if (out_d) out_d[((size_t)s * n + rel) * 2 + ch] = acc;
+        if (w && mix) acc += mix[rel];
+        const double other = lane_ror8(acc); // the other output channel of the same frame
+        if (w) {
+          if (out) out[((size_t)s * n + rel) * 2 + ch] = (float)acc;
+          if (out_d) out_d[((size_t)s * n + rel) * 2 + ch] = acc;
+          if (fb_mono && ch == 0) fb_mono[rel] = (float)(acc + other);
+        }
       }
     }
     if (Ppad > 64) __syncthreads();
@@ -612,7 +618,8 @@ __device__ inline void render_segment(const RaParams &p, const RaBuffers &b, con
     if (p.render_mode == 2) render_range<false>(c, L, k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
     else render_range<true>(c, L, k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
   } else render_range_fast<MONO>(c, reinterpret_cast<double *>(ra_smem_syn) + (size_t)wy * Ppad * (MONO ? TROW_MONO : TROW), k, p, s, l, seg_begin, seg_end,
-                                 sp.t0, sp.n, mix, out, out_d, b.error_flags, clk);
+                                 sp.t0, sp.n, mix, out, out_d, b.error_flags,
+                                 b.fb_block ? b.fb_block + (size_t)s * sp.n : nullptr, clk);
   if (clk.dst) { // workgroup lifetime: maximum and a histogram in steps of 200 k ticks
     const unsigned long long d = __builtin_readcyclecounter() - wg_t0;
     atomicMax(clk.dst + 39, d);

@@ -13,8 +13,7 @@
 // The JSON reader below covers what nlohmann::json reads for these files: objects, strings, numbers, booleans, null, arrays.
 // Keys of this path that the GPU build does not implement are carried through read/write unchanged and listed by
 // unsupported_keys(): the vocoder *carrier synth* volumes (the carrier here is the job's carrier file), the envelope follower
-// ratio (time-domain vocoder variant), pitch_wheel_multiplier (MIDI), analysis_output_feedback_gain / output_delay_seconds
-// (feedback of the output into the analysis input: only gain 0 is supported; a non-zero gain throws).
+// ratio (time-domain vocoder variant), pitch_wheel_multiplier (MIDI).
 #pragma once
 #include <cctype>
 #include <cstdint>
@@ -249,7 +248,7 @@ inline const std::vector<std::string> &unsupported_keys() {
   static const std::vector<std::string> k = {
       "pitch_wheel_multiplier", "vocoder_carrier_noise_volume", "vocoder_carrier_saw_volume", "vocoder_carrier_triangle_volume",
       "vocoder_carrier_square_volume", "vocoder_carrier_sine_volume", "vocoder_carrier_pulse_volume", "vocoder_carrier_pulse_width",
-      "vocoder_env_follower_cutoff_ratio", "analysis_output_feedback_gain", "output_delay_seconds"};
+      "vocoder_env_follower_cutoff_ratio"};
   return k;
 }
 
@@ -310,9 +309,8 @@ inline void apply_preset(const Preset &p, ra_config &cfg) {
   read_param(p.float_params, "vocoder_volume", cfg.vocoder_volume);
   read_param(p.float_params, "analysis_volume", cfg.analysis_volume);
   read_param(p.float_params, "analysis_input_gain", cfg.analysis_input_gain);
-  auto fb = p.float_params.find("analysis_output_feedback_gain");
-  if (fb != p.float_params.end() && fb->second != 0.f)
-    throw std::runtime_error("preset: analysis_output_feedback_gain != 0 (feedback of the output into the analysis, lib.cpp:1626-1652) is not supported");
+  read_param(p.float_params, "analysis_output_feedback_gain", cfg.analysis_output_feedback_gain);
+  read_param(p.float_params, "output_delay_seconds", cfg.output_delay_seconds);
 }
 
 // RtResynth::saveAsPreset (lib.cpp:1941-2041).  `carry` supplies the values of the keys this build does not interpret
@@ -367,8 +365,8 @@ inline Preset save_as_preset(const ra_config &cfg, const Preset *carry = nullptr
   p.float_params["vocoder_volume"] = cfg.vocoder_volume;
   p.float_params["analysis_volume"] = cfg.analysis_volume;
   p.float_params["analysis_input_gain"] = cfg.analysis_input_gain;
-  p.float_params["analysis_output_feedback_gain"] = 0.f;
-  p.float_params["output_delay_seconds"] = carried("output_delay_seconds", 1.f);
+  p.float_params["analysis_output_feedback_gain"] = cfg.analysis_output_feedback_gain;
+  p.float_params["output_delay_seconds"] = cfg.output_delay_seconds;
   return p;
 }
 

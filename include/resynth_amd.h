@@ -88,6 +88,14 @@ typedef struct ra_config {
    * sample-by-sample stepping at rounding level (~1e-13).  1: one sample-serial launch per stream that follows the
    * reference's operation order exactly (slow; for bit-level comparisons). */
   int32_t reference_order;
+
+  /* Feedback of the output into the analysis input (analyze_until_input_starvation, lib.cpp:1626-1652): analysis input k =
+   * analysis_input_gain * voice[k] + analysis_output_feedback_gain * mono_out[k - 1 - delay], delay = int(0.5 + output_delay_seconds *
+   * sample_rate) frames, mono_out = float(L + R) of the final mix.  With a non-zero gain a block is processed in sequential pieces of
+   * delay / stride + 1 analysis frames (the analysis of a piece needs the output of the pieces before it): correct for any delay, fast
+   * only for delays of many strides (the reference default is 1 s).  Not available with reference_order != 0. */
+  float analysis_output_feedback_gain; /* 0 */
+  float output_delay_seconds;          /* 1 */
 } ra_config;
 
 typedef struct ra_context ra_context;

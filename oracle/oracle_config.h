@@ -60,6 +60,10 @@ typedef struct ora_config {
   /* declared policy replacing the reference's unpinned mersenne<> engines */
   int32_t phase_policy;
   uint64_t seed;
+
+  /* feedback of the (mono) output into the analysis input, lib.cpp:1626-1652 */
+  float analysis_output_feedback_gain; /* 0 */
+  float output_delay_seconds;          /* 1 */
 } ora_config;
 
 #ifdef __cplusplus

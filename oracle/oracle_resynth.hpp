@@ -42,6 +42,8 @@ inline ora_config default_config() { // lib.cpp:943-999
   c.vocoder_volume = 0.f;
   c.analysis_volume = 0.f;
   c.analysis_input_gain = 1.f;
+  c.analysis_output_feedback_gain = 0.f;
+  c.output_delay_seconds = 1.f;
   c.phase_policy = ORA_PHASE_HASH;
   c.seed = 0;
   return c;
@@ -247,6 +249,11 @@ struct RtResynthOffline {
   // the current modulator / carrier samples, handed to the vocoder compute (lib.cpp:1397-1418)
   double cur_voice = 0, cur_carrier = 0;
   bool enable_vocoder = true;
+  // output -> analysis feedback (lib.cpp:1626-1652): the last published mono sample and the cyclic delay line (L0 `cyclic<float>`: a ring
+  // whose cycleEnd() is the oldest element and whose feed() overwrites it)
+  float last_published = 0.f;
+  std::vector<float> output_delay;
+  int delay_pos = 0;
 
   explicit RtResynthOffline(ora_config const &c) : cfg(c), synth(c.n_channels) {
     synth.phase_policy = c.phase_policy;
@@ -265,6 +272,9 @@ struct RtResynthOffline {
         return true;
       });
     });
+    stepper.post = [this](double *buf, int frames) { // init_post, lib.cpp:1262-1272 (post "none": only the mono publication)
+      for (int i = 0; i < frames; ++i) last_published = static_cast<float>(buf[2 * i] + buf[2 * i + 1]);
+    };
     periodic_fft.op.window_kind = c.window_kind;
     periodic_fft.setup(c.window_size, c.stride, [this](int stride, SqMagOp const &op) {
       extract_local_max_freqs_mags(cfg.sample_rate, op.result, freqmags); // lib.cpp:1592-1595
@@ -341,8 +351,22 @@ struct RtResynthOffline {
       cur_voice = v; // read_direct_input: the float sample widened to double (lib.cpp:1073-1079)
       cur_carrier = carrier ? static_cast<double>(carrier[k]) : 0.0;
       if (k >= 2) {
+        // analyze_until_input_starvation, lib.cpp:1622-1652.  The aggregator's start-up synchronisation (pubsub.cpp:151-200) swallows
+        // input samples 0, 1 and output sample 0; from then on it pairs input sample k with output sample k - 1 (published by the post
+        // processor of the previous step as float(L + R), lib.cpp:1262-1272, pubsub.cpp:92).
         float sum = 0.f;
-        sum += cfg.analysis_input_gain * v; // lib.cpp:1626,1636
+        sum += cfg.analysis_input_gain * v; // :1636
+        {
+          int const sz = std::max(0, static_cast<int>(0.5f + cfg.output_delay_seconds * cfg.sample_rate)); // :1638-1639
+          if (static_cast<int>(output_delay.size()) != sz) { output_delay.assign(sz, 0.f); delay_pos = 0; } // resize zeroes, :1640-1642
+          float const o = last_published;
+          if (sz) {
+            float const value = output_delay[delay_pos]; // *cycleEnd(): the oldest element
+            sum += cfg.analysis_output_feedback_gain * value;
+            output_delay[delay_pos] = o;                 // feed()
+            delay_pos = (delay_pos + 1) % sz;
+          } else sum += cfg.analysis_output_feedback_gain * o;
+        }
         periodic_fft.feed(sum);
       }
       stepper.step(out + 2 * k, 1);

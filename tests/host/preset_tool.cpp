@@ -28,6 +28,7 @@ static void dump(const ra_config &c) {
               c.vocoder_modulator_window_size_seconds, c.vocoder_stride_seconds, c.vocoder_count_bands, c.vocoder_min_freq, c.vocoder_max_freq);
   std::printf("voice_volume %.9g\ncarrier_volume %.9g\nvocoder_volume %.9g\nanalysis_volume %.9g\nanalysis_input_gain %.9g\n", c.voice_volume,
               c.carrier_volume, c.vocoder_volume, c.analysis_volume, c.analysis_input_gain);
+  std::printf("analysis_output_feedback_gain %.9g\noutput_delay_seconds %.9g\n", c.analysis_output_feedback_gain, c.output_delay_seconds);
 }
 
 int main(int argc, char **argv) {

@@ -34,6 +34,7 @@ class OraConfig(C.Structure):
         ("voice_volume", C.c_float), ("carrier_volume", C.c_float), ("vocoder_volume", C.c_float),
         ("analysis_volume", C.c_float), ("analysis_input_gain", C.c_float),
         ("phase_policy", C.c_int32), ("seed", C.c_uint64),
+        ("analysis_output_feedback_gain", C.c_float), ("output_delay_seconds", C.c_float),
     ]
 
 

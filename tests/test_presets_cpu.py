@@ -68,7 +68,7 @@ def test_missing_key_keeps_the_current_value_and_is_reported(tool, tmp_path):
     assert float(kv(r.stdout)["min_volume"]) == pytest.approx(1e-4, rel=1e-6)              # ra_default_config's value
 
 
-def test_missing_section_and_feedback_are_errors(tool, tmp_path):
+def test_missing_section_is_an_error_and_feedback_keys_map(tool, tmp_path):
     doc = json.load(open(os.path.join(GOLD, "preset_example.json")))
     bad = dict(doc)
     del bad["uint64_params"]                                              # Preset::fromjson uses json::at -> throws
@@ -77,9 +77,10 @@ def test_missing_section_and_feedback_are_errors(tool, tmp_path):
     r = subprocess.run([tool, "parse", str(p), "48000"], capture_output=True, text=True)
     assert r.returncode == 1 and "uint64_params" in r.stdout
     doc["float_params"]["analysis_output_feedback_gain"] = 0.5
+    doc["float_params"]["output_delay_seconds"] = 0.25
     p.write_text(json.dumps(doc))
-    r = subprocess.run([tool, "parse", str(p), "48000"], capture_output=True, text=True)
-    assert r.returncode == 1 and "feedback" in r.stdout
+    out = kv(subprocess.check_output([tool, "parse", str(p), "48000"], stderr=subprocess.DEVNULL).decode())
+    assert float(out["analysis_output_feedback_gain"]) == 0.5 and float(out["output_delay_seconds"]) == 0.25
 
 
 def test_preset_round_trip_and_key_set(tool, tmp_path):
