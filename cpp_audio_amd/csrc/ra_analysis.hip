@@ -569,7 +569,7 @@ void ra_launch_analysis(const RaParams &p, const RaBuffers &b, const float *d_vo
   size_t lds = ra_analysis_lds_bytes(p);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void *>(ra_analysis_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_analysis_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   hipLaunchKernelGGL(ra_analysis_kernel, grid, dim3(RA_ANALYSIS_THREADS), lds, st, p, b, d_voice, t0, n, f_lo, (int)fb0, (int)nfb_total);

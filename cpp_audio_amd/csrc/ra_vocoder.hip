@@ -163,7 +163,7 @@ __global__ void ra_voc_mix_kernel(RaParams p, RaBuffers b, const float *__restri
 __global__ void ra_voc_roll_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, const float *__restrict__ carrier, int64_t n, int64_t i_lo,
                                    int64_t n_car, int64_t n_mod) {
   const int s = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
-  const int S = p.voc_S, W = 2 * p.voc_S, Wm = p.voc_Wm, B = p.voc_bands;
+  const int W = 2 * p.voc_S, Wm = p.voc_Wm, B = p.voc_bands;
   double *tmp = reinterpret_cast<double *>(ra_smem_voc); // >= max(2*W doubles, Wm floats)
   // carrier frames: new prev = frames (i_hi - 1, i_hi) where i_hi = i_lo + n_car - 1
   if (n_car > 0) {
@@ -209,9 +209,9 @@ void ra_launch_vocoder(const RaParams &p, const RaBuffers &b, const float *d_voi
   RaFrameRange car = ra_frames_firing(W, S, t0, n);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_modulator_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_carrier_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_roll_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_modulator_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_carrier_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_roll_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   if (mod.count > 0)
