@@ -16,6 +16,12 @@ extern __shared__ __align__(16) unsigned char ra_smem[];
 
 __host__ __device__ inline int ra_list_capacity(const RaParams &p) { return (p.harm_pre != 0.f || p.harm_post != 0.f) ? 2 * p.maxr : p.maxr; }
 
+// tuning aid: -DRA_X_STOP=n ends the analysis kernel after phase n (instruction-count ablations with scripts/pmc_probe.sh); 0 = off
+#ifndef RA_X_STOP
+#define RA_X_STOP 0
+#endif
+#define RA_STOP_AFTER(n) do { if (RA_X_STOP == (n)) return; } while (0)
+
 namespace {
 
 __device__ inline double sqmag_to_db(double x) { return 10.0 * log10(x > 1e-300 ? x : 1e-300); }
@@ -195,9 +201,27 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
       const double w = b.half_window[j];
       return i < N ? x * w : 0.0;
     };
-    ra_fft_fused(z, M, p.log2M, b.tw_half, tid, T, [&](int k) { return make_double2(sample(2 * k), sample(2 * k + 1)); });
+    // Usual case (the window lies inside the block, no zero padding, no feedback): one address computation per pair — samples 2k and
+    // 2k + 1 sit on the same side of the window's centre, so their weights are one aligned 16-byte load of the half-window table.
+    const bool plain = vs && !fb_on && p.L == N && start >= t0 && (N & 3) == 0; // workgroup-uniform
+    if (plain) {
+      const float *w0 = vs + (start - t0);
+      const double2 *hw2 = reinterpret_cast<const double2 *>(b.half_window);
+      ra_fft_fused(z, M, p.log2M, b.tw_half, tid, T, [&](int k) {
+        const int i0 = 2 * k;
+        const float v0 = w0[i0], v1 = w0[i0 + 1];
+        const bool upper = i0 >= h;
+        const double2 ww = hw2[upper ? (i0 - h) >> 1 : (h - 2 - i0) >> 1]; // upper: (w[j], w[j + 1]); lower: (w[j1 - 1], w[j1]) mirrored
+        float s0 = 0.f, s1 = 0.f;
+        s0 += p.input_gain * v0; s1 += p.input_gain * v1; // lib.cpp:1626,1636 (float)
+        return make_double2((double)s0 * (upper ? ww.x : ww.y), (double)s1 * (upper ? ww.y : ww.x));
+      });
+    } else {
+      ra_fft_fused(z, M, p.log2M, b.tw_half, tid, T, [&](int k) { return make_double2(sample(2 * k), sample(2 * k + 1)); });
+    }
   }
   clk.mark(1);
+  RA_STOP_AFTER(1);
 
   // ---- 3. split into the real spectrum, |X|^2 written over .x of the same slots -------------------
   // X[k] = E[k] + W^k O[k],  E = (Z[k] + conj Z[M-k]) / 2,  O = -i/2 (Z[k] - conj Z[M-k]);  bins 0..M-1 kept
@@ -225,6 +249,7 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   }
   __syncthreads();
   clk.mark(2);
+  RA_STOP_AFTER(2);
   if (b.dbg_sqmag) {
     double *dst = b.dbg_sqmag + ((size_t)s * nfb_total + fb) * M;
     for (int k = tid; k < M; k += T) dst[k] = Z(k).x;
@@ -265,13 +290,14 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
       double mag_db = db - 0.25 * (da - dc) * pp;
       // frequencies_to_pitches, algo.cpp:10-29 with midi.h:223-232 (f > 0 always holds here: i >= 1, pp > -1/2)
       double pitch = 69.0 + (12 / 1.0) * log2(freq / (double)440.f);
-      double vol = pow(10.0, mag_db / 20.0);
+      double vol = exp10(mag_db / 20.0); // DbToMag: 10^(dB / 20)
       Z(pk).y = pitch;        // slot pk held this peak's bin: read above by this thread only
       Z(Mh + pk).y = vol;     // Mh + pk > K - 1: never a bin slot
     }
   }
   __syncthreads();
   clk.mark(4);
+  RA_STOP_AFTER(4);
 
   // ---- 5. aggregate_pitches + reduce_pitches (algo.cpp:124-184, PonderateByVolume / SumVolumes) -------------------
   // Pitches ascend, so an interval opened at peak i0 runs up to the first peak j with pitch[j] - pitch[i0] > nearby:
@@ -331,6 +357,7 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   }
   __syncthreads();
   clk.mark(6);
+  RA_STOP_AFTER(6);
   const int R = scan[T];
   const int chunkR = (R + T - 1) / T;
   const int r0 = min(R, tid * chunkR), r1 = min(R, r0 + chunkR);
@@ -354,6 +381,7 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   }
   __syncthreads();
   clk.mark(7);
+  RA_STOP_AFTER(7);
 
   // ---- 6. shift / harmonize / autotune on the reduced list ---------------------------------------------------------
   // The autotune function (divisions, scale / chord searches) is evaluated for all items at once; one lane then runs the
