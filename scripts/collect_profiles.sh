@@ -22,6 +22,6 @@ python scripts/pmc_aggregate.py $OUT > $OUT/aggregate.log 2>&1
 tail -3 $OUT/aggregate.log
 # keep the merge-back small: drop the raw per-dispatch CSVs, keep the summaries
 find $OUT -name "*_agent_info.csv" -delete
-find $OUT/pmc_* -name "*.csv" -delete 2>/dev/null
+# (the per-dispatch counter CSVs are small: kept, so that the aggregation can be redone)
 find $OUT/stats -name "*kernel_trace.csv" -delete 2>/dev/null
 ls $OUT

@@ -15,13 +15,20 @@ def short(name):
 
 
 kern = {}
+STAGE = {"ra_analysis_kernel": "analysis", "ra_track_kernel": "track", "ra_synth_propagate_kernel": "propagate", "ra_synth_render_mono_kernel": "render",
+         "ra_synth_render_kernel": "render", "ra_roll_history_kernel": "history"}
+try:
+    LAUNCHES = json.load(open(os.path.join(out, "bench.json")))["kernel_launches_per_step"]
+except Exception:
+    LAUNCHES = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
     files = glob.glob(os.path.join(out, "pmc_" + ctr, "**", "*counter_collection.csv"), recursive=True)
     if not files:
         print("no counter file for", ctr)
         continue
     rows = list(csv.DictReader(open(files[0])))
-    # one row per dispatch (and counter); the bench ran warmup 1 + steps 1: keep the second half of each kernel's dispatches
+    # one row per dispatch (and counter).  The bench ran its set-up block, 1 warm-up step and 1 timed step: keep the dispatches of the
+    # timed step = the last kernel_launches_per_step[stage] of each kernel (from the bench line collected beside this)
     per = {}
     for r in rows:
         k = short(r["Kernel_Name"])
@@ -29,10 +36,11 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
             per.setdefault(k, []).append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
     for k, lst in per.items():
         lst.sort()
-        half = lst[len(lst) // 2:]
+        nl = int(round(LAUNCHES.get(STAGE[k], len(lst) // 2))) or 1
+        last = lst[-nl:]
         d = kern.setdefault(k, {})
-        d[ctr if ctr == "SQ_INSTS_VALU" else ctr + "_KB"] = sum(v for _, v in half)
-        d["launches"] = len(half)
+        d[ctr if ctr == "SQ_INSTS_VALU" else ctr + "_KB"] = sum(v for _, v in last)
+        d["launches"] = len(last)
 doc = {
     "collected_with": "rocprofv3 --kernel-trace --pmc <one counter per run: FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU> -- python3 bench.py --steps 1 "
                       "--warmup 1 --no-cpu-baseline ; sums over the launches of the timed step (scripts/collect_profiles.sh, scripts/pmc_aggregate.py)",
