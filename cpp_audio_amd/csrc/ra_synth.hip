@@ -206,7 +206,11 @@ __device__ inline double lane_ror8(double x) { // value of lane (i + 8) mod 16 o
   return __hiloint2double(hi, lo);
 }
 
-constexpr int TD = 8;            // tile depth of the regime renderer
+#ifndef RA_TILE_DEPTH
+#define RA_TILE_DEPTH 16 // samples per tile: 8 or 16 (the per-tile set-up and the channel sums are amortised over them)
+#endif
+constexpr int TD = RA_TILE_DEPTH; // tile depth of the regime renderer
+static_assert(TD == 8 || TD == 16, "tile depth");
 constexpr int TROW = 2 * TD + 1; // its LDS tile is lane-major: [Ppad][TROW] doubles, entry out * TD + frame (odd row length: conflict-free both ways)
 constexpr int TROW_MONO = TD + 1; // stereo_spread 0: every channel has the same two gains, applied after the channel sum
 
@@ -215,7 +219,7 @@ constexpr int TROW_MONO = TD + 1; // stereo_spread 0: every channel has the same
 // HI: some gliding lane passes above fs/8, where the anti-aliasing gain follows the increment.
 // The phasor is renormalised once per tile instead of once per step (drift < 1e-15 per tile; every hop restarts from the angle).
 #ifndef RA_TILE_UNROLL
-#define RA_TILE_UNROLL 8 // measured on configs[1]: 8 (straight-line tile) 14.9 ms, 1 (rolled) 15.4 ms, 2: 16.5 ms per step
+#define RA_TILE_UNROLL 16 // (tile depth 8: measured on configs[1]: 8 (straight-line tile) 14.9 ms, 1 (rolled) 15.4 ms, 2: 16.5 ms per step)
 #endif
 #define RA_PRAGMA(x) _Pragma(#x)
 #define RA_UNROLL(n) RA_PRAGMA(unroll n)
@@ -287,8 +291,10 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
   constexpr int ROW = MONO ? TROW_MONO : TROW;
   double *mine = tile + l * ROW;                                                // this lane's row
   // reduction role of lanes 0..63: frame fr of output ch over a quarter of the channels (MONO: frame fr over an eighth)
-  const int fr = l & (TD - 1), ch = (l >> 3) & 1, part = MONO ? (l >> 3) & 7 : (l >> 4) & 3;
-  const double *col = MONO ? tile + (part * (Ppad >> 3)) * ROW + fr : tile + (part * (Ppad >> 2)) * ROW + ch * TD + fr;
+  // the 64 reducing lanes: output value o (frame fr of channel ch; entries of a row are laid out [ch][fr]) over one of NPART channel groups
+  constexpr int NOUT = MONO ? TD : 2 * TD, NPART = 64 / NOUT;
+  const int o = l & (NOUT - 1), fr = o & (TD - 1), ch = o / TD, part = (l & 63) / NOUT;
+  const double *col = tile + (part * (Ppad / NPART)) * ROW + o;
   double gLm = 0.0, gRm = 0.0;
   if (MONO) { const double ang = (0.25 * M_PI) * (0.0 + 1.); gLm = cos(ang); gRm = sin(ang); } // stereo(0), stereo.h:18-27, as at note-on
 
@@ -342,7 +348,7 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
     // reciprocal, two Newton steps).  A tile in which the increment crosses 1/4 or 1 is not clean (the checked step evaluates the function).
     double al0 = c.alias, al_da = 0.0, al_dda = 0.0;
     if (clean && r.active && r.gliding && r.hi) {
-      const double f0 = fma(r.slope, c.cur, r.base), df = r.slope * step0, f7 = fma((double)(TD - 1), df, f0);
+      const double f0 = fma(r.slope, c.cur, r.base), df = r.slope * step0, f7 = fma((double)(TD - 1), df, f0); // first and last increment of the tile
       const double flo = f0 < f7 ? f0 : f7, fhi = f0 < f7 ? f7 : f0;
       double rf = r.rf * fma(-f0, r.rf, 2.0);
       rf = rf * fma(-f0, rf, 2.0);
@@ -405,37 +411,37 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
       clk.lap<1>();
     }
     if (Ppad > 64) __syncthreads(); // one wave: its LDS operations execute in order, no barrier needed
-    if (l < 64) { // 16 outputs (8 frames x 2) x 4 channel quarters; MONO: 8 sums x 8 channel eighths
+    if (l < 64) { // NOUT outputs x NPART channel groups
       double acc = 0.0;
       if (fr < m) {
         const double *q = col;
-        constexpr int NJ = MONO ? 8 : 16;
+        constexpr int NJ = 64 / NPART; // channels of a group per 64-channel block
         for (int blk = 0; blk < (Ppad >> 6); ++blk, q += NJ * ROW) {
 #pragma unroll
           for (int j = 0; j < NJ; ++j) acc += q[j * ROW];
         }
       }
       acc += lane_xor32_low(acc);
-      acc += lane_xor16_even(acc);
+      if (NPART >= 4) acc += lane_xor16_even(acc);
+      if (NPART >= 8) acc += lane_ror8(acc);
       if (MONO) {
-        acc += lane_ror8(acc);
-        if (l < 8 && fr < m) {
+        if (l < NOUT && fr < m) {
           const int64_t rel = (t - t0) + fr;
           double oL = gLm * acc, oR = gRm * acc;
           if (mix) { oL += mix[rel]; oR += mix[rel]; }
           if (out) { // one 8-byte store per frame when the caller's buffer allows it (two 4-byte stores make partial-line writes)
-            float *o = out + ((size_t)s * n + rel) * 2;
-            if ((reinterpret_cast<uintptr_t>(out) & 7) == 0) *reinterpret_cast<float2 *>(o) = make_float2((float)oL, (float)oR);
-            else { o[0] = (float)oL; o[1] = (float)oR; }
+            float *op = out + ((size_t)s * n + rel) * 2;
+            if ((reinterpret_cast<uintptr_t>(out) & 7) == 0) *reinterpret_cast<float2 *>(op) = make_float2((float)oL, (float)oR);
+            else { op[0] = (float)oL; op[1] = (float)oR; }
           }
           if (out_d) { out_d[((size_t)s * n + rel) * 2] = oL; out_d[((size_t)s * n + rel) * 2 + 1] = oR; }
           if (fb_mono) fb_mono[rel] = (float)(oL + oR); // what the post processor publishes to the analysis (lib.cpp:1262-1272, pubsub.cpp:92)
         }
       } else {
-        const bool w = l < 16 && fr < m;
+        const bool w = l < NOUT && fr < m;
         const int64_t rel = (t - t0) + fr;
         if (w && mix) acc += mix[rel];
-        const double other = lane_ror8(acc); // the other output channel of the same frame
+        const double other = (TD == 8) ? lane_ror8(acc) : lane_xor16_even(acc); // the other output channel of the same frame (lane +- TD)
         if (w) {
           if (out) out[((size_t)s * n + rel) * 2 + ch] = (float)acc;
           if (out_d) out_d[((size_t)s * n + rel) * 2 + ch] = acc;

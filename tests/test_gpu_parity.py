@@ -403,7 +403,7 @@ def test_overlapped_blocks_equal_stream_ordered_blocks(api, sig):
     assert np.array_equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("delay_s,gain,seconds", [(0.05, 0.15, 1.0), (0.0, 0.3, 0.4), (1.0, 0.8, 2.5), (0.0123, -0.15, 0.8)])
+@pytest.mark.parametrize("delay_s,gain,seconds", [(0.05, 0.15, 1.0), (0.0, 0.1, 0.3), (1.0, 0.8, 2.5), (0.0123, -0.15, 0.8)])
 def test_output_feedback_into_the_analysis(api, oracle, sig, delay_s, gain, seconds):
     # analyze_until_input_starvation (lib.cpp:1626-1652): analysis input k = gain_in * voice[k] + gain_fb * mono_out[k - 1 - delay].
     # The GPU path runs the block in sequential pieces of delay / stride + 1 analysis frames.
