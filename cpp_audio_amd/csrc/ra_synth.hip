@@ -19,6 +19,7 @@
 #include "ra_chan.cuh"
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 extern __shared__ __align__(16) unsigned char ra_smem_syn[];
 
@@ -214,7 +215,7 @@ static_assert(TD == 8 || TD == 16, "tile depth");
 constexpr int TROW = 2 * TD + 1; // its LDS tile is lane-major: [Ppad][TROW] doubles, entry out * TD + frame (odd row length: conflict-free both ways)
 constexpr int TROW_MONO = TD + 1; // stereo_spread 0: every channel has the same two gains, applied after the channel sum
 
-// TD steps of a lane whose wave has no transition inside the tile: straight-line code, no state machine.
+// LEN steps (a whole tile, or half of one) of a lane whose wave has no transition inside them: straight-line code, no state machine.
 // GLIDE: some lane of the wave glides (the others run the same code with the identity rotation, alpha = 1, beta = 0);
 // HI: some gliding lane passes above fs/8, where the anti-aliasing gain follows the increment.
 // The phasor is renormalised once per tile instead of once per step (drift < 1e-15 per tile; every hop restarts from the angle).
@@ -223,7 +224,7 @@ constexpr int TROW_MONO = TD + 1; // stereo_spread 0: every channel has the same
 #endif
 #define RA_PRAGMA(x) _Pragma(#x)
 #define RA_UNROLL(n) RA_PRAGMA(unroll n)
-template <bool GLIDE, bool HI, bool KVAR, bool MONO>
+template <int LEN, bool GLIDE, bool HI, bool KVAR, bool MONO>
 __device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, double cd0, double sd0, double cd, double sd, double al_da, double al_dda,
                                   double *mine) {
   double cur = c.cur, mre = c.mre, mim = c.mim, cre = c.cre, cim = c.cim, y = c.y, value = c.value, alias = c.alias, f = c.inc;
@@ -265,10 +266,10 @@ __device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, dou
   auto put = [&](int i, double v) { if (MONO) mine[i] = v; else { mine[i] = c.gL * v; mine[TD + i] = c.gR * v; } };
   put(0, step(cd0, sd0));
   RA_UNROLL(RA_TILE_UNROLL)
-  for (int i = 1; i < TD; ++i) put(i, step(cd, sd));
+  for (int i = 1; i < LEN; ++i) put(i, step(cd, sd));
   const double g = 0.5 * (3.0 - fma(cre, cre, cim * cim));
   c.cre = cre * g; c.cim = cim * g;
-  c.y = y; c.vol = y; c.value = HI ? value : fma((double)TD, r.dv, value);
+  c.y = y; c.vol = y; c.value = HI ? value : fma((double)LEN, r.dv, value);
   if (GLIDE) {
     c.mre = mre; c.mim = mim; c.cur = cur; c.alias = HI ? a_used : alias;
     if (r.gliding) { c.fres = f; c.inc = f; }
@@ -336,20 +337,23 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
   };
   if (__any(r.active && r.irregular)) atomicOr(b_error_flags, RA_ERR_BOOKKEEPING); // see regime_setup
 
-  while (t < seg_end) {
-    const int m = (int)min((int64_t)TD, seg_end - t);
-    // a tile is clean for a lane if no transition can fall inside it: then the loop needs no per-sample checks
+  // LEN consecutive samples of the tile, written to row entries off .. off + LEN - 1.  If no lane has a transition inside them they take
+  // the straight-line code; otherwise (when allowed) every sample is a checked step.  Returns whether the samples were produced.
+  auto span = [&](auto len_tag, int off, bool allow_checked) -> bool {
+    constexpr int LEN = decltype(len_tag)::value;
+    double *row = mine + off;
+    // a span is clean for a lane if no transition can fall inside it: then the loop needs no per-sample checks
     double step0 = 0.0;
-    if (r.active && r.gliding) step0 = fma(r.alpha - 1.0, c.cur, r.beta); // cur increment of the tile's first step
-    bool clean = !r.active || (!stepped0 && r.steps_left >= TD &&
-                               (!r.gliding || (fabs(r.alpha - 1.0) < 1e-2 && c.cur + (TD - 1) * fabs(step0) * 1.1 <= lim)));
+    if (r.active && r.gliding) step0 = fma(r.alpha - 1.0, c.cur, r.beta); // cur increment of the span's first step
+    bool clean = !r.active || (!stepped0 && r.steps_left >= LEN &&
+                               (!r.gliding || (fabs(r.alpha - 1.0) < 1e-2 && c.cur + (LEN - 1) * fabs(step0) * 1.1 <= lim)));
     // Anti-aliasing gain of a glide above fs/8, (1 / inc - 1) / 3 between inc = 1/4 and 1 (freqAliasingMultiplicator, audioelement.h:466-483):
-    // over a tile it is followed by its value and first two forward differences at the tile's first increment (1 / inc from the running
-    // reciprocal, two Newton steps).  A tile in which the increment crosses 1/4 or 1 is not clean (the checked step evaluates the function).
+    // over a span it is followed by its value and first two forward differences at the span's first increment (1 / inc from the running
+    // reciprocal, two Newton steps).  A span in which the increment crosses 1/4 or 1 is not clean (the checked step evaluates the function).
     double al0 = c.alias, al_da = 0.0, al_dda = 0.0;
     if (clean && r.active && r.gliding && r.hi) {
-      const double f0 = fma(r.slope, c.cur, r.base), df = r.slope * step0, f7 = fma((double)(TD - 1), df, f0); // first and last increment of the tile
-      const double flo = f0 < f7 ? f0 : f7, fhi = f0 < f7 ? f7 : f0;
+      const double f0 = fma(r.slope, c.cur, r.base), df = r.slope * step0, fl = fma((double)(LEN - 1), df, f0); // first and last increment
+      const double flo = f0 < fl ? f0 : fl, fhi = f0 < fl ? fl : f0;
       double rf = r.rf * fma(-f0, r.rf, 2.0);
       rf = rf * fma(-f0, rf, 2.0);
       r.rf = rf;
@@ -362,19 +366,19 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
         al_dda = 2.0 * q;
       } else clean = false;
     }
-    if (m == TD && __all(clean)) {
+    if (__all(clean)) {
       const bool any_glide = __any(r.active && r.gliding);
       if (r.active) {
         c.alias = al0; // (its own value for lanes whose gain does not move)
-        if (!any_glide) { clk.tally<0>(); clean_tile<false, false, false, MONO>(c, r, k.max_filter_inc, 1.0, 0.0, 1.0, 0.0, 0.0, 0.0, mine); }
+        if (!any_glide) { clk.tally<0>(); clean_tile<LEN, false, false, false, MONO>(c, r, k.max_filter_inc, 1.0, 0.0, 1.0, 0.0, 0.0, 0.0, row); }
         else {
-          // Rotation of `mult` per step while gliding: pi (inc_i - inc_{i-1}).  The tile's first step turns by d0 = pi (inc_0 - inc),
+          // Rotation of `mult` per step while gliding: pi (inc_i - inc_{i-1}).  The span's first step turns by d0 = pi (inc_0 - inc),
           // whatever the oscillator's increment currently is (0 right after a note change); the later steps turn by
           // pi slope (cur_i - cur_{i-1}), a geometric sequence with ratio alpha (|alpha - 1| ~ 1e-5): their mean serves all of them.
           double cd0 = 1.0, sd0 = 0.0, cd = 1.0, sd = 0.0;
           if (r.gliding) {
             const double d0 = M_PI * (fma(r.slope, c.cur, r.base) - c.inc);
-            const double dA = (M_PI * r.slope) * step0 * (1.0 + 0.5 * (TD - 2) * (r.alpha - 1.0));
+            const double dA = (M_PI * r.slope) * step0 * (1.0 + 0.5 * (LEN - 2) * (r.alpha - 1.0));
             double d2 = d0 * d0;
             sd0 = d0 * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
             cd0 = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
@@ -383,26 +387,50 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
             cd = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
           }
           if (__any(r.active && r.kvar)) clk.tally<3>(); else if (__any(r.active && r.gliding && r.hi)) clk.tally<2>(); else clk.tally<1>();
-          if (__any(r.active && r.kvar)) clean_tile<true, true, true, MONO>(c, r, k.max_filter_inc, cd0, sd0, cd, sd, al_da, al_dda, mine);
-          else if (__any(r.active && r.gliding && r.hi)) clean_tile<true, true, false, MONO>(c, r, k.max_filter_inc, cd0, sd0, cd, sd, al_da, al_dda, mine);
-          else clean_tile<true, false, false, MONO>(c, r, k.max_filter_inc, cd0, sd0, cd, sd, 0.0, 0.0, mine);
-          // over the m' = TD - 1 later steps the even spread runs ahead of the exact (linearly growing) rotation by b (j+1)(m'-1-j)/2
+          if (__any(r.active && r.kvar)) clean_tile<LEN, true, true, true, MONO>(c, r, k.max_filter_inc, cd0, sd0, cd, sd, al_da, al_dda, row);
+          else if (__any(r.active && r.gliding && r.hi)) clean_tile<LEN, true, true, false, MONO>(c, r, k.max_filter_inc, cd0, sd0, cd, sd, al_da, al_dda, row);
+          else clean_tile<LEN, true, false, false, MONO>(c, r, k.max_filter_inc, cd0, sd0, cd, sd, 0.0, 0.0, row);
+          // over the m' = LEN - 1 later steps the even spread runs ahead of the exact (linearly growing) rotation by b (j+1)(m'-1-j)/2
           // at step j, b = pi slope step0 (alpha - 1); the oscillator has integrated that: take the sum b (m'-1) m' (m'+1) / 12 back out
-          const double dl = (M_PI * r.slope) * step0 * (r.alpha - 1.0) * ((TD - 2) * (TD - 1) * TD * (1.0 / 12.0));
+          const double dl = (M_PI * r.slope) * step0 * (r.alpha - 1.0) * ((LEN - 2) * (LEN - 1) * LEN * (1.0 / 12.0));
           const double re = fma(c.cim, dl, c.cre), im = fma(-c.cre, dl, c.cim);
           c.cre = re; c.cim = im;
         }
-        r.pending += TD; r.steps_left -= TD;
+        r.pending += LEN; r.steps_left -= LEN;
       } else {
 #pragma unroll
-        for (int i = 0; i < (MONO ? TD : 2 * TD); ++i) mine[i] = 0.0;
+        for (int i = 0; i < LEN; ++i) { row[i] = 0.0; if (!MONO) row[TD + i] = 0.0; }
       }
       clk.lap<0>();
-    } else {
+      return true;
+    }
+    if (!allow_checked) return false;
+    for (int i = 0; i < LEN; ++i) {
+      double v = 0.0;
+      if (r.active) {
+        if (stepped0) v = c.vol * ((c.alias * c.cim) * c.value); // already stepped (propagate kernel): StereoPanned::imag of the state as loaded
+        else v = checked_step();
+      }
+      stepped0 = false;
+      if (MONO) row[i] = v; else { row[i] = c.gL * v; row[TD + i] = c.gR * v; }
+    }
+    clk.lap<1>();
+    return true;
+  };
+
+  while (t < seg_end) {
+    const int m = (int)min((int64_t)TD, seg_end - t);
+    if (m == TD) {
+      // the whole tile in one go if it is clean; otherwise its two halves separately, so that one transition costs half a tile of checked steps
+      if (!span(std::integral_constant<int, TD>{}, 0, false)) {
+        span(std::integral_constant<int, TD / 2>{}, 0, true);
+        span(std::integral_constant<int, TD / 2>{}, TD / 2, true);
+      }
+    } else { // a partial tile at the end of a segment
       for (int i = 0; i < m; ++i) {
         double v = 0.0;
         if (r.active) {
-          if (stepped0) v = c.vol * ((c.alias * c.cim) * c.value); // already stepped (propagate kernel): StereoPanned::imag of the state as loaded
+          if (stepped0) v = c.vol * ((c.alias * c.cim) * c.value);
           else v = checked_step();
         }
         stepped0 = false;
