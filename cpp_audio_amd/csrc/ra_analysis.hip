@@ -10,6 +10,7 @@
 // as an M = L/2 point complex FFT in LDS (fp64, like the reference), |X|^2 overwrites the same LDS slots,
 // peaks are compacted in bin order and only the short autotuned pitch list goes back to HBM.
 #include "ra_fft.cuh"
+#include "ra_math.cuh"
 #include <algorithm>
 
 extern __shared__ __align__(16) unsigned char ra_smem[];
@@ -24,7 +25,7 @@ __host__ __device__ inline int ra_list_capacity(const RaParams &p) { return (p.h
 
 namespace {
 
-__device__ inline double sqmag_to_db(double x) { return 10.0 * log10(x > 1e-300 ? x : 1e-300); }
+__device__ inline double sqmag_to_db(double x) { return 10.0 * ra_log10(x > 1e-300 ? x : 1e-300); }
 
 // canonical lower_bound on .x of a double2 list (find_closest_pitch, rt.resynth.lib.autotune.cpp:189-218)
 __device__ inline int find_closest_x(const double2 *v, int n, double pitch) {
@@ -289,8 +290,8 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
       double freq = (i + pp) * bin_hz;
       double mag_db = db - 0.25 * (da - dc) * pp;
       // frequencies_to_pitches, algo.cpp:10-29 with midi.h:223-232 (f > 0 always holds here: i >= 1, pp > -1/2)
-      double pitch = 69.0 + (12 / 1.0) * log2(freq / (double)440.f);
-      double vol = exp10(mag_db / 20.0); // DbToMag: 10^(dB / 20)
+      double pitch = 69.0 + (12 / 1.0) * ra_log2(freq / (double)440.f);
+      double vol = ra_exp10(mag_db / 20.0); // DbToMag: 10^(dB / 20)
       Z(pk).y = pitch;        // slot pk held this peak's bin: read above by this thread only
       Z(Mh + pk).y = vol;     // Mh + pk > K - 1: never a bin slot
     }
