@@ -12,6 +12,7 @@
 #include "ra_fft.cuh"
 #include "ra_math.cuh"
 #include <algorithm>
+#include <cstdlib>
 
 extern __shared__ __align__(16) unsigned char ra_smem[];
 
@@ -121,10 +122,10 @@ __device__ inline float equal_loudness_db(const double *arr, const float *elv, d
   return ratio * elv[i] + (1.f - ratio) * elv[i - 1];
 }
 
-// exclusive prefix sum of one int per thread over the 256-thread workgroup: scan[tid] = sum of v over lower threads, scan[T] = total
-// (wave-level shuffles + 4 wave totals; scan needs T + 5 ints)
+// exclusive prefix sum of one int per thread over the T-thread workgroup: scan[tid] = sum of v over lower threads, scan[T] = total
+// (wave-level shuffles + T / 64 wave totals; scan needs T + 1 + T / 64 ints)
+template <int T>
 __device__ inline void block_exclusive_scan(int *scan, int v, int tid) {
-  constexpr int T = RA_ANALYSIS_THREADS;
   const int lane = tid & 63, w = tid >> 6;
   int x = v;
 #pragma unroll
@@ -138,7 +139,8 @@ __device__ inline void block_exclusive_scan(int *scan, int v, int tid) {
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(RA_ANALYSIS_THREADS)
+template <int T>
+__global__ void __launch_bounds__(T, (T >= 512 ? 4 : 1)) // 512 / 1024 threads: 4 waves per SIMD (<= 128 VGPRs), so that two 512-thread groups share a CU
 ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int64_t t0, int64_t n, int64_t f_lo, int fb0, int nfb_total) {
 #ifndef RA_ANALYSIS_PRIO
 #define RA_ANALYSIS_PRIO 0
@@ -150,16 +152,14 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   const int fb = fb0 + blockIdx.x; // frame index inside the block [t0, t0 + n): this launch covers frames fb0 .. fb0 + gridDim.x - 1
   const int s = blockIdx.y;
   const int64_t f = f_lo + fb;
-  const int M = p.M, N = p.N, T = RA_ANALYSIS_THREADS;
+  const int M = p.M, N = p.N;
 
-  double2 *z = reinterpret_cast<double2 *>(ra_smem);           // [ra_zpad_size(M)], element i lives in slot ra_zpad(i)
-  auto Z = [&](int i) -> double2 & { return z[ra_zpad(i)]; };
+  double2 *z = reinterpret_cast<double2 *>(ra_smem);           // [ra_zsize(M)], element i lives in slot ra_zslot(i, zs)
+  const int zs = ra_zshift(p.log2M);
+  auto Z = [&](int i) -> double2 & { return z[ra_zslot(i, zs)]; };
   const int cap = ra_list_capacity(p);                         // harmonize may double a list; otherwise maxr entries suffice
-  double2 *listA = z + ra_zpad_size(M);                        // [cap]
+  double2 *listA = z + ra_zsize(M);                        // [cap]
   double2 *listB = listA + cap;                                // [cap]
-  double *lds_loud_pitches = reinterpret_cast<double *>(listB + cap); // [29] ISO-226 pitches and, behind them as floats, the 60 phon row:
-  float *lds_loud_elv = reinterpret_cast<float *>(lds_loud_pitches + 29); // [29]   the loudness keys' binary search stays out of global memory
-  if (tid < 29) { lds_loud_pitches[tid] = b.loud_pitches[tid]; lds_loud_elv[tid] = b.loud_elv[tid]; } // visible after the FFT's barriers
   int *scan = reinterpret_cast<int *>(listA);                   // [T+1], aliases listA: consumed (K read) before the lists are written
 
   RaPhaseClock clk(b.dbg_clk, tid == 0);
@@ -268,7 +268,7 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
     double a = Z(i - 1).x, m = Z(i).x, c = Z(i + 1).x;
     cnt += (a < m && m >= c) ? 1 : 0;
   }
-  block_exclusive_scan(scan, cnt, tid);
+  block_exclusive_scan<T>(scan, cnt, tid);
   {
     int pos = scan[tid];
     for (int i = max(c0, 1); i < c1 && i + 1 < M; ++i) {
@@ -307,9 +307,9 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   //  5c each interval is summed by one thread in index order (the reference's summation order) and kept if its volume
   //     reaches min_volume; kept intervals are compacted in order with a block scan
   // pointer jumping needs two ints per peak beside the scan area (all inside the list region, which is idle until 5c)
-  const int area_ints = max(8 * cap, T + 8);
-  int *jump = scan + T + 16, *mark = jump + K;
-  const bool par = K > 0 && K <= 4 * T && T + 16 + 2 * K <= area_ints;
+  const int area_ints = max(8 * cap, T + 32);
+  int *jump = scan + T + 32, *mark = jump + K;
+  const bool par = K > 0 && K <= 4 * T && T + 32 + 2 * K <= area_ints;
   for (int i = tid; i < K; i += T) {
     const double pi0 = Z(i).y;
     int lo = i + 1, hi = K;
@@ -346,7 +346,7 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
     const int a0 = min(K, tid * c), a1 = min(K, a0 + c);
     int cntm = 0;
     for (int i = a0; i < a1; ++i) cntm += mark[i];
-    block_exclusive_scan(scan, cntm, tid);
+    block_exclusive_scan<T>(scan, cntm, tid);
     int posm = scan[tid];
     for (int i = a0; i < a1; ++i) if (mark[i]) Z(Mh + posm++).x = (double)i;
     if (tid == 0) Z(Mh + scan[T]).x = (double)K; // R <= K <= Mh - 1, so slot Mh + R exists; scan[T] = R stays for 5c
@@ -370,7 +370,7 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   {
     int kept = 0;
     for (int r = r0; r < r1; ++r) { double sv, spv; interval(r, sv, spv); kept += !(sv < p.min_volume) ? 1 : 0; }
-    block_exclusive_scan(scan, kept, tid);
+    block_exclusive_scan<T>(scan, kept, tid);
   }
   int pos = scan[tid];
   const int Rk = scan[T];
@@ -387,6 +387,12 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   // ---- 6. shift / harmonize / autotune on the reduced list ---------------------------------------------------------
   // The autotune function (divisions, scale / chord searches) is evaluated for all items at once; one lane then runs the
   // order-dependent merge of algo.cpp:191-229 over the precomputed values, and the harmonize steps when they are enabled.
+  // The ISO-226 pitches [29 doubles] and, behind them as floats, the 60 phon row [29]: the loudness keys' binary search (step 8) stays
+  // out of global memory.  They sit in the idle FFT buffer behind the scan area (from M = 512 up; smaller frames have LDS to spare and
+  // keep them behind the lists) — 360 bytes that would otherwise push an 8192-point frame over half a CU's LDS.
+  double *lds_loud_pitches = M >= 512 ? reinterpret_cast<double *>(z + 384) : reinterpret_cast<double *>(listB + cap);
+  float *lds_loud_elv = reinterpret_cast<float *>(lds_loud_pitches + 29);
+  if (tid < 29) { lds_loud_pitches[tid] = b.loud_pitches[tid]; lds_loud_elv[tid] = b.loud_elv[tid]; } // read after step 7's barriers
   int *pub = reinterpret_cast<int *>(z); // [0] = A, [1] = which list holds the result, [2] = Rn, [3] = input list, [4] = err, [5] = merge fallback, [6] = kept   (z is free now)
   if (tid == 0) {
     int err = Rk > cap ? 1 : 0;
@@ -458,7 +464,7 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
       const int a0 = min(Rn, tid * c), a1 = min(Rn, a0 + c);
       int cntk = 0;
       for (int i = a0; i < a1; ++i) cntk += (oth[i].y >= 0.0) ? 1 : 0;
-      block_exclusive_scan(mscan, cntk, tid);
+      block_exclusive_scan<T>(mscan, cntk, tid);
       int pk = mscan[tid];
       const int nk = mscan[T];
       for (int i = a0; i < a1; ++i) { const double2 e = oth[i]; if (e.y >= 0.0) cur[pk++] = e; } // cur was consumed before the barrier above
@@ -476,7 +482,7 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
         if (tj < tp || (joins && tj != tp)) bad = true;
       }
       if (bad) atomicOr(&pub[5], 1);
-      block_exclusive_scan(mscan, cntb, tid); // its barriers also publish pub[5]
+      block_exclusive_scan<T>(mscan, cntb, tid); // its barriers also publish pub[5]
       if (!pub[5]) {
         int pb = mscan[tid];
         A_par = mscan[T];
@@ -584,11 +590,21 @@ void ra_launch_roll_feedback(const RaParams &p, const RaBuffers &b, int64_t n, h
   hipLaunchKernelGGL(ra_roll_feedback_kernel, grid, dim3(256), 0, st, b, n);
 }
 
+// Threads per analysis workgroup.  The FFT buffer of a frame decides how many workgroups share a CU (160 KB of LDS): up to N = 4096 three
+// or more 256-thread groups fit; an 8192-point frame (70 KB + lists) is alone on its CU, so it brings 512 threads (two waves per SIMD —
+// one wave per SIMD issues fp64 at half the rate two reach, scripts/ubench/fp64_rate.hip).  RA_ANALYSIS_T overrides (tuning aid).
+int ra_analysis_threads(const RaParams &p) {
+  static const int forced = [] { const char *e = getenv("RA_ANALYSIS_T"); return e ? atoi(e) : 0; }();
+  if (forced == 256 || forced == 512 || forced == 1024) return forced;
+  return p.M >= 4096 ? 512 : 256;
+}
+
 size_t ra_analysis_lds_bytes(const RaParams &p) {
-  size_t m = (size_t)ra_zpad_size(p.M);
+  size_t m = (size_t)ra_zsize(p.M);
   size_t lists = 2 * (size_t)ra_list_capacity(p) * sizeof(double2);
-  size_t scan = (RA_ANALYSIS_THREADS + 8) * sizeof(int);
-  return m * sizeof(double2) + (lists > scan ? lists : scan) + 29 * (sizeof(double) + sizeof(float)) + 12;
+  size_t scan = ((size_t)ra_analysis_threads(p) + 32) * sizeof(int);
+  size_t tables = p.M >= 512 ? 0 : 29 * (sizeof(double) + sizeof(float)) + 12; // the loudness tables move into the FFT buffer from M = 512 up
+  return m * sizeof(double2) + (lists > scan ? lists : scan) + tables;
 }
 
 void ra_launch_analysis(const RaParams &p, const RaBuffers &b, const float *d_voice, int64_t t0, int64_t n, int64_t f_lo, int64_t fb0, int64_t nfb_chunk,
@@ -598,10 +614,16 @@ void ra_launch_analysis(const RaParams &p, const RaBuffers &b, const float *d_vo
   size_t lds = ra_analysis_lds_bytes(p);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_analysis_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_analysis_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_analysis_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_analysis_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(ra_analysis_kernel, grid, dim3(RA_ANALYSIS_THREADS), lds, st, p, b, d_voice, t0, n, f_lo, (int)fb0, (int)nfb_total);
+  switch (ra_analysis_threads(p)) {
+  case 1024: hipLaunchKernelGGL(ra_analysis_kernel<1024>, grid, dim3(1024), lds, st, p, b, d_voice, t0, n, f_lo, (int)fb0, (int)nfb_total); break;
+  case 512: hipLaunchKernelGGL(ra_analysis_kernel<512>, grid, dim3(512), lds, st, p, b, d_voice, t0, n, f_lo, (int)fb0, (int)nfb_total); break;
+  default: hipLaunchKernelGGL(ra_analysis_kernel<256>, grid, dim3(256), lds, st, p, b, d_voice, t0, n, f_lo, (int)fb0, (int)nfb_total); break;
+  }
 }
 
 void ra_launch_roll_history(const RaParams &p, const RaBuffers &b, const float *d_voice, int64_t n, hipStream_t st) {

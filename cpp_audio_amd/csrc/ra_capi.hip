@@ -455,8 +455,9 @@ int ensure_scratch(ra_context *c, int64_t nfb, int64_t n, int n_chunks) {
     if (nfb > sc.frames_cap) {
       HIP_TRY(hipDeviceSynchronize()); // nothing may still read the old buffers
       dev_free(c, sc.pl_pitch); dev_free(c, sc.pl_vol); dev_free(c, sc.pl_key); dev_free(c, sc.pl_count); dev_free(c, sc.cmd); dev_free(c, sc.cmd_non);
-      size_t S = p.n_streams, F = static_cast<size_t>(nfb);
-      sc.frames_cap = nfb;
+      // equal-length blocks differ by one frame depending on where they start: leave room, a reallocation synchronises the device
+      size_t S = p.n_streams, F = static_cast<size_t>(nfb + 2);
+      sc.frames_cap = nfb + 2;
       if ((r = dev_alloc(c, &sc.pl_pitch, S * F * p.maxr, false))) return r;
       if ((r = dev_alloc(c, &sc.pl_vol, S * F * p.maxr, false))) return r;
       if ((r = dev_alloc(c, &sc.pl_key, S * F * p.maxr, false))) return r;
@@ -469,8 +470,8 @@ int ensure_scratch(ra_context *c, int64_t nfb, int64_t n, int n_chunks) {
       HIP_TRY(hipDeviceSynchronize());
       dev_free(c, sc.seg_sd); dev_free(c, sc.seg_si);
       const int64_t extra = std::max<int64_t>(kMaxChunks, n_chunks);
-      size_t S = p.n_streams, G = static_cast<size_t>(nfb + extra);
-      sc.seg_cap = nfb + extra;
+      size_t S = p.n_streams, G = static_cast<size_t>(nfb + 2 + extra);
+      sc.seg_cap = nfb + 2 + extra;
       if ((r = dev_alloc(c, &sc.seg_sd, S * G * SD_COUNT * p.Ppad, false))) return r;
       if ((r = dev_alloc(c, &sc.seg_si, S * G * SI_COUNT * p.Ppad, false))) return r;
     }
@@ -497,14 +498,14 @@ int ensure_scratch(ra_context *c, int64_t nfb, int64_t n, int n_chunks) {
     if (mod.count > b.voc_mod_cap) {
       HIP_TRY(hipStreamSynchronize(c->stream));
       dev_free(c, b.voc_amp);
-      b.voc_mod_cap = mod.count;
-      if ((r = dev_alloc(c, &b.voc_amp, S * mod.count * p.voc_bands, false))) return r;
+      b.voc_mod_cap = mod.count + 2;
+      if ((r = dev_alloc(c, &b.voc_amp, S * b.voc_mod_cap * p.voc_bands, false))) return r;
     }
     if (car.count > b.voc_car_cap) {
       HIP_TRY(hipStreamSynchronize(c->stream));
       dev_free(c, b.voc_sig);
-      b.voc_car_cap = car.count;
-      if ((r = dev_alloc(c, &b.voc_sig, S * car.count * 2 * p.voc_S, false))) return r;
+      b.voc_car_cap = car.count + 2;
+      if ((r = dev_alloc(c, &b.voc_sig, S * b.voc_car_cap * 2 * p.voc_S, false))) return r;
     }
   }
   return RA_OK;

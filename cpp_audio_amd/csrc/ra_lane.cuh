@@ -1,0 +1,39 @@
+// Cross-lane moves on the VALU (gfx950 permlane swaps / DPP): a ds_bpermute round trip costs ~100 cycles each.
+#pragma once
+#include <hip/hip_runtime.h>
+
+__device__ inline double lane_xor32_low(double x) { // value of lane ^ 32, valid in lanes 0..31
+  const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ inline double lane_xor16_even(double x) { // value of lane ^ 16, valid in the even rows of 16 lanes
+  const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ inline double lane_ror8(double x) { // value of lane (i + 8) mod 16 of the same row
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int N>
+__device__ inline double lane_ror(double x) { // value of lane (i + N) mod 16 of the same row
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x120 + N, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x120 + N, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// sum over the wavefront's 64 lanes, valid in lanes 0..15 (fixed pairing order: reproducible)
+__device__ inline double wave_sum_row0(double x) {
+  x += lane_xor32_low(x);
+  x += lane_xor16_even(x);
+  x += lane_ror<8>(x);
+  x += lane_ror<4>(x);
+  x += lane_ror<2>(x);
+  x += lane_ror<1>(x);
+  return x;
+}

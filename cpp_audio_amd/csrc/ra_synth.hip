@@ -17,6 +17,7 @@
 // Outputs of a 16-frame tile are transposed through LDS and summed over channels by 32 lanes (one per frame x output),
 // so the cross-lane reduction costs ~2 LDS ops per channel-sample instead of a 64-lane butterfly per sample.
 #include "ra_chan.cuh"
+#include "ra_lane.cuh"
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -185,26 +186,6 @@ __device__ inline void regime_setup(Chan &c, const SynConst &k, double inv_dur, 
     if (r.gliding && lo < k.max_filter_inc) r.kvar = true;
     else if (c.finit != want) { c.finit = want; const double a = M_PI * want; c.k = a / (1.0 + a); }
   }
-}
-
-// cross-lane moves on the VALU (gfx950 permlane swaps / DPP) for the channel sums: a ds_bpermute round trip costs ~100 cycles each
-__device__ inline double lane_xor32_low(double x) { // value of lane ^ 32, valid in lanes 0..31
-  const unsigned lo = __double2loint(x), hi = __double2hiint(x);
-  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-  return __hiloint2double((int)b[1], (int)a[1]);
-}
-__device__ inline double lane_xor16_even(double x) { // value of lane ^ 16, valid in the even rows of 16 lanes
-  const unsigned lo = __double2loint(x), hi = __double2hiint(x);
-  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-  return __hiloint2double((int)b[1], (int)a[1]);
-}
-__device__ inline double lane_ror8(double x) { // value of lane (i + 8) mod 16 of the same row
-  int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
 }
 
 #ifndef RA_TILE_DEPTH

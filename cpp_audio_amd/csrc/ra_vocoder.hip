@@ -12,59 +12,116 @@
 // Frames are independent given "the latest modulator frame fired at or before this carrier frame", so all of a block's
 // frames run concurrently; the sequential per-sample loop of the reference is only an ordering, not a data dependence.
 #include "ra_fft.cuh"
+#include "ra_lane.cuh"
 
 extern __shared__ __align__(16) unsigned char ra_smem_voc[];
 
 namespace {
 
-constexpr int VT = 256;
+
+__device__ inline int ilog2(int m) { return 31 - __clz(m); }
 
 // ---- K4a ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(VT) ra_voc_modulator_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int64_t t0, int64_t n, int64_t j_lo) {
+// T threads per frame: 256, or 512 when the FFT buffer (M >= 4096: 70 KB) leaves room for only two workgroups per CU.
+template <int T>
+__global__ void __launch_bounds__(T) ra_voc_modulator_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int64_t t0, int64_t n, int64_t j_lo) {
   const int tid = threadIdx.x, jb = blockIdx.x, s = blockIdx.y;
-  const int M = p.voc_Mm, W = p.voc_Wm, S = p.voc_S;
-  double2 *z = reinterpret_cast<double2 *>(ra_smem_voc);
+  const int M = p.voc_Mm, W = p.voc_Wm, S = p.voc_S, log2M = ilog2(M);
+  double2 *z = reinterpret_cast<double2 *>(ra_smem_voc); // element i lives in slot ra_zslot(i, zs)
+  const int zs = ra_zshift(log2M);
+  auto Z = [&](int i) -> double2 & { return z[ra_zslot(i, zs)]; };
+  // twiddles of the first trip of the real-spectrum split, fetched before the FFT
+  const int Mh1 = M >> 1;
+  RaPhaseClock clk(b.dbg_clk, tid == 0);
+  double2 sw0 = make_double2(0, 0), sw1 = sw0;
+  if (tid <= Mh1) { sw0 = b.vm_tw_full[tid]; sw1 = b.vm_tw_full[(M - tid) % M]; }
   {
     const int64_t start = (j_lo + jb) * (int64_t)S;
     const float *hist = b.voc_mod_hist + (size_t)s * W;
     const float *vs = voice ? voice + (size_t)s * n : nullptr;
     const int h = W / 2;
-    auto sample = [&](int i) -> double {
-      if (i >= W) return 0.0;
-      int64_t a = start + i;
-      float v = (a < t0) ? hist[W - (t0 - a)] : (vs ? vs[a - t0] : 0.f);
-      int j = (i >= h) ? (i - h) : (h - 1 - i);
-      return (double)v * b.voc_half_window[j];
-    };
-    for (int k = tid; k < M; k += VT) z[b.vm_bitrev[k]] = make_double2(sample(2 * k), sample(2 * k + 1));
+    // usual case: the window lies inside the block and its two halves hold whole pairs — one address computation and one 16-byte
+    // weight load per packed element, consecutive lanes on consecutive samples (the fused first pass resolves the bit reversal)
+    const bool plain = vs && start >= t0 && (W & 3) == 0; // workgroup-uniform
+    if (plain) {
+      const float *w0 = vs + (start - t0);
+      const double2 *hw2 = reinterpret_cast<const double2 *>(b.voc_half_window);
+      ra_fft_fused(z, M, log2M, b.vm_tw_half, tid, T, [&](int k) {
+        // Zero padding without control flow: out-of-window elements load the window's last pair (one address for the whole wave) and are
+        // multiplied by 0 — a select would let the compiler sink the loads into a branch and wait for each one in turn; this way a
+        // thread's 8 sample pairs and 8 weight pairs are in flight together.
+        const bool in = 2 * k < W;
+        const int i0 = in ? 2 * k : W - 2;
+        const float v0 = w0[i0], v1 = w0[i0 + 1];
+        const bool upper = i0 >= h;
+        const double2 ww = hw2[upper ? (i0 - h) >> 1 : (h - 2 - i0) >> 1];
+        const double keep = in ? 1.0 : 0.0;
+        return make_double2((double)v0 * (upper ? ww.x : ww.y) * keep, (double)v1 * (upper ? ww.y : ww.x) * keep);
+      }, &clk);
+    } else {
+      auto sample = [&](int i) -> double {
+        if (i >= W) return 0.0;
+        int64_t a = start + i;
+        float v = (a < t0) ? hist[W - (t0 - a)] : (vs ? vs[a - t0] : 0.f);
+        int j = (i >= h) ? (i - h) : (h - 1 - i);
+        return (double)v * b.voc_half_window[j];
+      };
+      ra_fft_fused(z, M, log2M, b.vm_tw_half, tid, T, [&](int k) { return make_double2(sample(2 * k), sample(2 * k + 1)); });
+    }
+  }
+  for (int k = tid; k <= Mh1; k += T) {
+    const int km = (M - k) % M;
+    const double2 zk = Z(k), zm = Z(km);
+    const double2 wk = sw0, wm = sw1;
+    if (k + T <= Mh1) { sw0 = b.vm_tw_full[k + T]; sw1 = b.vm_tw_full[M - k - T]; }
+    const double2 xk = ra_real_split_bin(zk, zm, wk);
+    const double sk = xk.x * xk.x + xk.y * xk.y;
+    Z(k).x = sk; // the pair's slots are private to this thread
+    if (km != k) { const double2 xm = ra_real_split_bin(zm, zk, wm); Z(km).x = xm.x * xm.x + xm.y * xm.y; }
   }
   __syncthreads();
-  ra_fft_dit(z, M, b.vm_tw_half, tid, VT, false);
-  for (int k = tid; k <= (M >> 1); k += VT) {
-    int km = (M - k) % M;
-    double2 zk = z[k], zm = z[km];
-    double2 xk = ra_real_split_bin(zk, zm, b.vm_tw_full[k]);
-    double sk = xk.x * xk.x + xk.y * xk.y, sm = 0.0;
-    if (km != k) { double2 xm = ra_real_split_bin(zm, zk, b.vm_tw_full[km]); sm = xm.x * xm.x + xm.y * xm.y; }
-    z[k].x = sk;
-    if (km != k) z[km].x = sm;
+  clk.mark(58);
+  // band amplitudes sqrt(sum of |X|^2 over the band's bins) (vocoder.cpp:137-160).  One wave per band, four bands at a time (their LDS
+  // reads and lane sums overlap); lanes stride over the band's bins and the 64 partial sums are folded pairwise on the VALU: the
+  // reference adds in bin order, so a sum differs from its value by rounding only (~1e-16 relative on a gain; a band of one bin is exact).
+  // Bands hold up to several hundred bins: one lane per band cost more than the whole FFT.
+  const int B = p.voc_bands, lane = tid & 63, nw = T >> 6, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int band0 = wv; band0 < B; band0 += 4 * nw) {
+    int lo[4], len[4], maxlen = 0;
+    double acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int band = band0 + u * nw;
+      const bool ok = band < B;
+      const int l = ok ? b.voc_mod_band_start[2 * band] : 0, hh = ok ? b.voc_mod_band_start[2 * band + 1] : 0;
+      lo[u] = l; len[u] = hh - l; acc[u] = 0.0;
+      maxlen = max(maxlen, len[u]);
+    }
+    for (int i = lane; i < maxlen; i += 64) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (i < len[u]) acc[u] += Z(lo[u] + i).x;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int band = band0 + u * nw;
+      const double tot = wave_sum_row0(acc[u]);
+      if (lane == 0 && band < B) b.voc_amp[((size_t)s * b.voc_mod_cap + jb) * B + band] = sqrt(tot);
+    }
   }
-  __syncthreads();
-  // band amplitudes: bins in ascending order per band, like the reference's single pass (vocoder.cpp:137-160)
-  const int B = p.voc_bands;
-  if (tid < B) {
-    double acc = 0.0;
-    for (int i = b.voc_mod_band_start[2 * tid]; i < b.voc_mod_band_start[2 * tid + 1]; ++i) acc += z[i].x;
-    b.voc_amp[((size_t)s * b.voc_mod_cap + jb) * B + tid] = sqrt(acc);
-  }
+  clk.mark(59);
 }
 
 // ---- K4b ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(VT) ra_voc_carrier_kernel(RaParams p, RaBuffers b, const float *__restrict__ carrier, int64_t t0, int64_t n, int64_t i_lo,
+// T threads per frame: one wavefront for the usual short carrier frames (L = 512: 32 radix-8 groups per pass), 256 for long ones.
+template <int T>
+__global__ void __launch_bounds__(T) ra_voc_carrier_kernel(RaParams p, RaBuffers b, const float *__restrict__ carrier, int64_t t0, int64_t n, int64_t i_lo,
                                                           int64_t j_lo, int64_t n_mod) {
   const int tid = threadIdx.x, ib = blockIdx.x, s = blockIdx.y;
-  const int M = p.voc_Mc, L = p.voc_Lc, S = p.voc_S, W = 2 * p.voc_S, B = p.voc_bands;
-  double2 *z = reinterpret_cast<double2 *>(ra_smem_voc);
+  const int M = p.voc_Mc, L = p.voc_Lc, S = p.voc_S, W = 2 * p.voc_S, B = p.voc_bands, log2M = ilog2(M);
+  double2 *z = reinterpret_cast<double2 *>(ra_smem_voc);  // [ra_zsize(M)] transform buffer
+  double2 *zin = z + ra_zsize(M);                      // [M] input of the inverse transform
+  const int zs = ra_zshift(log2M);
+  auto Z = [&](int i) -> double2 & { return z[ra_zslot(i, zs)]; };
   const int64_t i = i_lo + ib;
   const int64_t fire = (int64_t)W - 1 + i * S;
   {
@@ -77,10 +134,19 @@ __global__ void __launch_bounds__(VT) ra_voc_carrier_kernel(RaParams p, RaBuffer
       float v = (a < t0) ? hist[W - (t0 - a)] : (cs ? cs[a - t0] : 0.f);
       return (double)v; // PeriodicFFT::feed(float), apply_rectangular_window (periodicfft.cpp:228)
     };
-    for (int k = tid; k < M; k += VT) z[b.vc_bitrev[k]] = make_double2(sample(2 * k), sample(2 * k + 1));
+    if (cs && start >= t0) { // the frame lies inside the block (W = 2 S is even)
+      const float *w0 = cs + (start - t0);
+      ra_fft_fused(z, M, log2M, b.vc_tw_half, tid, T, [&](int k) {
+        const bool in = 2 * k < W; // zero padding as a multiplication, like the modulator's loader
+        const int i0 = in ? 2 * k : W - 2;
+        const float v0 = w0[i0], v1 = w0[i0 + 1];
+        const double keep = in ? 1.0 : 0.0;
+        return make_double2((double)v0 * keep, (double)v1 * keep);
+      });
+    } else {
+      ra_fft_fused(z, M, log2M, b.vc_tw_half, tid, T, [&](int k) { return make_double2(sample(2 * k), sample(2 * k + 1)); });
+    }
   }
-  __syncthreads();
-  ra_fft_dit(z, M, b.vc_tw_half, tid, VT, false);
 
   // band amplitudes in force when this frame fires: the latest modulator frame with fire_j <= fire_i (it is fed first, :782-790)
   const double *amp = nullptr;
@@ -96,10 +162,11 @@ __global__ void __launch_bounds__(VT) ra_voc_carrier_kernel(RaParams p, RaBuffer
     int band = b.voc_car_band[k];
     return (band >= 0 && amp) ? amp[band] : 0.0;
   };
-  // forward split, modulate, and the inverse transform's pre-pass, all on the private slot pair (k, M-k)
-  for (int k = tid; k <= (M >> 1); k += VT) {
+  // forward split, modulate, and the inverse transform's pre-pass on the pair (k, M-k).  The inverse runs as conj(FFT(conj(.))) through
+  // the same fused forward passes: conjugation is exact, so the bits equal those of a conjugated-twiddle inverse network.
+  for (int k = tid; k <= (M >> 1); k += T) {
     const int km = M - k; // 1..M ; km == M stands for the Nyquist bin (pairs with k = 0)
-    double2 zk = z[k], zm = z[km % M];
+    double2 zk = Z(k), zm = Z(km % M);
     double2 Xk = ra_real_split_bin(zk, zm, b.vc_tw_full[k]);
     double2 Xm = ra_real_split_bin(zm, zk, b.vc_tw_full[km]); // for k = 0 this is X[M] (Nyquist)
     double gk = gain(k), gm = gain(km);
@@ -111,24 +178,18 @@ __global__ void __launch_bounds__(VT) ra_voc_carrier_kernel(RaParams p, RaBuffer
       double dr = xa.x - xb.x, di = xa.y + xb.y;
       double o_r = dr * w.x + di * w.y;   // (dr + i di) * (w.x - i w.y)
       double o_i = di * w.x - dr * w.y;
-      return make_double2(er - o_i, ei + o_r);
+      return make_double2(er - o_i, -(ei + o_r)); // conjugated for the forward passes below
     };
-    double2 nk = pre(Xk, Xm, b.vc_tw_full[k]);
-    z[k] = nk;
-    if (k != 0 && km != k) z[km] = pre(Xm, Xk, b.vc_tw_full[km]);
+    zin[k] = pre(Xk, Xm, b.vc_tw_full[k]);
+    if (k != 0 && km != k) zin[km] = pre(Xm, Xk, b.vc_tw_full[km]);
   }
   __syncthreads();
-  for (int k = tid; k < M; k += VT) { // bit-reversal permutation (pairs are disjoint)
-    int r = b.vc_bitrev[k];
-    if (k < r) { double2 t = z[k]; z[k] = z[r]; z[r] = t; }
-  }
-  __syncthreads();
-  ra_fft_dit(z, M, b.vc_tw_half, tid, VT, true);
+  ra_fft_fused(z, M, log2M, b.vc_tw_half, tid, T, [&](int k) { return zin[k]; });
   const double scale = 1.0 / (double)L;
   double *dst = b.voc_sig + ((size_t)s * b.voc_car_cap + ib) * W;
-  for (int q = tid; q < W; q += VT) {
-    double2 v = z[q >> 1];
-    dst[q] = ((q & 1) ? v.y : v.x) * scale;
+  for (int q = tid; q < W; q += T) {
+    double2 v = Z(q >> 1);
+    dst[q] = ((q & 1) ? -v.y : v.x) * scale;
   }
 }
 
@@ -209,17 +270,26 @@ void ra_launch_vocoder(const RaParams &p, const RaBuffers &b, const float *d_voi
   RaFrameRange car = ra_frames_firing(W, S, t0, n);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_modulator_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_carrier_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_modulator_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_modulator_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_carrier_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_carrier_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_roll_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  if (mod.count > 0)
-    hipLaunchKernelGGL(ra_voc_modulator_kernel, dim3((unsigned)mod.count, (unsigned)p.n_streams), dim3(VT), (size_t)p.voc_Mm * sizeof(double2), st, p, b, d_voice,
-                       t0, n, mod.lo);
-  if (car.count > 0)
-    hipLaunchKernelGGL(ra_voc_carrier_kernel, dim3((unsigned)car.count, (unsigned)p.n_streams), dim3(VT), (size_t)std::max(p.voc_Mc, 1) * sizeof(double2), st,
-                       p, b, d_carrier, t0, n, car.lo, mod.lo, mod.count);
+  if (mod.count > 0) {
+    const dim3 grid((unsigned)mod.count, (unsigned)p.n_streams);
+    const size_t lds = (size_t)ra_zsize(p.voc_Mm) * sizeof(double2);
+    if (p.voc_Mm >= 4096) hipLaunchKernelGGL(ra_voc_modulator_kernel<512>, grid, dim3(512), lds, st, p, b, d_voice, t0, n, mod.lo);
+    else hipLaunchKernelGGL(ra_voc_modulator_kernel<256>, grid, dim3(256), lds, st, p, b, d_voice, t0, n, mod.lo);
+  }
+  if (car.count > 0) {
+    const dim3 grid((unsigned)car.count, (unsigned)p.n_streams);
+    const int Mc = std::max(p.voc_Mc, 1);
+    const size_t lds = ((size_t)ra_zsize(Mc) + Mc) * sizeof(double2);
+    if (Mc <= 512) hipLaunchKernelGGL(ra_voc_carrier_kernel<64>, grid, dim3(64), lds, st, p, b, d_carrier, t0, n, car.lo, mod.lo, mod.count);
+    else hipLaunchKernelGGL(ra_voc_carrier_kernel<256>, grid, dim3(256), lds, st, p, b, d_carrier, t0, n, car.lo, mod.lo, mod.count);
+  }
   {
     unsigned gx = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
     hipLaunchKernelGGL(ra_voc_mix_kernel, dim3(gx, (unsigned)p.n_streams), dim3(256), 0, st, p, b, d_voice, d_carrier, t0, n, car.lo, car.count);

@@ -1,14 +1,17 @@
 #!/bin/bash
 # Tuning aid (GPU box): per-kernel SQ counters of an un-pipelined step (RA_PIPELINE_CHUNKS=1), one rocprofv3 run per counter group.
+# PMC_SCRIPT / PMC_ARGS choose the profiled python script (default: bench.py, one step).
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/pmc_probe
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export RA_PIPELINE_CHUNKS=1
+SCRIPT=${PMC_SCRIPT:-bench.py}
+ARGS=${PMC_ARGS:---steps 1 --warmup 1 --no-cpu-baseline}
 i=0
 for grp in "$@"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/g$i -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/g$i.log 2>&1 || tail -3 $OUT/g$i.log
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/g$i -- python3 $ROOT/$SCRIPT $ARGS > $OUT/g$i.log 2>&1 || tail -3 $OUT/g$i.log
 done
 cd $ROOT
 python3 - <<'PY'
