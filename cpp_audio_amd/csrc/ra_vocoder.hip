@@ -13,6 +13,8 @@
 // frames run concurrently; the sequential per-sample loop of the reference is only an ordering, not a data dependence.
 #include "ra_fft.cuh"
 #include "ra_lane.cuh"
+#include <algorithm>
+#include <cstdlib>
 
 extern __shared__ __align__(16) unsigned char ra_smem_voc[];
 
@@ -24,9 +26,16 @@ __device__ inline int ilog2(int m) { return 31 - __clz(m); }
 // ---- K4a ------------------------------------------------------------------------------------------
 // T threads per frame: 256, or 512 when the FFT buffer (M >= 4096: 70 KB) leaves room for only two workgroups per CU.
 template <int T>
-__global__ void __launch_bounds__(T) ra_voc_modulator_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int64_t t0, int64_t n, int64_t j_lo) {
-  const int tid = threadIdx.x, jb = blockIdx.x, s = blockIdx.y;
-  const int M = p.voc_Mm, W = p.voc_Wm, S = p.voc_S, log2M = ilog2(M);
+__global__ void __launch_bounds__(T, 4) ra_voc_modulator_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int64_t t0, int64_t n, int64_t j_lo,
+                                                            int n_mod, int fpw) {
+  // a workgroup takes fpw consecutive frames of its stream (workgroup launches amortised; the window weights and twiddles stay warm)
+  const int s = blockIdx.y;
+  for (int jb = blockIdx.x * fpw, jb_end = min(jb + fpw, n_mod); jb < jb_end; ++jb) {
+  // The body is the single-frame kernel; tid and M pass through an empty asm so that nothing computed from them is hoisted out of the
+  // loop (hoisted addresses and twiddles cost 100 VGPRs and with them the second workgroup per CU).
+  int tid = threadIdx.x, M = p.voc_Mm;
+  asm volatile("" : "+v"(tid), "+s"(M));
+  const int W = p.voc_Wm, S = p.voc_S, log2M = ilog2(M);
   double2 *z = reinterpret_cast<double2 *>(ra_smem_voc); // element i lives in slot ra_zslot(i, zs)
   const int zs = ra_zshift(log2M);
   auto Z = [&](int i) -> double2 & { return z[ra_zslot(i, zs)]; };
@@ -109,6 +118,8 @@ __global__ void __launch_bounds__(T) ra_voc_modulator_kernel(RaParams p, RaBuffe
     }
   }
   clk.mark(59);
+  __syncthreads(); // the buffer is reused by the next frame
+  }
 }
 
 // ---- K4b ------------------------------------------------------------------------------------------
@@ -278,10 +289,16 @@ void ra_launch_vocoder(const RaParams &p, const RaBuffers &b, const float *d_voi
     attr_set = true;
   }
   if (mod.count > 0) {
-    const dim3 grid((unsigned)mod.count, (unsigned)p.n_streams);
+    static const int fpw_env = [] { const char *e = getenv("RA_VOC_FPW"); return e ? atoi(e) : 0; }();
+    // frames per workgroup: 8 when that still leaves every CU several workgroups (28.0 vs 33.1 ms per configs[2] step: a 512-thread
+    // workgroup lives ~25 us and its successor's launch is not free), fewer for short blocks / few streams
+    int fpw = 8;
+    while (fpw > 1 && ((mod.count + fpw - 1) / fpw) * (int64_t)p.n_streams < 1024) fpw >>= 1;
+    if (fpw_env > 0) fpw = fpw_env;
+    const dim3 grid((unsigned)((mod.count + fpw - 1) / fpw), (unsigned)p.n_streams);
     const size_t lds = (size_t)ra_zsize(p.voc_Mm) * sizeof(double2);
-    if (p.voc_Mm >= 4096) hipLaunchKernelGGL(ra_voc_modulator_kernel<512>, grid, dim3(512), lds, st, p, b, d_voice, t0, n, mod.lo);
-    else hipLaunchKernelGGL(ra_voc_modulator_kernel<256>, grid, dim3(256), lds, st, p, b, d_voice, t0, n, mod.lo);
+    if (p.voc_Mm >= 4096) hipLaunchKernelGGL(ra_voc_modulator_kernel<512>, grid, dim3(512), lds, st, p, b, d_voice, t0, n, mod.lo, (int)mod.count, fpw);
+    else hipLaunchKernelGGL(ra_voc_modulator_kernel<256>, grid, dim3(256), lds, st, p, b, d_voice, t0, n, mod.lo, (int)mod.count, fpw);
   }
   if (car.count > 0) {
     const dim3 grid((unsigned)car.count, (unsigned)p.n_streams);

@@ -305,6 +305,22 @@ def test_vocoder_block_size_invariance(api, sig):
         assert np.array_equal(a, b)
 
 
+def test_vocoder_many_streams_frames_per_workgroup(api, oracle, sig):
+    # enough streams x frames that a modulator workgroup takes 8 consecutive frames (ra_launch_vocoder); two unequal blocks, so that a
+    # workgroup's last frames fall off the end of a block
+    S, n = 64, 48000
+    x = sig.make_streams(S, n, kind="speech", base_seed=300)
+    car = np.stack([sig.carrier_stream(n, freq=80.0 + 3.0 * s) for s in range(S)])
+    gcfg, k = both_configs(api, oracle, **VOC_KW)
+    with api.Context(gcfg, S, 0) as ctx:
+        out = np.concatenate([ctx.process_host(x[:, :30011], car[:, :30011]), ctx.process_host(x[:, 30011:], car[:, 30011:])], axis=1)
+        assert ctx.stats().error_flags == 0
+    for s in (0, 21, 63):
+        ref, _, _ = oracle.run_offline(oracle.default_config(**dict(k, seed=k["seed"] + s)), x[s], car[s])
+        assert np.sqrt(np.mean(ref.astype(np.float64) ** 2)) > 1e-4
+        assert rms(out[s], ref) <= RMS_TOL, f"stream {s}"
+
+
 def _random_notes(rng, n_notes, max_start, sr):
     start = np.sort(rng.integers(0, max_start, n_notes)).astype(np.int32)
     start[: n_notes // 8] = start[0]                      # several notes on the same start frame
