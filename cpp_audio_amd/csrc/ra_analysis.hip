@@ -217,6 +217,22 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
         s0 += p.input_gain * v0; s1 += p.input_gain * v1; // lib.cpp:1626,1636 (float)
         return make_double2((double)s0 * (upper ? ww.x : ww.y), (double)s1 * (upper ? ww.y : ww.x));
       });
+    } else if (vs && !fb_on && start >= t0 && (N & 1) == 0) {
+      // The same for any even window inside the block (the reference's window sizes are even, lib.cpp:484-487; its default 0.1814 s is
+      // 8000 samples at 44.1 kHz, zero padded to 8192): the two weights of a pair are loaded separately (the pair may straddle the
+      // window's centre or sit on an odd table index), and the zero padding is a multiplication on clamped loads — a select would let the
+      // compiler sink the loads into branches and wait for each one in turn.
+      const float *w0 = vs + (start - t0);
+      ra_fft_fused(z, M, p.log2M, b.tw_half, tid, T, [&](int k) {
+        const bool in = 2 * k < N;
+        const int i0 = in ? 2 * k : N - 2, i1 = i0 + 1;
+        const float v0 = w0[i0], v1 = w0[i1];
+        const double wa = b.half_window[i0 >= h ? i0 - h : h - 1 - i0], wb = b.half_window[i1 >= h ? i1 - h : h - 1 - i1];
+        float s0 = 0.f, s1 = 0.f;
+        s0 += p.input_gain * v0; s1 += p.input_gain * v1; // lib.cpp:1626,1636 (float)
+        const double keep = in ? 1.0 : 0.0;
+        return make_double2((double)s0 * wa * keep, (double)s1 * wb * keep);
+      });
     } else {
       ra_fft_fused(z, M, p.log2M, b.tw_half, tid, T, [&](int k) { return make_double2(sample(2 * k), sample(2 * k + 1)); });
     }
@@ -264,16 +280,23 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   const int c0 = tid * chunk, c1 = min(M, c0 + chunk);
   const int Mh = M >> 1;
   int cnt = 0;
-  for (int i = max(c0, 1); i < c1 && i + 1 < M; ++i) {
-    double a = Z(i - 1).x, m = Z(i).x, c = Z(i + 1).x;
-    cnt += (a < m && m >= c) ? 1 : 0;
+  const int i_first = max(c0, 1), i_stop = min(c1, M - 1); // bins i_first .. i_stop - 1; a sliding (a, m, c) window: one LDS read per bin
+  if (i_first < i_stop) {
+    double a = Z(i_first - 1).x, m = Z(i_first).x;
+    for (int i = i_first; i < i_stop; ++i) {
+      const double c = Z(i + 1).x;
+      cnt += (a < m && m >= c) ? 1 : 0;
+      a = m; m = c;
+    }
   }
   block_exclusive_scan<T>(scan, cnt, tid);
-  {
+  if (i_first < i_stop) {
     int pos = scan[tid];
-    for (int i = max(c0, 1); i < c1 && i + 1 < M; ++i) {
-      double a = Z(i - 1).x, m = Z(i).x, c = Z(i + 1).x;
+    double a = Z(i_first - 1).x, m = Z(i_first).x;
+    for (int i = i_first; i < i_stop; ++i) {
+      const double c = Z(i + 1).x;
       if (a < m && m >= c) Z(pos++).y = (double)i;
+      a = m; m = c;
     }
   }
   const int K = scan[T];

@@ -32,13 +32,15 @@ __device__ inline void ra_fft_pass(double2 *z, int M, int log2M, int log2h, cons
     // thread gi takes group g = bitrev_{m-S}(gi), so that consecutive lanes load consecutive packed elements (coalesced)
     const int g = (FIRST && log2M > S) ? (int)(__brev((unsigned)gi) >> (32 - (log2M - S))) : gi;
     const int r = g & (h - 1), base = ((g - r) << S) + r;
+    // base and k h occupy disjoint bits and ra_zslot is XOR-linear: slot(base + k h) = slot(base) ^ slot(k h), the second term wave-uniform
+    const int sb = ra_zslot(base, zs);
     double2 x[R], w[R];
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       if (FIRST) {
         const unsigned rk = __brev((unsigned)k) >> (32 - S);
         x[k] = load((int)((rk << (log2M - S)) | (unsigned)gi));
-      } else x[k] = z[ra_zslot(base + k * h, zs)];
+      } else x[k] = z[sb ^ ra_zslot(k << log2h, zs)];
     }
 #pragma unroll
     for (int s = 0; s < S; ++s) {
@@ -59,7 +61,7 @@ __device__ inline void ra_fft_pass(double2 *z, int M, int log2M, int log2h, cons
       }
     }
 #pragma unroll
-    for (int k = 0; k < R; ++k) z[ra_zslot(base + k * h, zs)] = x[k];
+    for (int k = 0; k < R; ++k) z[sb ^ ra_zslot(k << log2h, zs)] = x[k];
   }
   __syncthreads();
 }
@@ -83,9 +85,10 @@ __device__ inline void ra_fft_pass_w(double2 *z, int M, int log2M, int log2h, in
   const int h = 1 << log2h, zs = ra_zshift(log2M);
   if (g < (M >> S)) {
     const int r = g & (h - 1), base = ((g - r) << S) + r;
+    const int sb = ra_zslot(base, zs);
     double2 x[R];
 #pragma unroll
-    for (int k = 0; k < R; ++k) x[k] = z[ra_zslot(base + k * h, zs)];
+    for (int k = 0; k < R; ++k) x[k] = z[sb ^ ra_zslot(k << log2h, zs)];
 #pragma unroll
     for (int s = 0; s < S; ++s) {
 #pragma unroll
@@ -100,7 +103,7 @@ __device__ inline void ra_fft_pass_w(double2 *z, int M, int log2M, int log2h, in
       }
     }
 #pragma unroll
-    for (int k = 0; k < R; ++k) z[ra_zslot(base + k * h, zs)] = x[k];
+    for (int k = 0; k < R; ++k) z[sb ^ ra_zslot(k << log2h, zs)] = x[k];
   }
   __syncthreads();
 }

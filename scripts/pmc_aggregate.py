@@ -9,7 +9,7 @@ KERNELS = ("ra_analysis_kernel", "ra_track_kernel", "ra_synth_propagate_kernel",
 
 def short(name):
     for k in KERNELS:
-        if k + "(" in name or name.endswith(k):
+        if k + "(" in name or k + "<" in name or name.endswith(k):  # templated kernels print as name<256>(...)
             return k
     return None
 
