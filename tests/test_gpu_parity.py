@@ -75,7 +75,8 @@ def check_streams(api, oracle, x, carrier=None, expect_sound=True, **kw):
     return out
 
 
-@pytest.mark.parametrize("N,kind", [(2, 0), (16, 0), (800, 0), (1024, 0), (4096, 0), (4096, 1), (4096, 2), (4800, 0), (8192, 0), (16000, 0)])
+@pytest.mark.parametrize("N,kind", [(2, 0), (6, 0), (16, 0), (800, 0), (1024, 0), (1026, 0), (4096, 0), (4096, 1), (4096, 2), (4800, 0), (4802, 1), (8000, 0), (8192, 0),
+                                    (16000, 0)])
 def test_sqmag_matches_oracle(api, oracle, N, kind):
     rng = np.random.default_rng(N + kind)
     w = rng.standard_normal((3, N)).astype(np.float32)
@@ -148,6 +149,8 @@ def test_c4_shape_autotune_128_partials(api, oracle, sig):
     dict(analysis_input_gain=0.5, analysis_volume=2.0),
     dict(min_volume=0.01, nearby_distance_tones=1.5, max_track_pitches=0.3),
     dict(window_kind=1), dict(window_kind=2),
+    dict(sample_rate=44100, window_size=8000, stride=3969),   # the reference's default window / stride at 44.1 kHz (lib.cpp:945-946): zero padded to 8192
+    dict(window_size=1026, stride=300),                       # even, not a multiple of 4: a sample pair straddles the window's centre
 ])
 def test_parameter_variants(api, oracle, sig, kw):
     x = sig.make_streams(2, 48000, base_seed=5)
