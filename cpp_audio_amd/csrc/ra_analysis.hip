@@ -635,13 +635,12 @@ void ra_launch_analysis(const RaParams &p, const RaBuffers &b, const float *d_vo
   if (nfb_chunk <= 0) return;
   dim3 grid((unsigned)nfb_chunk, (unsigned)p.n_streams);
   size_t lds = ra_analysis_lds_bytes(p);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_done = 0;
+  ra_once_per_device(attr_done, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_analysis_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_analysis_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_analysis_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  });
   switch (ra_analysis_threads(p)) {
   case 1024: hipLaunchKernelGGL(ra_analysis_kernel<1024>, grid, dim3(1024), lds, st, p, b, d_voice, t0, n, f_lo, (int)fb0, (int)nfb_total); break;
   case 512: hipLaunchKernelGGL(ra_analysis_kernel<512>, grid, dim3(512), lds, st, p, b, d_voice, t0, n, f_lo, (int)fb0, (int)nfb_total); break;

@@ -165,6 +165,20 @@ struct RaPhaseClock {
   }
 };
 
+// Runs fn the first time the calling site is reached on the current device (function attributes are per device: a process may hold
+// contexts on several GPUs).  `done` is the site's own static bit set; the lock keeps a second host thread from launching before the
+// attributes are in place.
+#include <mutex>
+template <typename Fn>
+inline void ra_once_per_device(unsigned long long &done, Fn fn) {
+  static std::mutex mu;
+  std::lock_guard<std::mutex> g(mu);
+  int d = 0;
+  (void)hipGetDevice(&d);
+  const unsigned long long bit = 1ull << (d & 63);
+  if (!(done & bit)) { fn(); done |= bit; }
+}
+
 // frames of the block [t0, t0+n) for a PeriodicFFT fed from sample 0 with window W and stride S: fire = W - 1 + j S
 struct RaFrameRange { int64_t lo, count; };
 __host__ __device__ inline RaFrameRange ra_frames_firing(int64_t W, int64_t S, int64_t t0, int64_t n) {

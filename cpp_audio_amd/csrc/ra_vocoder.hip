@@ -279,15 +279,14 @@ void ra_launch_vocoder(const RaParams &p, const RaBuffers &b, const float *d_voi
   const int S = p.voc_S, W = 2 * S;
   RaFrameRange mod = ra_frames_firing(p.voc_Wm, S, t0, n);
   RaFrameRange car = ra_frames_firing(W, S, t0, n);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_done = 0;
+  ra_once_per_device(attr_done, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_modulator_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_modulator_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_carrier_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_carrier_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_roll_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  });
   if (mod.count > 0) {
     static const int fpw_env = [] { const char *e = getenv("RA_VOC_FPW"); return e ? atoi(e) : 0; }();
     // frames per workgroup: 8 when that still leaves every CU several workgroups (28.0 vs 33.1 ms per configs[2] step: a 512-thread
