@@ -183,10 +183,14 @@ int upload_fft_tables(ra_context *c, int L, double2 **tw_half, double2 **tw_full
   int M = L / 2, log2M = 0, r;
   while ((1 << log2M) < M) ++log2M;
   std::vector<double2> tw(std::max(M / 2, 1));
-  for (int k = 0; k < M / 2; ++k) { double a = -2.0 * M_PI * k / M; tw[k] = make_double2(std::cos(a), std::sin(a)); }
+  // separate cos and sin calls that cannot be merged into one sincos call (volatile): glibc's sincos differs from its sin / cos by an
+  // ulp at a few arguments per table, and whether a compiler merges the pair is its own business (g++ -O2 does); the CPU restatement
+  // builds its tables the same way
+  auto twiddle = [](double a) { volatile double a_again = a; const double cs = std::cos(a); const double sn = std::sin(a_again); return make_double2(cs, sn); };
+  for (int k = 0; k < M / 2; ++k) tw[k] = twiddle(-2.0 * M_PI * k / M);
   if ((r = upload(c, tw_half, tw))) return r;
   std::vector<double2> tf(M + 1);
-  for (int k = 0; k <= M; ++k) { double a = -2.0 * M_PI * k / L; tf[k] = make_double2(std::cos(a), std::sin(a)); }
+  for (int k = 0; k <= M; ++k) tf[k] = twiddle(-2.0 * M_PI * k / L);
   if ((r = upload(c, tw_full, tf))) return r;
   std::vector<int> rev(std::max(M, 1), 0);
   for (int i = 0; i < M; ++i) {
@@ -344,7 +348,11 @@ int build_tables(ra_context *c) {
   {
     int M = p.M;
     std::vector<double2> tw(std::max(M / 2, 1));
-    for (int k = 0; k < M / 2; ++k) { double a = -2.0 * M_PI * k / M; tw[k] = make_double2(std::cos(a), std::sin(a)); }
+    // separate cos and sin calls that cannot be merged into one sincos call (volatile): glibc's sincos differs from its sin / cos by an
+  // ulp at a few arguments per table, and whether a compiler merges the pair is its own business (g++ -O2 does); the CPU restatement
+  // builds its tables the same way
+  auto twiddle = [](double a) { volatile double a_again = a; const double cs = std::cos(a); const double sn = std::sin(a_again); return make_double2(cs, sn); };
+  for (int k = 0; k < M / 2; ++k) tw[k] = twiddle(-2.0 * M_PI * k / M);
     if ((r = upload(c, &b.tw_half, tw))) return r;
     std::vector<double2> tf(M + 1);
     for (int k = 0; k <= M; ++k) { double a = -2.0 * M_PI * k / p.L; tf[k] = make_double2(std::cos(a), std::sin(a)); }

@@ -1,8 +1,11 @@
 // Lean fp64 log2 / exp10 for the peak refinement of the analysis kernel (5 transcendentals per spectral peak, ~600 peaks per frame:
 // 40 % of that kernel's VALU instructions with the general-purpose library versions, which also carry special-case and denormal
 // handling that cannot occur here).  Domain: log2 for positive normal x; exp10 for |x| < 300.  Measured on gfx950 against the host's long
-// double libm over 1e-300 .. 1e12 and around 1 (scripts/ubench/lean_math_check.hip): log2 <= 2.7 ulp, exp10 <= 1.1 ulp; the pitch lists
-// agree with the CPU restatement to 1e-9 as before (tests/test_gpu_parity.py: check_streams) and the bench's decisions are unchanged.
+// double libm over 1e-300 .. 1e12 and around 1 (scripts/ubench/lean_math_check.hip): log2 <= 2.7 ulp, exp10 <= 1.1 ulp.
+// Every step is a correctly rounded IEEE operation (add, multiply, divide, fma, rint, exponent-field arithmetic), so the results are the
+// same bits on any conforming machine: the CPU restatement evaluates the same sequences (oracle/oracle_math.hpp; 0 mismatches in 4 M
+// arguments, scripts/ubench/det_math_bits.hip), and the pitch / volume lists of the two agree bit for bit (tests/test_gpu_parity.py) —
+// which events need: with autotune a pitch one ulp off decides a NoteChange against a NoteOff + NoteOn (see oracle_math.hpp).
 #pragma once
 #include <hip/hip_runtime.h>
 

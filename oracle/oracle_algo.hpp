@@ -53,6 +53,11 @@ struct Midi { // midi.h:234-268 with tuning_stretch = 1
     if (freq <= 0) return {};
     return A_pitch + (num_halftones_per_octave / tuning_stretch) * std::log2(freq / freq_A);
   }
+  // the same for analysed peaks: log2 as the explicit sequence of oracle_math.hpp (its last bits decide events, see there)
+  std::optional<double> frequency_to_midi_pitch_analysis(double freq) const {
+    if (freq <= 0) return {};
+    return A_pitch + (num_halftones_per_octave / tuning_stretch) * det_log2(freq / freq_A);
+  }
   double midi_pitch_to_freq(double pitch) const { // midi.h:258-264
     return freq_A * std::pow(half_tone_ratio, pitch - A_pitch);
   }
@@ -135,7 +140,7 @@ struct PitchVolume { double midipitch; double volume; }; // algo.cpp:5-8
 inline void frequencies_to_pitches(Midi const &midi, std::vector<FreqMag> const &fs, std::vector<PitchVolume> &res) {
   res.clear();
   for (auto const &f : fs)
-    if (auto pitch = midi.frequency_to_midi_pitch(f.freq)) res.push_back({*pitch, db_to_mag(f.mag_db)});
+    if (auto pitch = midi.frequency_to_midi_pitch_analysis(f.freq)) res.push_back({*pitch, db_to_mag_analysis(f.mag_db)});
 }
 
 // algo.cpp:42-104 (only the two reduction methods RtResynth uses, lib.cpp:400-403)

@@ -30,6 +30,10 @@ double ora_midi_get_pitch(int note, int octave) { return Midi().get_pitch(NoteOc
 double ora_scale_closest_pitch(int mode, double root_pitch, double pitch) { return getMusicalScale(mode).closest_pitch(root_pitch, pitch); }
 double ora_frequency_to_midi_pitch(double f) { auto p = Midi().frequency_to_midi_pitch(f); return p ? *p : NAN; }
 double ora_midi_pitch_to_freq(double p) { return Midi().midi_pitch_to_freq(p); }
+// the explicit log2 / exp10 of the analysis path (oracle_math.hpp), for the known-answer test against libm
+void ora_det_math(const double *x, int64_t n, int which, double *out) {
+  for (int64_t i = 0; i < n; ++i) out[i] = which == 0 ? det_log2(x[i]) : which == 1 ? det_log10(x[i]) : det_exp10(x[i]);
+}
 float ora_equal_loudness_volume_db(double pitch, int level) { return loudness::equal_loudness_volume_db(pitch, level); }
 void ora_stereo(double pan, double *l, double *r) { auto g = stereo(pan); *l = g.gains[0]; *r = g.gains[1]; }
 float ora_hash_uniform_pm1(uint64_t seed, uint64_t noteid, uint64_t salt) { return hash_uniform_pm1(seed, noteid, salt); }

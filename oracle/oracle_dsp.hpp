@@ -14,6 +14,8 @@
 #include <cstdint>
 #include <vector>
 
+#include "oracle_math.hpp"
+
 namespace ora {
 
 // get_fft_length_for(n, zero_padding_factor) — call sites rt.resynth.lib.periodicfft.cpp:195,218,275.
@@ -31,6 +33,17 @@ inline int get_fft_length_for(int n, int zero_padding_factor) {
 // X_k = sum x_n e^{-2 pi i n k / L}; inverse is unnormalised too and callers scale by 1/L.
 // Iterative radix-2 decimation-in-time, twiddles from cos/sin directly.
 // ---------------------------------------------------------------------------------------------
+// e^{ia} from separate cos and sin calls that a compiler cannot merge into one sincos call (the second argument passes through a
+// volatile): glibc's sincos differs from its sin / cos by an ulp at a few arguments per table (k = 1955 of L = 4096, ...), and g++ -O2
+// does merge the plain pair — enough to change single spectrum bins between two builds of the same source.  The product's host code
+// builds its tables the same way.
+inline std::complex<double> twiddle(double a) {
+  volatile double a_again = a;
+  const double c = std::cos(a);
+  const double s = std::sin(a_again);
+  return {c, s};
+}
+
 struct FftPlan {
   int n = 0;
   std::vector<std::complex<double>> tw; // e^{-2 pi i k / n}, k < n/2
@@ -39,10 +52,7 @@ struct FftPlan {
   void init(int n_) {
     n = n_;
     tw.resize(n / 2 > 0 ? n / 2 : 1);
-    for (int k = 0; k < n / 2; ++k) {
-      double a = -2.0 * M_PI * k / n;
-      tw[k] = {std::cos(a), std::sin(a)};
-    }
+    for (int k = 0; k < n / 2; ++k) tw[k] = twiddle(-2.0 * M_PI * k / n);
     rev.assign(n, 0);
     int bits = 0;
     while ((1 << bits) < n) ++bits;
@@ -82,10 +92,7 @@ struct RealFft {
     L = L_;
     half.init(L / 2);
     tw.resize(L / 2 + 1);
-    for (int k = 0; k <= L / 2; ++k) {
-      double a = -2.0 * M_PI * k / L;
-      tw[k] = {std::cos(a), std::sin(a)};
-    }
+    for (int k = 0; k <= L / 2; ++k) tw[k] = twiddle(-2.0 * M_PI * k / L);
     z.resize(L / 2);
   }
   void forward(const double *x, std::complex<double> *X) {
@@ -176,8 +183,11 @@ struct SqMagFft {
 };
 
 // SqMagToDb / DbToMag (lib.cpp:1594, algo.cpp:25, resynth.hpp:86).
-// Decision: 10 log10(x) with x floored at 1e-300 (keeps exact zeros finite); 10^(dB/20).
-inline double sqmag_to_db(double x) { return 10.0 * std::log10(x > 1e-300 ? x : 1e-300); }
+// Decision: 10 log10(x) with x floored at 1e-300 (keeps exact zeros finite); 10^(dB/20).  On the analysis path (peak dB values, peak
+// volumes) the logarithm and the power are the explicit sequences of oracle_math.hpp — events depend on their last bits, see there;
+// the note driver's volume (resynth.hpp:86, continuous only) keeps the libm power, as the product's host code does.
+inline double sqmag_to_db(double x) { return 10.0 * det_log10(x > 1e-300 ? x : 1e-300); }
+inline double db_to_mag_analysis(double db) { return det_exp10(db / 20.0); }
 inline double db_to_mag(double db) { return std::pow(10.0, db / 20.0); }
 
 struct FreqMag { double freq; double mag_db; };

@@ -65,6 +65,8 @@ def lib():
         L.ora_frequency_to_midi_pitch.restype = C.c_double
         L.ora_frequency_to_midi_pitch.argtypes = [C.c_double]
         L.ora_midi_pitch_to_freq.restype = C.c_double
+        L.ora_det_math.restype = None
+        L.ora_det_math.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         L.ora_midi_pitch_to_freq.argtypes = [C.c_double]
         L.ora_equal_loudness_volume_db.restype = C.c_float
         L.ora_equal_loudness_volume_db.argtypes = [C.c_double, C.c_int]
@@ -201,3 +203,11 @@ def resynth_notes(start, end, freq, amp_db, stride, sr, cap=1 << 24):
                                 C.c_int32(sr), _p(out), C.c_int64(cap))
     assert n <= cap
     return out[:n]
+
+
+def det_math(x, which):
+    """oracle_math.hpp: which = 'log2' | 'log10' | 'exp10' over a float64 array."""
+    x = np.ascontiguousarray(x, np.float64)
+    out = np.empty_like(x)
+    lib().ora_det_math(x.ctypes.data, x.size, {"log2": 0, "log10": 1, "exp10": 2}[which], out.ctypes.data)
+    return out

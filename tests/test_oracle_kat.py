@@ -46,6 +46,24 @@ def test_midi_pitch_math(oracle):
     assert np.isnan(L.ora_frequency_to_midi_pitch(0.0))
 
 
+def test_explicit_log2_exp10_against_libm(oracle):
+    # oracle_math.hpp: the analysis path's log2 / log10 / exp10 as explicit IEEE operation sequences (the product evaluates the same
+    # sequences, csrc/ra_math.cuh).  Against libm (numpy): a few ulps, and exact where the result is a power of two.
+    rng = np.random.default_rng(5)
+    x = np.concatenate([np.exp(rng.uniform(np.log(1e-300), np.log(1e12), 200000)), 1.0 + rng.uniform(-1e-3, 1e-3, 20000),
+                        2.0 ** np.arange(-60, 60).astype(np.float64)])
+    got, ref = oracle.det_math(x, "log2"), np.log2(x)
+    ulp = np.spacing(np.maximum(np.abs(ref), 1e-300))
+    assert np.max(np.abs(got - ref) / ulp) <= 4.0
+    assert np.array_equal(oracle.det_math(2.0 ** np.arange(-60, 60).astype(np.float64), "log2"), np.arange(-60, 60).astype(np.float64))
+    got, ref = oracle.det_math(x, "log10"), np.log10(x)
+    assert np.max(np.abs(got - ref) / np.spacing(np.maximum(np.abs(ref), 1e-300))) <= 6.0
+    y = rng.uniform(-15.0, 5.0, 200000)   # dB / 20 of peak magnitudes
+    got, ref = oracle.det_math(y, "exp10"), 10.0 ** y
+    assert np.max(np.abs(got - ref) / np.spacing(ref)) <= 3.0
+    assert np.array_equal(oracle.det_math(np.array([0.0]), "exp10"), np.array([1.0]))
+
+
 @pytest.mark.parametrize("L", [2, 4, 64, 1024, 4096, 8192])
 def test_fft_vs_numpy(oracle, L):
     rng = np.random.default_rng(L)
