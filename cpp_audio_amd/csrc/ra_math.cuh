@@ -44,3 +44,19 @@ __device__ inline double ra_exp10(double x) {
   const long long ni = (long long)n;
   return p * __longlong_as_double((ni + 1023) << 52); // 2^n, n well inside the normal range for |x| < 300
 }
+
+// 2^t for |t| < 1000: n = round(t), f = t - n (exact), 2^f by the series above.
+__device__ inline double ra_exp2(double t) {
+  const double n = rint(t);
+  const double f = t - n;
+  const double g = f * 0.69314718055994531;
+  double p = 1.0 / 87178291200.0;
+  p = fma(p, g, 1.0 / 6227020800.0); p = fma(p, g, 1.0 / 479001600.0); p = fma(p, g, 1.0 / 39916800.0); p = fma(p, g, 1.0 / 3628800.0);
+  p = fma(p, g, 1.0 / 362880.0); p = fma(p, g, 1.0 / 40320.0); p = fma(p, g, 1.0 / 5040.0); p = fma(p, g, 1.0 / 720.0);
+  p = fma(p, g, 1.0 / 120.0); p = fma(p, g, 1.0 / 24.0); p = fma(p, g, 1.0 / 6.0); p = fma(p, g, 0.5);
+  p = fma(p, g, 1.0); p = fma(p, g, 1.0);
+  const long long ni = (long long)n;
+  return p * __longlong_as_double((ni + 1023) << 52);
+}
+// base^y for a positive normal base, as 2^(y log2 base) (the exponent's rounding error grows with |y|: ~6 ulp at |y| = 70)
+__device__ inline double ra_pow(double base, double y) { return ra_exp2(y * ra_log2(base)); }

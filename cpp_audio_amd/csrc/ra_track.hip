@@ -17,6 +17,7 @@
 // (the k-th note-on candidate in loudness order gets the k-th free channel in channel order — what the reference's
 // sequential first-free search yields, since channels only get taken inside one frame).
 #include "ra_internal.h"
+#include "ra_math.cuh"
 
 extern __shared__ __align__(16) unsigned char ra_smem_trk[];
 
@@ -92,7 +93,7 @@ __global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, i
     for (int i = lane; i < A; i += 64) {
       double pt = b.pl_pitch[lbase + i], v = b.pl_vol[lbase + i];
       pitch[i] = pt; vol[i] = v; key[i] = b.pl_key[lbase + i];
-      float f = (float)((double)440.f * pow(p.half_tone_ratio, pt - 69.0));
+      float f = (float)((double)440.f * ra_pow(p.half_tone_ratio, pt - 69.0)); // midi.h:258-264; the power as in oracle_math.hpp (events are compared bit for bit)
       nf[i] = f;
       nv[i] = (float)((double)p.analysis_volume * v / (double)0.1f);
       nmc[i] = min_change_for(f, p.sample_rate);

@@ -32,7 +32,7 @@ double ora_frequency_to_midi_pitch(double f) { auto p = Midi().frequency_to_midi
 double ora_midi_pitch_to_freq(double p) { return Midi().midi_pitch_to_freq(p); }
 // the explicit log2 / exp10 of the analysis path (oracle_math.hpp), for the known-answer test against libm
 void ora_det_math(const double *x, int64_t n, int which, double *out) {
-  for (int64_t i = 0; i < n; ++i) out[i] = which == 0 ? det_log2(x[i]) : which == 1 ? det_log10(x[i]) : det_exp10(x[i]);
+  for (int64_t i = 0; i < n; ++i) out[i] = which == 0 ? det_log2(x[i]) : which == 1 ? det_log10(x[i]) : which == 2 ? det_exp10(x[i]) : Midi().midi_pitch_to_freq_event(x[i]);
 }
 float ora_equal_loudness_volume_db(double pitch, int level) { return loudness::equal_loudness_volume_db(pitch, level); }
 void ora_stereo(double pan, double *l, double *r) { auto g = stereo(pan); *l = g.gains[0]; *r = g.gains[1]; }

@@ -55,4 +55,20 @@ inline double det_exp10(double x) {
   return p * bits_to_double(static_cast<uint64_t>(ni + 1023) << 52);
 }
 
+// 2^t for |t| < 1000: n = round(t), f = t - n (exact), 2^f by the same series.
+inline double det_exp2(double t) {
+  const double n = std::rint(t);
+  const double f = t - n;
+  const double g = f * 0.69314718055994531;
+  double p = 1.0 / 87178291200.0;
+  p = std::fma(p, g, 1.0 / 6227020800.0); p = std::fma(p, g, 1.0 / 479001600.0); p = std::fma(p, g, 1.0 / 39916800.0); p = std::fma(p, g, 1.0 / 3628800.0);
+  p = std::fma(p, g, 1.0 / 362880.0); p = std::fma(p, g, 1.0 / 40320.0); p = std::fma(p, g, 1.0 / 5040.0); p = std::fma(p, g, 1.0 / 720.0);
+  p = std::fma(p, g, 1.0 / 120.0); p = std::fma(p, g, 1.0 / 24.0); p = std::fma(p, g, 1.0 / 6.0); p = std::fma(p, g, 0.5);
+  p = std::fma(p, g, 1.0); p = std::fma(p, g, 1.0);
+  const int64_t ni = static_cast<int64_t>(n);
+  return p * bits_to_double(static_cast<uint64_t>(ni + 1023) << 52);
+}
+// base^y for a positive normal base, as 2^(y log2 base)
+inline double det_pow(double base, double y) { return det_exp2(y * det_log2(base)); }
+
 } // namespace ora

@@ -322,7 +322,7 @@ struct RtResynthOffline {
     for (int idx : order) {
       int const pitch_change = pitch_changes[idx];
       double const new_pitch = autotuned_pitches[idx].midipitch;
-      float const new_freq = static_cast<float>(midi.midi_pitch_to_freq(new_pitch));
+      float const new_freq = static_cast<float>(midi.midi_pitch_to_freq_event(new_pitch));
       float const volume = static_cast<float>(cfg.analysis_volume * autotuned_pitches[idx].volume / reduceUnadjustedVolumes);
       if (pitch_change >= 0) {
         PlayedNote &played = played_pitches[pitch_change];

@@ -206,8 +206,8 @@ def resynth_notes(start, end, freq, amp_db, stride, sr, cap=1 << 24):
 
 
 def det_math(x, which):
-    """oracle_math.hpp: which = 'log2' | 'log10' | 'exp10' over a float64 array."""
+    """oracle_math.hpp: which = 'log2' | 'log10' | 'exp10' | 'pitch_to_freq' (440 * det_pow(2^(1/12), x - 69)) over a float64 array."""
     x = np.ascontiguousarray(x, np.float64)
     out = np.empty_like(x)
-    lib().ora_det_math(x.ctypes.data, x.size, {"log2": 0, "log10": 1, "exp10": 2}[which], out.ctypes.data)
+    lib().ora_det_math(x.ctypes.data, x.size, {"log2": 0, "log10": 1, "exp10": 2, "pitch_to_freq": 3}[which], out.ctypes.data)
     return out

@@ -62,6 +62,10 @@ def test_explicit_log2_exp10_against_libm(oracle):
     got, ref = oracle.det_math(y, "exp10"), 10.0 ** y
     assert np.max(np.abs(got - ref) / np.spacing(ref)) <= 3.0
     assert np.array_equal(oracle.det_math(np.array([0.0]), "exp10"), np.array([1.0]))
+    pit = rng.uniform(0.0, 140.0, 200000)  # event frequencies: 440 * (2^(1/12))^(pitch - 69) within a few ulps of libm's power
+    got, ref = oracle.det_math(pit, "pitch_to_freq"), 440.0 * np.power(2.0 ** (1.0 / 12.0), pit - 69.0)
+    assert np.max(np.abs(got - ref) / np.spacing(ref)) <= 16.0
+    assert np.mean(got.astype(np.float32) != ref.astype(np.float32)) < 1e-5
 
 
 @pytest.mark.parametrize("L", [2, 4, 64, 1024, 4096, 8192])
