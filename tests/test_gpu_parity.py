@@ -422,11 +422,16 @@ def test_c4_many_streams_properties(api, oracle, sig):
         ctx.synchronize()
         assert ctx.stats().error_flags == 0
     assert float((torch.cat([o1, o2], dim=1).double() - whole.double()).abs().max()) < 1e-6
+    # every stream against the oracle (one thread per host core).  With autotune the pitches sit on a semitone grid and notes one
+    # semitone apart tie with max_track_pitches = 1: a single event decided differently shows as an RMS of 1e-2, not 1e-5 — this is
+    # the test that found the ulp-level differences the bit-reproducible decision path removed.
+    import os
     hv = voice.cpu().numpy()
-    for s in (0, 383):
-        ref, _, _ = oracle.run_offline(oracle.default_config(**dict(k, seed=k["seed"] + s)), hv[s])
-        assert np.sqrt(np.mean(ref.astype(np.float64) ** 2)) > 1e-4
-        assert rms(whole[s].cpu().numpy(), ref) <= RMS_TOL
+    ref = oracle.run_offline_batch(oracle.default_config(**k), hv, n_threads=min(len(os.sched_getaffinity(0)), 32))
+    got = whole.cpu().numpy()
+    err = np.sqrt(np.mean((got.astype(np.float64) - ref.astype(np.float64)) ** 2, axis=(1, 2)))
+    assert np.sqrt(np.mean(ref.astype(np.float64) ** 2)) > 1e-3
+    assert err.max() <= RMS_TOL, f"streams {np.nonzero(err > RMS_TOL)[0].tolist()[:10]}: rms up to {err.max():.3g}"
 
 
 def test_overlapped_blocks_equal_stream_ordered_blocks(api, sig):
