@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep (GPU box): random configurations of the analysis / decision / synthesis path on short random streams,
+checked like tests/test_gpu_parity.py:check_streams (frame schedule, pitch / volume lists bit for bit, every event field, audio RMS).
+
+    python scripts/gpu_parity_fuzz.py [n_configs] [seed]
+"""
+import os
+import sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as oracle
+from cpp_audio_amd import api, signals
+
+n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+GPU_ONLY = ("reference_order", "max_pitches_per_frame")
+
+
+def random_config():
+    sr = int(rng.choice([44100, 48000]))
+    N = int(rng.choice([800, 1024, 1026, 2048, 4096, 4800, 8000, 8192]))
+    H = int(rng.choice([N // 4, N // 2, 300, 1024, N + 100])) if rng.random() < 0.8 else int(rng.integers(64, 3000))
+    kw = dict(sample_rate=sr, window_size=N, stride=max(H, 16), n_channels=int(rng.choice([8, 16, 64, 128])), analysis_volume=1.0,
+              stereo_spread=float(rng.choice([0.0, 0.0, 1.0])), carrier_volume=0.0, seed=int(rng.integers(1, 1 << 30)),
+              window_kind=int(rng.choice([0, 0, 0, 1, 2])))
+    if rng.random() < 0.6:
+        kw.update(use_autotune=1, autotune_type=int(rng.integers(0, 3)), autotune_scale_mode=int(rng.integers(0, 4)), autotune_root_note=int(rng.integers(0, 12)),
+                  autotune_root_transpose=int(rng.integers(-5, 6)), autotune_chord_frequencies=int(rng.integers(0, 3)), autotune_factor=int(rng.integers(1, 5)),
+                  autotune_tolerance_pitches=float(rng.choice([100.0, 100.0, 0.5, 0.3])))
+    if rng.random() < 0.3: kw.update(pitch_shift_pre_autotune=float(rng.integers(-12, 13)), pitch_shift_post_autotune=float(rng.integers(-12, 13)))
+    if rng.random() < 0.3: kw.update(pitch_harmonize_pre_autotune=float(rng.choice([0.0, 7.0, 12.0])), pitch_harmonize_post_autotune=float(rng.choice([0.0, 4.0])))
+    if rng.random() < 0.3: kw.update(min_volume=float(rng.choice([1e-4, 1e-3, 1e-2])), nearby_distance_tones=float(rng.choice([0.4, 1.0, 1.5])),
+                                     max_track_pitches=float(rng.choice([1.0, 0.3, 2.0])))
+    if rng.random() < 0.3: kw.update(env_attack_seconds=0.01, env_decay_seconds=0.03, env_release_seconds=0.05, env_sustain_level=0.7)
+    if rng.random() < 0.2: kw.update(reference_order=1)
+    return kw
+
+
+bad = 0
+for ci in range(n_cfg):
+    kw = random_config()
+    n = int(rng.integers(20000, 60000))
+    x = signals.make_streams(2, n, sr=kw["sample_rate"], base_seed=int(rng.integers(0, 10000)), kind=str(rng.choice(["partials", "speech"])))
+    okw = {a: v for a, v in kw.items() if a not in GPU_ONLY}
+    msg = []
+    try:
+        with api.Context(api.default_config(**kw), 2, 0) as ctx:
+            out = ctx.process_host(x)
+            st = ctx.stats()
+            for s in range(2):
+                ocfg = oracle.default_config(**dict(okw, seed=okw["seed"] + s))
+                ref, ev, dropped = oracle.run_offline(ocfg, x[s])
+                fire, offs, pitch, vol = oracle.run_frames(ocfg, x[s])
+                gfire, goffs, gpitch, gvol = ctx.frame_pitches(s)
+                ev = ev[ev["type"] != 3]
+                gev = ctx.events(s)
+                if not np.array_equal(fire, gfire) or not np.array_equal(offs, goffs): msg.append(f"s{s}: frame schedule / list sizes")
+                elif not np.array_equal(pitch, gpitch) or not np.array_equal(vol, gvol): msg.append(f"s{s}: lists differ (pitch {np.max(np.abs(pitch - gpitch)):.2g})")
+                if len(ev) != len(gev) or any(not np.array_equal(ev[f], gev[f]) for f in ("sample", "type", "channel", "noteid", "frequency", "velocity")):
+                    msg.append(f"s{s}: events {len(ev)}/{len(gev)}")
+                e = float(np.sqrt(np.mean((out[s].astype(np.float64) - ref.astype(np.float64)) ** 2)))
+                if e > 1e-5: msg.append(f"s{s}: rms {e:.2g}")
+            if st.error_flags: msg.append(f"error_flags {st.error_flags}")
+    except api.RaError as e:
+        msg.append(f"RaError {e}")
+    if msg:
+        bad += 1
+        print(f"config {ci} FAILED: {msg}\n   {kw}")
+print(f"{n_cfg - bad} of {n_cfg} random configurations agree with the restatement (bit for bit on the decision path)")
+sys.exit(1 if bad else 0)
