@@ -12,12 +12,10 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as oracle
 from cpp_audio_amd import api, signals
 
-n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
 GPU_ONLY = ("reference_order", "max_pitches_per_frame")
 
 
-def random_config():
+def random_config(rng):
     sr = int(rng.choice([44100, 48000]))
     N = int(rng.choice([800, 1024, 1026, 2048, 4096, 4800, 8000, 8192]))
     H = int(rng.choice([N // 4, N // 2, 300, 1024, N + 100])) if rng.random() < 0.8 else int(rng.integers(64, 3000))
@@ -37,35 +35,44 @@ def random_config():
     return kw
 
 
-bad = 0
-for ci in range(n_cfg):
-    kw = random_config()
-    n = int(rng.integers(20000, 60000))
-    x = signals.make_streams(2, n, sr=kw["sample_rate"], base_seed=int(rng.integers(0, 10000)), kind=str(rng.choice(["partials", "speech"])))
-    okw = {a: v for a, v in kw.items() if a not in GPU_ONLY}
-    msg = []
-    try:
-        with api.Context(api.default_config(**kw), 2, 0) as ctx:
-            out = ctx.process_host(x)
-            st = ctx.stats()
-            for s in range(2):
-                ocfg = oracle.default_config(**dict(okw, seed=okw["seed"] + s))
-                ref, ev, dropped = oracle.run_offline(ocfg, x[s])
-                fire, offs, pitch, vol = oracle.run_frames(ocfg, x[s])
-                gfire, goffs, gpitch, gvol = ctx.frame_pitches(s)
-                ev = ev[ev["type"] != 3]
-                gev = ctx.events(s)
-                if not np.array_equal(fire, gfire) or not np.array_equal(offs, goffs): msg.append(f"s{s}: frame schedule / list sizes")
-                elif not np.array_equal(pitch, gpitch) or not np.array_equal(vol, gvol): msg.append(f"s{s}: lists differ (pitch {np.max(np.abs(pitch - gpitch)):.2g})")
-                if len(ev) != len(gev) or any(not np.array_equal(ev[f], gev[f]) for f in ("sample", "type", "channel", "noteid", "frequency", "velocity")):
-                    msg.append(f"s{s}: events {len(ev)}/{len(gev)}")
-                e = float(np.sqrt(np.mean((out[s].astype(np.float64) - ref.astype(np.float64)) ** 2)))
-                if e > 1e-5: msg.append(f"s{s}: rms {e:.2g}")
-            if st.error_flags: msg.append(f"error_flags {st.error_flags}")
-    except api.RaError as e:
-        msg.append(f"RaError {e}")
-    if msg:
-        bad += 1
-        print(f"config {ci} FAILED: {msg}\n   {kw}")
-print(f"{n_cfg - bad} of {n_cfg} random configurations agree with the restatement (bit for bit on the decision path)")
-sys.exit(1 if bad else 0)
+def run(n_cfg, seed, verbose=True):
+    """Returns the list of failing configurations (empty = all agree)."""
+    rng = np.random.default_rng(seed)
+    failures = []
+    for ci in range(n_cfg):
+        kw = random_config(rng)
+        n = int(rng.integers(20000, 60000))
+        x = signals.make_streams(2, n, sr=kw["sample_rate"], base_seed=int(rng.integers(0, 10000)), kind=str(rng.choice(["partials", "speech"])))
+        okw = {a: v for a, v in kw.items() if a not in GPU_ONLY}
+        msg = []
+        try:
+            with api.Context(api.default_config(**kw), 2, 0) as ctx:
+                out = ctx.process_host(x)
+                st = ctx.stats()
+                for s in range(2):
+                    ocfg = oracle.default_config(**dict(okw, seed=okw["seed"] + s))
+                    ref, ev, dropped = oracle.run_offline(ocfg, x[s])
+                    fire, offs, pitch, vol = oracle.run_frames(ocfg, x[s])
+                    gfire, goffs, gpitch, gvol = ctx.frame_pitches(s)
+                    ev = ev[ev["type"] != 3]
+                    gev = ctx.events(s)
+                    if not np.array_equal(fire, gfire) or not np.array_equal(offs, goffs): msg.append(f"s{s}: frame schedule / list sizes")
+                    elif not np.array_equal(pitch, gpitch) or not np.array_equal(vol, gvol): msg.append(f"s{s}: lists differ (pitch {np.max(np.abs(pitch - gpitch)):.2g})")
+                    if len(ev) != len(gev) or any(not np.array_equal(ev[f], gev[f]) for f in ("sample", "type", "channel", "noteid", "frequency", "velocity")):
+                        msg.append(f"s{s}: events {len(ev)}/{len(gev)}")
+                    e = float(np.sqrt(np.mean((out[s].astype(np.float64) - ref.astype(np.float64)) ** 2)))
+                    if e > 1e-5: msg.append(f"s{s}: rms {e:.2g}")
+                if st.error_flags: msg.append(f"error_flags {st.error_flags}")
+        except api.RaError as e:
+            msg.append(f"RaError {e}")
+        if msg:
+            bad += 1
+            print(f"config {ci} FAILED: {msg}\n   {kw}")
+    return failures
+
+
+if __name__ == "__main__":
+    n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    failures = run(n_cfg, int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+    print(f"{n_cfg - len(failures)} of {n_cfg} random configurations agree with the restatement (bit for bit on the decision path)")
+    sys.exit(1 if failures else 0)

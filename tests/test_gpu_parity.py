@@ -434,6 +434,19 @@ def test_c4_many_streams_properties(api, oracle, sig):
     assert err.max() <= RMS_TOL, f"streams {np.nonzero(err > RMS_TOL)[0].tolist()[:10]}: rms up to {err.max():.3g}"
 
 
+def test_randomised_configurations(api, oracle):
+    # scripts/gpu_parity_fuzz.py: random window sizes / strides / channel counts / autotune, shift, harmonize, envelope and threshold
+    # settings on short random streams, checked like check_streams (400 of 400 agree on the GPU box; a slice of them here)
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "gpu_parity_fuzz.py")
+    spec = importlib.util.spec_from_file_location("gpu_parity_fuzz", path)
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    failures = fuzz.run(30, 11, verbose=False)
+    assert not failures, failures[:3]
+
+
 def test_overlapped_blocks_equal_stream_ordered_blocks(api, sig):
     # ra_process_device_async: block k + 1's analysis / tracking / propagation overlap block k's render (double-buffered scratch);
     # every stage still runs its blocks in order, so the bits equal those of the synchronous calls
