@@ -126,9 +126,13 @@ __global__ void __launch_bounds__(T, 4) ra_voc_modulator_kernel(RaParams p, RaBu
 // T threads per frame: one wavefront for the usual short carrier frames (L = 512: 32 radix-8 groups per pass), 256 for long ones.
 template <int T>
 __global__ void __launch_bounds__(T) ra_voc_carrier_kernel(RaParams p, RaBuffers b, const float *__restrict__ carrier, int64_t t0, int64_t n, int64_t i_lo,
-                                                          int64_t j_lo, int64_t n_mod) {
-  const int tid = threadIdx.x, ib = blockIdx.x, s = blockIdx.y;
-  const int M = p.voc_Mc, L = p.voc_Lc, S = p.voc_S, W = 2 * p.voc_S, B = p.voc_bands, log2M = ilog2(M);
+                                                          int64_t j_lo, int64_t n_mod, int n_car, int fpw) {
+  // a workgroup takes fpw consecutive frames of its stream, like the modulator's (tid and M laundered against hoisting)
+  const int s = blockIdx.y;
+  for (int ib = blockIdx.x * fpw, ib_end = min(ib + fpw, n_car); ib < ib_end; ++ib) {
+  int tid = threadIdx.x, M = p.voc_Mc;
+  asm volatile("" : "+v"(tid), "+s"(M));
+  const int L = p.voc_Lc, S = p.voc_S, W = 2 * p.voc_S, B = p.voc_bands, log2M = ilog2(M);
   double2 *z = reinterpret_cast<double2 *>(ra_smem_voc);  // [ra_zsize(M)] transform buffer
   double2 *zin = z + ra_zsize(M);                      // [M] input of the inverse transform
   const int zs = ra_zshift(log2M);
@@ -201,6 +205,8 @@ __global__ void __launch_bounds__(T) ra_voc_carrier_kernel(RaParams p, RaBuffers
   for (int q = tid; q < W; q += T) {
     double2 v = Z(q >> 1);
     dst[q] = ((q & 1) ? -v.y : v.x) * scale;
+  }
+  __syncthreads(); // both buffers are reused by the next frame
   }
 }
 
@@ -300,11 +306,15 @@ void ra_launch_vocoder(const RaParams &p, const RaBuffers &b, const float *d_voi
     else hipLaunchKernelGGL(ra_voc_modulator_kernel<256>, grid, dim3(256), lds, st, p, b, d_voice, t0, n, mod.lo, (int)mod.count, fpw);
   }
   if (car.count > 0) {
-    const dim3 grid((unsigned)car.count, (unsigned)p.n_streams);
+    static const int cfpw_env = [] { const char *e = getenv("RA_VOC_CARRIER_FPW"); return e ? atoi(e) : 0; }();
+    int cfpw = 8; // frames per workgroup, as for the modulator
+    while (cfpw > 1 && ((car.count + cfpw - 1) / cfpw) * (int64_t)p.n_streams < 4096) cfpw >>= 1;
+    if (cfpw_env > 0) cfpw = cfpw_env;
+    const dim3 grid((unsigned)((car.count + cfpw - 1) / cfpw), (unsigned)p.n_streams);
     const int Mc = std::max(p.voc_Mc, 1);
     const size_t lds = ((size_t)ra_zsize(Mc) + Mc) * sizeof(double2);
-    if (Mc <= 512) hipLaunchKernelGGL(ra_voc_carrier_kernel<64>, grid, dim3(64), lds, st, p, b, d_carrier, t0, n, car.lo, mod.lo, mod.count);
-    else hipLaunchKernelGGL(ra_voc_carrier_kernel<256>, grid, dim3(256), lds, st, p, b, d_carrier, t0, n, car.lo, mod.lo, mod.count);
+    if (Mc <= 512) hipLaunchKernelGGL(ra_voc_carrier_kernel<64>, grid, dim3(64), lds, st, p, b, d_carrier, t0, n, car.lo, mod.lo, mod.count, (int)car.count, cfpw);
+    else hipLaunchKernelGGL(ra_voc_carrier_kernel<256>, grid, dim3(256), lds, st, p, b, d_carrier, t0, n, car.lo, mod.lo, mod.count, (int)car.count, cfpw);
   }
   {
     unsigned gx = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
