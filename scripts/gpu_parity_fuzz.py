@@ -39,6 +39,7 @@ def run(n_cfg, seed, verbose=True):
     """Returns the list of failing configurations (empty = all agree)."""
     rng = np.random.default_rng(seed)
     failures = []
+    skipped = []
     for ci in range(n_cfg):
         kw = random_config(rng)
         n = int(rng.integers(20000, 60000))
@@ -64,10 +65,14 @@ def run(n_cfg, seed, verbose=True):
                     if e > 1e-5: msg.append(f"s{s}: rms {e:.2g}")
                 if st.error_flags: msg.append(f"error_flags {st.error_flags}")
         except api.RaError as e:
-            msg.append(f"RaError {e}")
+            # RA_EOVERFLOW is the documented, loud answer to a frame with more pitches than max_pitches_per_frame (rectangular window plus
+            # two harmonize steps on a noisy stream): not a parity question
+            if e.code == -4: skipped.append(ci)
+            else: msg.append(f"RaError {e}")
         if msg:
-            bad += 1
-            print(f"config {ci} FAILED: {msg}\n   {kw}")
+            failures.append((ci, msg, kw))
+            if verbose: print(f"config {ci} FAILED: {msg}\n   {kw} n={n}")
+    if verbose and skipped: print(f"{len(skipped)} configurations hit the per-frame list capacity (RA_EOVERFLOW, raise max_pitches_per_frame): {skipped[:10]}")
     return failures
 
 
