@@ -11,6 +11,7 @@
 #include <vector>
 
 static thread_local std::string g_last_error;
+#define RA_TRY(expr) do { if (int rc_ = (expr)) return rc_; } while (0)
 static int fail(int code, const std::string &msg) { g_last_error = msg; return code; }
 
 #define HIP_TRY(expr)                                                                                          \
@@ -60,6 +61,9 @@ struct ra_context {
     bool used = false;
   } scr[2];
   int parity = 0;
+  // a block failed after it had started to change stream state (launches issued, histories rolled): the streams are then neither at the
+  // block's start nor at its end, and every entry point returns RA_EINTERNAL until ra_reset
+  bool poisoned = false;
   bool pending_join = false; // asynchronous blocks are in flight on the internal streams; the caller's stream has not been made to wait yet
 };
 
@@ -331,40 +335,9 @@ int build_tables(ra_context *c) {
   RaBuffers &b = c->b;
   std::memset(&b, 0, sizeof(b));
   int r;
-  { // half window: Gaussian truncated at 4 sigma, normalised so the full window sums to 2
-    int n = p.N / 2;
-    std::vector<double> hw(n);
-    double sigma = n / 4.0, sum = 0;
-    for (int j = 0; j < n; ++j) {
-      double d = j + 0.5;
-      hw[j] = cfg.window_kind == RA_WINDOW_GAUSSIAN4 ? std::exp(-(d * d) / (2.0 * sigma * sigma))
-              : cfg.window_kind == RA_WINDOW_HANN   ? 0.5 * (1.0 + std::cos(M_PI * d / n))
-                                                    : 1.0;
-      sum += hw[j];
-    }
-    for (auto &v : hw) v /= sum;
-    if ((r = upload(c, &b.half_window, hw))) return r;
-  }
-  {
-    int M = p.M;
-    std::vector<double2> tw(std::max(M / 2, 1));
-    // separate cos and sin calls that cannot be merged into one sincos call (volatile): glibc's sincos differs from its sin / cos by an
-  // ulp at a few arguments per table, and whether a compiler merges the pair is its own business (g++ -O2 does); the CPU restatement
-  // builds its tables the same way
-  auto twiddle = [](double a) { volatile double a_again = a; const double cs = std::cos(a); const double sn = std::sin(a_again); return make_double2(cs, sn); };
-  for (int k = 0; k < M / 2; ++k) tw[k] = twiddle(-2.0 * M_PI * k / M);
-    if ((r = upload(c, &b.tw_half, tw))) return r;
-    std::vector<double2> tf(M + 1);
-    for (int k = 0; k <= M; ++k) { double a = -2.0 * M_PI * k / p.L; tf[k] = make_double2(std::cos(a), std::sin(a)); }
-    if ((r = upload(c, &b.tw_full, tf))) return r;
-    std::vector<int> rev(std::max(M, 1), 0);
-    for (int i = 0; i < M; ++i) {
-      int x = 0;
-      for (int bit = 0; bit < p.log2M; ++bit) if (i & (1 << bit)) x |= 1 << (p.log2M - 1 - bit);
-      rev[i] = x;
-    }
-    if ((r = upload(c, &b.bitrev, rev))) return r;
-  }
+  // half window: Gaussian truncated at 4 sigma, normalised so the full window sums to 2
+  if ((r = upload(c, &b.half_window, make_half_window(cfg.window_kind, p.N / 2)))) return r;
+  if ((r = upload_fft_tables(c, p.L, &b.tw_half, &b.tw_full, &b.bitrev))) return r;
   { // include/loudness.h: pitches table (:43-54) and the 60 phon row of elvs (:199-229, lib.cpp:1717)
     std::vector<double> lp(29);
     std::vector<float> elv(29);
@@ -549,14 +522,21 @@ int resolve_timing(ra_context *c) {
 
 template <typename F>
 int timed_launch(ra_context *c, int stage, hipStream_t st, F &&launch) {
-  if (!c->profiling) { launch(); return RA_OK; }
+  // a refused launch (grid / LDS / register limits) is reported by the launch that failed, not by whatever consumes its output later
+  auto checked = [&]() -> int {
+    launch();
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return fail(RA_EHIP, std::string("kernel launch failed: ") + hipGetErrorString(le));
+    return RA_OK;
+  };
+  if (!c->profiling) return checked();
   hipEvent_t ev[2];
   for (auto &e : ev) {
     if (c->ev_pool.empty()) { HIP_TRY(hipEventCreate(&e)); }
     else { e = c->ev_pool.back(); c->ev_pool.pop_back(); }
   }
   HIP_TRY(hipEventRecord(ev[0], st));
-  launch();
+  if (int lr = checked()) { c->ev_pool.push_back(ev[0]); c->ev_pool.push_back(ev[1]); return lr; }
   HIP_TRY(hipEventRecord(ev[1], st));
   c->timed.push_back({stage, ev[0], ev[1]});
   if (c->timed.size() > 8192) return resolve_timing(c); // bounds the event pool when nobody reads the timers (waits for those launches)
@@ -578,7 +558,7 @@ int join_streams(ra_context *c) {
 // streams chained by events.  Tracking and propagation are dependency chains over frames that occupy a few hundred
 // wavefronts; cutting the block lets the throughput kernels (analysis of later chunks, render of earlier ones) fill the
 // rest of the chip meanwhile.  Results do not depend on the cut (each chunk continues the carried state exactly).
-int process_block(ra_context *c, const float *d_voice, const float *d_carrier, int64_t n, float *d_out, double *d_out_d, bool async = false) {
+int process_block_impl(ra_context *c, const float *d_voice, const float *d_carrier, int64_t n, float *d_out, double *d_out_d, bool async, bool &started) {
   if (n <= 0) return RA_OK;
   HIP_TRY(hipSetDevice(c->device));
   RaParams &p = c->p;
@@ -596,8 +576,9 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
   if (p.fb_gain != 0.f) n_chunks = static_cast<int>(std::min<int64_t>(nfb, nfb / ((int64_t)p.fb_sz / p.H + 1) + 1)) + 2; // pieces (only sizes the hop-state buffer)
   const bool caller_stream_only = n_chunks == 1 || p.fb_gain != 0.f;
   if (caller_stream_only || p.voc_enabled) { if ((r = join_streams(c))) return r; async = false; }
-  c->parity ^= 1;
-  if ((r = ensure_scratch(c, nfb, n, n_chunks))) return r;
+  c->parity ^= 1; // (ensure_scratch binds the set `parity` names; a failure there flips it back: nothing has been launched yet)
+  if ((r = ensure_scratch(c, nfb, n, n_chunks))) { c->parity ^= 1; return r; }
+  started = true;
   ra_context::Scratch &sc = c->scr[c->parity];
   c->b.dbg_sqmag = c->dbg_sqmag;
   c->b.dbg_clk = c->dbg_clk;
@@ -609,7 +590,7 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
     // last frame fires, i.e. only output of earlier pieces if a piece holds at most fb_sz / H + 1 analysis frames.  The pieces run one
     // after the other on the caller's stream (no overlap: that is the price of the dependency).
     const int64_t per = (int64_t)p.fb_sz / p.H + 1;
-    if (p.voc_enabled) timed_launch(c, ST_VOCODER, user, [&] { ra_launch_vocoder(p, b, d_voice, d_carrier, t0, n, user); });
+    if (p.voc_enabled) RA_TRY(timed_launch(c, ST_VOCODER, user, [&] { ra_launch_vocoder(p, b, d_voice, d_carrier, t0, n, user); }));
     // piece 0 holds no frame: it only renders the samples before the block's first frame fires (that frame's window looks back at them)
     int64_t fb0 = 0, fb1 = 0;
     int piece = 0;
@@ -619,26 +600,26 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
       sp.ct0 = (piece == 0) ? t0 : ra_fire_sample(p.N, p.H, f_lo + fb0);
       sp.ct1 = (fb1 == nfb) ? t0 + n : ra_fire_sample(p.N, p.H, f_lo + fb1);
       if (sp.nfb > 0) {
-        timed_launch(c, ST_ANALYSIS, user, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, sp.fb0, sp.nfb, nfb, user); });
-        timed_launch(c, ST_TRACK, user, [&] { ra_launch_track(p, b, f_lo, sp.fb0, sp.nfb, user); });
+        RA_TRY(timed_launch(c, ST_ANALYSIS, user, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, sp.fb0, sp.nfb, nfb, user); }));
+        RA_TRY(timed_launch(c, ST_TRACK, user, [&] { ra_launch_track(p, b, f_lo, sp.fb0, sp.nfb, user); }));
       }
-      timed_launch(c, ST_PROPAGATE, user, [&] { ra_launch_synth_propagate(p, b, sp, user); });
-      timed_launch(c, ST_RENDER, user, [&] { ra_launch_synth_render(p, b, sp, d_out, d_out_d, user); });
+      RA_TRY(timed_launch(c, ST_PROPAGATE, user, [&] { ra_launch_synth_propagate(p, b, sp, user); }));
+      RA_TRY(timed_launch(c, ST_RENDER, user, [&] { ra_launch_synth_render(p, b, sp, d_out, d_out_d, user); }));
       fb0 = fb1;
       fb1 = std::min(nfb, fb0 + per);
       ++piece;
     } while (fb0 < nfb);
-    timed_launch(c, ST_HISTORY, user, [&] { ra_launch_roll_feedback(p, b, n, user); });
+    RA_TRY(timed_launch(c, ST_HISTORY, user, [&] { ra_launch_roll_feedback(p, b, n, user); }));
     n_chunks = 1; // the window history is rolled on the caller's stream below
   } else if (n_chunks == 1) { // everything in order on the caller's stream
     RaSpan sp{t0, n, t0, t0 + n, f_lo, 0, nfb, 0};
-    timed_launch(c, ST_ANALYSIS, user, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, 0, nfb, nfb, user); });
-    timed_launch(c, ST_TRACK, user, [&] { ra_launch_track(p, b, f_lo, 0, nfb, user); });
-    if (p.voc_enabled) timed_launch(c, ST_VOCODER, user, [&] { ra_launch_vocoder(p, b, d_voice, d_carrier, t0, n, user); });
-    if (c->cfg.reference_order == 1) timed_launch(c, ST_RENDER, user, [&] { ra_launch_synth_serial(p, b, sp, d_out, d_out_d, user); });
+    RA_TRY(timed_launch(c, ST_ANALYSIS, user, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, 0, nfb, nfb, user); }));
+    RA_TRY(timed_launch(c, ST_TRACK, user, [&] { ra_launch_track(p, b, f_lo, 0, nfb, user); }));
+    if (p.voc_enabled) RA_TRY(timed_launch(c, ST_VOCODER, user, [&] { ra_launch_vocoder(p, b, d_voice, d_carrier, t0, n, user); }));
+    if (c->cfg.reference_order == 1) RA_TRY(timed_launch(c, ST_RENDER, user, [&] { ra_launch_synth_serial(p, b, sp, d_out, d_out_d, user); }));
     else {
-      timed_launch(c, ST_PROPAGATE, user, [&] { ra_launch_synth_propagate(p, b, sp, user); });
-      timed_launch(c, ST_RENDER, user, [&] { ra_launch_synth_render(p, b, sp, d_out, d_out_d, user); });
+      RA_TRY(timed_launch(c, ST_PROPAGATE, user, [&] { ra_launch_synth_propagate(p, b, sp, user); }));
+      RA_TRY(timed_launch(c, ST_RENDER, user, [&] { ra_launch_synth_render(p, b, sp, d_out, d_out_d, user); }));
     }
   } else {
     static const int prio_mode = std::getenv("RA_PIPELINE_PRIO") ? std::atoi(std::getenv("RA_PIPELINE_PRIO")) : 1;
@@ -682,7 +663,7 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
       HIP_TRY(hipStreamWaitEvent(sP, sc.ev_render_done, 0)); // propagation rewrites the hop states the render read
     }
     if (p.voc_enabled) { // independent of the analysis chain: runs beside it, only the render waits for the mix
-      timed_launch(c, ST_VOCODER, sR, [&] { ra_launch_vocoder(p, b, d_voice, d_carrier, t0, n, sR); });
+      RA_TRY(timed_launch(c, ST_VOCODER, sR, [&] { ra_launch_vocoder(p, b, d_voice, d_carrier, t0, n, sR); }));
     }
     // Chunk boundaries (in frames).  The first chunk is short — nothing overlaps its analysis -> tracking -> propagation, so the render
     // stream starts that much sooner — and so are the last two: when the analysis of the block is over, only the chain and the render of
@@ -723,13 +704,13 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
     if (order == 1 && !one_queue) sA = sR;
     auto front = [&](int i) -> int { // analysis of chunk i, and the two chains that hang off it
       const RaSpan sp = span_of(i);
-      timed_launch(c, ST_ANALYSIS, sA, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, sp.fb0, sp.nfb, nfb, sA); });
+      RA_TRY(timed_launch(c, ST_ANALYSIS, sA, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, sp.fb0, sp.nfb, nfb, sA); }));
       HIP_TRY(hipEventRecord(c->ev_chunk[0][i], sA));
       HIP_TRY(hipStreamWaitEvent(sT, c->ev_chunk[0][i], 0));
-      timed_launch(c, ST_TRACK, sT, [&] { ra_launch_track(p, b, f_lo, sp.fb0, sp.nfb, sT); });
+      RA_TRY(timed_launch(c, ST_TRACK, sT, [&] { ra_launch_track(p, b, f_lo, sp.fb0, sp.nfb, sT); }));
       HIP_TRY(hipEventRecord(c->ev_chunk[1][i], sT));
       HIP_TRY(hipStreamWaitEvent(sP, c->ev_chunk[1][i], 0));
-      timed_launch(c, ST_PROPAGATE, sP, [&] { ra_launch_synth_propagate(p, b, sp, sP); });
+      RA_TRY(timed_launch(c, ST_PROPAGATE, sP, [&] { ra_launch_synth_propagate(p, b, sp, sP); }));
       HIP_TRY(hipEventRecord(c->ev_chunk[2][i], sP));
       return RA_OK;
     };
@@ -740,10 +721,10 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
       if (i + ahead < n_chunks) if (int fr = front(i + ahead)) return fr;
       const RaSpan sp = span_of(i);
       HIP_TRY(hipStreamWaitEvent(sR, c->ev_chunk[2][i], 0));
-      timed_launch(c, ST_RENDER, sR, [&] { ra_launch_synth_render(p, b, sp, d_out, d_out_d, sR); });
+      RA_TRY(timed_launch(c, ST_RENDER, sR, [&] { ra_launch_synth_render(p, b, sp, d_out, d_out_d, sR); }));
     }
     // the window history for the next block: after this block's last analysis read of it, before the next block's first (same stream)
-    timed_launch(c, ST_HISTORY, sA, [&] { ra_launch_roll_history(p, b, d_voice, n, sA); });
+    RA_TRY(timed_launch(c, ST_HISTORY, sA, [&] { ra_launch_roll_history(p, b, d_voice, n, sA); }));
     HIP_TRY(hipEventRecord(sc.ev_track_done, sT));
     HIP_TRY(hipEventRecord(sc.ev_prop_done, sP));
     HIP_TRY(hipEventRecord(sc.ev_render_done, sR));
@@ -751,13 +732,23 @@ int process_block(ra_context *c, const float *d_voice, const float *d_carrier, i
     c->pending_join = true;
     if (!async && (r = join_streams(c))) return r;
   }
-  if (n_chunks == 1) timed_launch(c, ST_HISTORY, user, [&] { ra_launch_roll_history(p, b, d_voice, n, user); });
+  if (n_chunks == 1) RA_TRY(timed_launch(c, ST_HISTORY, user, [&] { ra_launch_roll_history(p, b, d_voice, n, user); }));
   HIP_TRY(hipGetLastError());
   if (c->profiling) ++c->kernel_calls;
   c->last_f_lo = f_lo; c->last_nfb = nfb; c->last_n = n; c->last_t0 = t0;
   c->t += n;
   c->frames_fired += nfb;
   return RA_OK;
+}
+
+// A block either completes, or fails before it touched any stream state (bad argument, allocation failure: the call can be retried), or
+// fails midway: then the context is poisoned until ra_reset (include/resynth_amd.h).
+int process_block(ra_context *c, const float *d_voice, const float *d_carrier, int64_t n, float *d_out, double *d_out_d, bool async = false) {
+  if (c->poisoned) return fail(RA_EINTERNAL, "an earlier block failed midway: the streams are in an undefined state until ra_reset");
+  bool started = false;
+  const int r = process_block_impl(c, d_voice, d_carrier, n, d_out, d_out_d, async, started);
+  if (r && started) c->poisoned = true;
+  return r;
 }
 
 int ensure_staging(ra_context *c, int64_t n) {
@@ -845,6 +836,15 @@ int ra_create(const ra_config *cfg, int32_t n_streams, int32_t device, ra_contex
   c->device = device;
   r = build_tables(c);
   c->p.n_streams = n_streams;
+  // per-workgroup LDS of the kernels whose footprint grows with the configuration: refuse here, with the numbers, rather than at a launch
+  if (!r) {
+    const size_t lim = RA_LDS_LIMIT_BYTES, la = ra_analysis_lds_bytes(c->p), lt = ra_track_lds_bytes(c->p);
+    if (la > lim)
+      r = fail(RA_EINVAL, "window_size / max_pitches_per_frame need " + std::to_string(la) + " bytes of LDS per analysis workgroup (limit " +
+                              std::to_string(lim) + "): lower max_pitches_per_frame" + ((cfg->pitch_harmonize_pre_autotune != 0.f || cfg->pitch_harmonize_post_autotune != 0.f) ? " (harmonize doubles the list capacity)" : ""));
+    else if (lt > lim)
+      r = fail(RA_EINVAL, "max_pitches_per_frame / n_channels need " + std::to_string(lt) + " bytes of LDS per tracking workgroup (limit " + std::to_string(lim) + ")");
+  }
   if (!r) r = alloc_state(c);
   if (!r) r = init_state(c);
   if (!r && std::getenv("RA_PHASE_CLOCKS")) {
@@ -883,8 +883,11 @@ void ra_destroy(ra_context *c) {
 int ra_reset(ra_context *c) {
   if (!c) return fail(RA_EINVAL, "null context");
   HIP_TRY(hipSetDevice(c->device));
+  if (c->poisoned) HIP_TRY(hipDeviceSynchronize()); // whatever the failed block still had in flight
   { int jr = join_streams(c); if (jr) return jr; }
-  return init_state(c);
+  const int r = init_state(c);
+  if (!r) c->poisoned = false;
+  return r;
 }
 
 int ra_set_hip_stream(ra_context *c, void *hip_stream) {

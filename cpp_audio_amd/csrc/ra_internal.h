@@ -10,6 +10,7 @@
 #define RA_MAX_FFT 16384
 #define RA_ANALYSIS_THREADS 256
 #define RA_N_FRAMES_PER_BUFFER 16 // audioelement.h:3
+#define RA_LDS_LIMIT_BYTES (160 * 1024) // LDS a workgroup may ask for on gfx950 (MI355X_MICROARCH.md)
 
 // ---- parameters every kernel reads (uniform; passed by value) -------------------------------------
 struct RaParams {
@@ -224,6 +225,7 @@ void ra_launch_synth_render(const RaParams &p, const RaBuffers &b, const RaSpan 
 void ra_launch_roll_history(const RaParams &p, const RaBuffers &b, const float *d_voice, int64_t n, hipStream_t st);
 void ra_launch_roll_feedback(const RaParams &p, const RaBuffers &b, int64_t n, hipStream_t st);
 size_t ra_analysis_lds_bytes(const RaParams &p);
+size_t ra_track_lds_bytes(const RaParams &p);
 
 // frame f covers input samples [2 + f H, 2 + f H + N) and fires in iteration N + 1 + f H
 __host__ __device__ inline int64_t ra_fire_sample(int N, int H, int64_t f) { return (int64_t)N + 1 + f * (int64_t)H; }

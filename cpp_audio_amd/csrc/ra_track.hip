@@ -236,8 +236,14 @@ __global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, i
 
 } // namespace
 
+size_t ra_track_lds_bytes(const RaParams &p) { return (size_t)p.maxr * (8 + 8 + 6 * 4) + (size_t)p.P * (6 * 8 + 10 * 4) + 64; }
+
 void ra_launch_track(const RaParams &p, const RaBuffers &b, int64_t f_lo, int64_t fb0, int64_t n_frames_blk, hipStream_t st) {
   if (n_frames_blk <= 0) return;
-  size_t lds = (size_t)p.maxr * (8 + 8 + 6 * 4) + (size_t)p.P * (6 * 8 + 10 * 4) + 64;
+  const size_t lds = ra_track_lds_bytes(p);
+  static unsigned long long attr_done = 0; // above the 64 KB default from max_pitches_per_frame ~ 1500 on (ra_create checks the 160 KB limit)
+  ra_once_per_device(attr_done, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_track_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RA_LDS_LIMIT_BYTES);
+  });
   hipLaunchKernelGGL(ra_track_kernel, dim3((unsigned)p.n_streams), dim3(64), lds, st, p, b, f_lo, fb0, n_frames_blk);
 }

@@ -26,7 +26,10 @@ extern "C" {
 #define RA_ENODEVICE -2   /* no usable HIP device: there is NO CPU fallback */
 #define RA_EHIP -3        /* a HIP runtime call failed */
 #define RA_EOVERFLOW -4   /* a per-frame list exceeded its capacity (see ra_config.max_pitches_per_frame) */
-#define RA_EINTERNAL -5   /* device-side consistency check failed (decision/synth channel bookkeeping disagree) */
+#define RA_EINTERNAL -5   /* device-side consistency check failed (decision/synth channel bookkeeping disagree), or the context is
+                             poisoned: a block failed after it had started to advance the streams (a HIP error midway); every entry
+                             point then returns RA_EINTERNAL until ra_reset.  A block that fails before that point (bad argument,
+                             allocation failure) leaves the streams untouched and may be retried. */
 
 enum { RA_AUTOTUNE_SCALE = 0, RA_AUTOTUNE_CHORD = 1, RA_AUTOTUNE_INTERVALS = 2 };     /* rt.resynth.lib.autotune.cpp:3-8   */
 enum { RA_SCALE_MAJOR = 0, RA_SCALE_MINOR_NATURAL = 1, RA_SCALE_MINOR_HARMONIC = 2 }; /* rt.resynth.lib.autotune.cpp:9-14  */
@@ -82,7 +85,9 @@ typedef struct ra_config {
 
   /* capacity of the per-frame pitch list handed from analysis to tracking (the reference's vectors grow
    * on demand, lib.cpp:1102-1112); exceeding it sets RA_EOVERFLOW instead of truncating silently. */
-  int32_t max_pitches_per_frame; /* default 512 */
+  int32_t max_pitches_per_frame; /* default 512; 1..4096, further limited by the 160 KB of LDS a workgroup may hold: the analysis keeps
+                                    two lists of this capacity (twice that with a harmonize step) beside its FFT buffer, the tracking
+                                    40 bytes per entry — ra_create returns RA_EINVAL with the byte counts when they do not fit */
 
   /* 0 (default): synthesis runs hop-parallel — per-hop channel states come from closed-form jumps, differing from
    * sample-by-sample stepping at rounding level (~1e-13).  1: one sample-serial launch per stream that follows the
