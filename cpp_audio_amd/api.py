@@ -44,17 +44,31 @@ class RaConfig(C.Structure):
         ("phase_policy", C.c_int32), ("seed", C.c_uint64),
         ("max_pitches_per_frame", C.c_int32), ("reference_order", C.c_int32),
         ("analysis_output_feedback_gain", C.c_float), ("output_delay_seconds", C.c_float),
+        ("vocoder_kind", C.c_int32), ("vocoder_env_follower_cutoff_ratio", C.c_float), ("carrier_n_channels", C.c_int32),
+        ("vocoder_carrier_noise_volume", C.c_float), ("vocoder_carrier_saw_volume", C.c_float),
+        ("vocoder_carrier_triangle_volume", C.c_float), ("vocoder_carrier_square_volume", C.c_float),
+        ("vocoder_carrier_sine_volume", C.c_float), ("vocoder_carrier_pulse_volume", C.c_float),
+        ("vocoder_carrier_pulse_width", C.c_float),
     ]
 
 
 class RaStats(C.Structure):
     _fields_ = [("frames_analysed", C.c_int64), ("samples_rendered", C.c_int64), ("dropped_note_on", C.c_int64),
-                ("error_flags", C.c_int32), ("reserved", C.c_int32)]
+                ("error_flags", C.c_int32), ("reserved", C.c_int32), ("carrier_dropped_note_on", C.c_int64)]
 
 
 class RaNote(C.Structure):
     _fields_ = [("start_frame", C.c_int32), ("end_frame", C.c_int32), ("frequency", C.c_double), ("amplitude_db", C.c_double)]
 
+
+class RaCarrierEvent(C.Structure):
+    """Mirror of include/resynth_amd.h:ra_carrier_event."""
+    _fields_ = [("sample", C.c_int64), ("stream", C.c_int32), ("type", C.c_int32), ("key", C.c_int32), ("delay", C.c_int32),
+                ("frequency", C.c_float), ("velocity", C.c_float)]
+
+
+CARRIER_EVENT_DTYPE = np.dtype([("sample", "<i8"), ("stream", "<i4"), ("type", "<i4"), ("key", "<i4"), ("delay", "<i4"),
+                                ("frequency", "<f4"), ("velocity", "<f4")])
 
 EVENT_DTYPE = np.dtype([("sample", "<i8"), ("type", "<i4"), ("channel", "<i4"), ("noteid", "<i8"),
                         ("frequency", "<f4"), ("velocity", "<f4")])
@@ -66,6 +80,7 @@ EXPORTED_SYMBOLS = [
     "ra_synchronize",
     "ra_feed", "ra_compute", "ra_get_stats", "ra_get_events", "ra_get_frame_pitches", "ra_resynth_notes", "ra_sqmag",
     "ra_set_profiling", "ra_get_kernel_ms", "ra_get_kernel_launches", "ra_render_note",
+    "ra_carrier_events", "ra_get_carrier",
 ]
 
 _lib = None
@@ -102,6 +117,8 @@ def lib():
         L.ra_set_profiling.argtypes = [C.c_void_p, C.c_int32]
         L.ra_get_kernel_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
         L.ra_get_kernel_launches.argtypes = [C.c_void_p, C.c_void_p]
+        L.ra_carrier_events.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.ra_get_carrier.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
         L.ra_even_window_size_frames.argtypes = [C.c_float, C.c_int]
         L.ra_window_center_stride_frames.argtypes = [C.c_float, C.c_int]
         _lib = L
@@ -160,10 +177,13 @@ class Context:
     def set_hip_stream(self, stream_handle):
         _check(lib().ra_set_hip_stream(self._h, C.c_void_p(stream_handle)))
 
-    def process_host(self, voice, carrier=None):
+    def process_host(self, voice, carrier=None, n_frames=None):
         """voice/carrier: [n_streams, n] float32 (or None). Returns out [n_streams, n, 2] float32."""
         a = voice if voice is not None else carrier
-        S, n = a.shape
+        if a is None:
+            S, n = self.n_streams, int(n_frames)
+        else:
+            S, n = a.shape
         assert S == self.n_streams
         v = np.ascontiguousarray(voice, np.float32) if voice is not None else None
         c = np.ascontiguousarray(carrier, np.float32) if carrier is not None else None
@@ -195,6 +215,25 @@ class Context:
         """Accumulates into buf ([n_frames, 2] float64), like the reference's ComputeFunc."""
         assert buf.dtype == np.float64 and buf.flags.c_contiguous
         return _check(lib().ra_compute(self._h, stream, _p(buf), n_frames))
+
+    def carrier_events(self, rows):
+        """Queue note events for the carrier synth.  rows: iterable of (sample, stream, type, key[, delay[, frequency[, velocity]]]),
+        or a CARRIER_EVENT_DTYPE array; per stream in non-decreasing sample order."""
+        if isinstance(rows, np.ndarray) and rows.dtype == CARRIER_EVENT_DTYPE:
+            ev = np.ascontiguousarray(rows)
+        else:
+            ev = np.zeros(len(rows), CARRIER_EVENT_DTYPE)
+            for i, r in enumerate(rows):
+                r = tuple(r)
+                r = r + (0, 0.0, 1.0)[len(r) - 4:] if len(r) < 7 else r
+                ev[i] = r
+        _check(lib().ra_carrier_events(self._h, _p(ev), len(ev)))
+
+    def carrier(self, n_frames, stream=0):
+        """The carrier the vocoder was given during the last process call (only when it came from the carrier synth)."""
+        out = np.zeros(n_frames, np.float64)
+        _check(lib().ra_get_carrier(self._h, stream, _p(out), n_frames))
+        return out
 
     def set_profiling(self, enable=True):
         _check(lib().ra_set_profiling(self._h, 1 if enable else 0))

@@ -7,7 +7,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 static thread_local std::string g_last_error;
@@ -61,6 +63,15 @@ struct ra_context {
     bool used = false;
   } scr[2];
   int parity = 0;
+  // vocoder carrier synth: note events not yet consumed by a block, per stream, and the key -> note id book of the reference's
+  // NoteIdsGenerator (include/events.h:228-281; one per RtResynth, lib.cpp:911)
+  struct CarNoteIds { int64_t next = 0; std::unordered_map<uint64_t, std::deque<int64_t>> ids; };
+  std::vector<std::deque<RaCarEv>> car_pending;
+  std::vector<CarNoteIds> car_noteids;
+  std::vector<int64_t> car_last_sample;
+  std::vector<RaCarEv> car_upload[2];   // host images of the blocks' event lists (kept until the set is reused)
+  std::vector<int32_t> car_upload_begin[2];
+  bool last_car_gen = false;            // the last block's carrier came from the synth (ra_get_carrier)
   // a block failed after it had started to change stream state (launches issued, histories rolled): the streams are then neither at the
   // block's start nor at its end, and every entry point returns RA_EINTERNAL until ra_reset
   bool poisoned = false;
@@ -179,6 +190,11 @@ int validate(const ra_config &c, int32_t n_streams) {
   if (c.autotune_factor < 0) return fail(RA_EINVAL, "autotune_factor must be >= 0");
   if (c.analysis_output_feedback_gain != 0.f && c.reference_order != 0) return fail(RA_EINVAL, "analysis_output_feedback_gain needs reference_order 0");
   if (c.analysis_output_feedback_gain != 0.f && !(c.output_delay_seconds >= 0.f && c.output_delay_seconds <= 60.f)) return fail(RA_EINVAL, "output_delay_seconds must be in 0..60");
+  if (c.vocoder_kind != RA_VOCODER_FFT && c.vocoder_kind != RA_VOCODER_BANDPASS) return fail(RA_EINVAL, "unknown vocoder_kind");
+  if (c.vocoder_kind == RA_VOCODER_BANDPASS && !(c.vocoder_env_follower_cutoff_ratio > 0.f)) return fail(RA_EINVAL, "vocoder_env_follower_cutoff_ratio must be > 0");
+  if (c.carrier_n_channels < 0 || c.carrier_n_channels > RA_MAX_CHANNELS) return fail(RA_EINVAL, "carrier_n_channels must be in 0..256");
+  if (c.carrier_n_channels > 0 && c.vocoder_carrier_noise_volume != 0.f)
+    return fail(RA_EINVAL, "vocoder_carrier_noise_volume must be 0: the noise voice plays a sound buffer of cpp.algorithms, which is absent (DESIGN.md §8)");
   return RA_OK;
 }
 
@@ -250,8 +266,10 @@ int build_vocoder_tables(ra_context *c) {
   p.voc_Lc = fft_length_for(2 * S);
   p.voc_Mc = p.voc_Lc / 2;
   p.voc_bands = cfg.vocoder_count_bands;
-  if (p.voc_Lm > RA_MAX_FFT) return fail(RA_EINVAL, "vocoder modulator window is too large (FFT length > 16384)");
-  if (p.voc_Lc > 4096) return fail(RA_EINVAL, "vocoder stride is too large (carrier FFT length > 4096)");
+  if (cfg.vocoder_kind == RA_VOCODER_FFT) {
+    if (p.voc_Lm > RA_MAX_FFT) return fail(RA_EINVAL, "vocoder modulator window is too large (FFT length > 16384)");
+    if (p.voc_Lc > 4096) return fail(RA_EINVAL, "vocoder stride is too large (carrier FFT length > 4096)");
+  }
   if (!(cfg.vocoder_min_freq > 0.f) || !(cfg.vocoder_max_freq > cfg.vocoder_min_freq)) return fail(RA_EINVAL, "vocoder band limits must satisfy 0 < min < max");
   // SetupParams::fill_freqs, vocoder.cpp:15-27 (float logs, double exp)
   std::vector<double> freqs;
@@ -262,6 +280,18 @@ int build_vocoder_tables(ra_context *c) {
       double const ratio = static_cast<double>(i) / p.voc_bands;
       freqs.push_back(std::exp(log_min + ratio * (log_max - log_min)));
     }
+  }
+  if (cfg.vocoder_kind == RA_VOCODER_BANDPASS) {
+    // BandPass::setup / EnvelopeFollower::setup (vocoder.cpp:48-52,67-69) through Modulator::setup_bands / setup (:315-354) and
+    // Carrier::setup (:669-692): initWithFreq(sample_rate, f) = initWithAngleIncrement(2 f / sample_rate), one-pole k = pi w / (1 + pi w)
+    std::vector<double> k(3 * 64, 0.0);
+    auto coeff = [&](double freq) { const double w = 2 * freq / cfg.sample_rate, a = M_PI * w; return a / (1.0 + a); };
+    for (int i = 0; i < p.voc_bands; ++i) {
+      k[i] = coeff(freqs[i]);
+      k[64 + i] = coeff(freqs[i + 1]);
+      k[128 + i] = coeff(freqs[i] * cfg.vocoder_env_follower_cutoff_ratio);
+    }
+    return upload(c, &b.bank_k, k);
   }
   if ((r = upload(c, &b.voc_half_window, make_half_window(RA_WINDOW_GAUSSIAN4, Wm / 2)))) return r;
   if ((r = upload_fft_tables(c, p.voc_Lm, &b.vm_tw_half, &b.vm_tw_full, &b.vm_bitrev))) return r;
@@ -331,6 +361,12 @@ int build_tables(ra_context *c) {
   p.fb_gain = cfg.analysis_output_feedback_gain;
   p.fb_sz = std::max(0, static_cast<int>(0.5f + cfg.output_delay_seconds * cfg.sample_rate)); // lib.cpp:1638-1639
   p.voc_enabled = (cfg.voice_volume != 0.f || cfg.carrier_volume != 0.f || cfg.vocoder_volume != 0.f) ? 1 : 0;
+  p.voc_kind = cfg.vocoder_kind;
+  p.car_P = p.voc_enabled ? cfg.carrier_n_channels : 0; // nothing hears the carrier synth while every vocoder volume is 0
+  p.car_Ppad = ((p.car_P + 63) / 64) * 64;
+  p.car_vol[0] = cfg.vocoder_carrier_noise_volume; p.car_vol[1] = cfg.vocoder_carrier_saw_volume; p.car_vol[2] = cfg.vocoder_carrier_triangle_volume;
+  p.car_vol[3] = cfg.vocoder_carrier_square_volume; p.car_vol[4] = cfg.vocoder_carrier_sine_volume; p.car_vol[5] = cfg.vocoder_carrier_pulse_volume;
+  p.car_pulse_width = cfg.vocoder_carrier_pulse_width;
 
   RaBuffers &b = c->b;
   std::memset(&b, 0, sizeof(b));
@@ -373,11 +409,20 @@ int alloc_state(ra_context *c) {
     b.fb_hist_len = (int64_t)p.fb_sz + p.N + 2;
     if ((r = dev_alloc(c, &b.fb_hist, S * b.fb_hist_len))) return r;
   }
-  if (p.voc_enabled) {
+  if (p.voc_enabled && p.voc_kind == RA_VOCODER_FFT) {
     if ((r = dev_alloc(c, &b.voc_mod_hist, S * p.voc_Wm))) return r;
     if ((r = dev_alloc(c, &b.voc_car_hist, S * 2 * p.voc_S))) return r;
     if ((r = dev_alloc(c, &b.voc_amp_prev, S * p.voc_bands))) return r;
     if ((r = dev_alloc(c, &b.voc_sig_prev, S * 4 * p.voc_S))) return r;
+  }
+  if (p.voc_enabled && p.voc_kind == RA_VOCODER_BANDPASS && (r = dev_alloc(c, &b.bank_state, S * 5 * 64))) return r;
+  if (p.car_P > 0) {
+    if ((r = dev_alloc(c, &b.car_sd, S * SD_COUNT * p.car_Ppad))) return r;
+    if ((r = dev_alloc(c, &b.car_si, S * SI_COUNT * p.car_Ppad))) return r;
+    if ((r = dev_alloc(c, &b.car_ext, S * CX_COUNT * p.car_Ppad))) return r;
+    if ((r = dev_alloc(c, &b.car_noteid, S * p.car_Ppad))) return r;
+    if ((r = dev_alloc(c, &b.car_dropped, S))) return r;
+    if ((r = dev_alloc(c, &b.car_ev_begin, S + 1))) return r;
   }
   return RA_OK;
 }
@@ -395,7 +440,30 @@ int init_state(ra_context *c) {
   HIP_TRY(hipMemsetAsync(b.chan_held, 0, S * p.P * sizeof(int32_t), c->stream));
   HIP_TRY(hipMemsetAsync(b.chan_minch, 0, S * p.P * sizeof(int32_t), c->stream));
   HIP_TRY(hipMemsetAsync(b.error_flags, 0, sizeof(int32_t), c->stream));
-  if (p.voc_enabled) {
+  if (b.bank_state) HIP_TRY(hipMemsetAsync(b.bank_state, 0, S * 5 * 64 * sizeof(double), c->stream)); // Filter<> starts from rest
+  if (p.car_P > 0) { // fresh elements: envelopes Done2, Phased angle 0 / increments 0 / aliasing gain 1, sine phasor 1 (audioelement.h:1473-1476,2438-2441)
+    std::vector<double> sd(S * SD_COUNT * p.car_Ppad, 0.0), ext(S * CX_COUNT * p.car_Ppad, 0.0);
+    std::vector<int32_t> si(S * SI_COUNT * p.car_Ppad, 0);
+    std::vector<int64_t> ids(S * p.car_Ppad, -1);
+    for (size_t s = 0; s < S; ++s)
+      for (int l = 0; l < p.car_Ppad; ++l) {
+        double *d = sd.data() + s * SD_COUNT * p.car_Ppad;
+        int32_t *i = si.data() + s * SI_COUNT * p.car_Ppad;
+        d[SD_OSC_CRE * p.car_Ppad + l] = 1.0; d[SD_OSC_MRE * p.car_Ppad + l] = 1.0; d[SD_OSC_ALIAS * p.car_Ppad + l] = 1.0;
+        i[SI_ENV_STATE * p.car_Ppad + l] = ENV_DONE2; i[SI_ENV_RELDELAY * p.car_Ppad + l] = -1; i[SI_ENV_AHDSTATE * p.car_Ppad + l] = -1;
+        ext[s * CX_COUNT * p.car_Ppad + CX_PH_ALIAS * p.car_Ppad + l] = 1.0;
+      }
+    HIP_TRY(hipMemcpyAsync(b.car_sd, sd.data(), sd.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(b.car_si, si.data(), si.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(b.car_ext, ext.data(), ext.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(b.car_noteid, ids.data(), ids.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(b.car_dropped, 0, S * sizeof(int32_t), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream)); // the host images go out of scope
+    c->car_pending.assign(S, {});
+    c->car_noteids.assign(S, {});
+    c->car_last_sample.assign(S, 0);
+  }
+  if (p.voc_enabled && p.voc_kind == RA_VOCODER_FFT) {
     HIP_TRY(hipMemsetAsync(b.voc_mod_hist, 0, S * p.voc_Wm * sizeof(float), c->stream));
     HIP_TRY(hipMemsetAsync(b.voc_car_hist, 0, S * 2 * p.voc_S * sizeof(float), c->stream));
     HIP_TRY(hipMemsetAsync(b.voc_amp_prev, 0, S * p.voc_bands * sizeof(double), c->stream));
@@ -475,7 +543,15 @@ int ensure_scratch(ra_context *c, int64_t nfb, int64_t n, int n_chunks) {
       b.mix_cap = n;
       if ((r = dev_alloc(c, &b.voc_mix, S * n, false))) return r;
     }
+    if (p.car_P > 0 && n > b.car_gen_cap) {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      dev_free(c, b.car_gen_d); dev_free(c, b.car_gen_f);
+      b.car_gen_cap = n;
+      if ((r = dev_alloc(c, &b.car_gen_d, S * n, false))) return r;
+      if ((r = dev_alloc(c, &b.car_gen_f, S * n, false))) return r;
+    }
     RaFrameRange mod = ra_frames_firing(p.voc_Wm, p.voc_S, c->t, n), car = ra_frames_firing(2 * p.voc_S, p.voc_S, c->t, n);
+    if (p.voc_kind != RA_VOCODER_FFT) { mod.count = 0; car.count = 0; }
     if (mod.count > b.voc_mod_cap) {
       HIP_TRY(hipStreamSynchronize(c->stream));
       dev_free(c, b.voc_amp);
@@ -554,6 +630,35 @@ int join_streams(ra_context *c) {
   return RA_OK;
 }
 
+// The carrier synth's note events of the block [t0, t0 + n): taken from the per-stream queues into one list, stream after stream.
+// Everything that can fail happens before a queue is touched.
+int stage_carrier_events(ra_context *c, int64_t t0, int64_t n) {
+  const RaParams &p = c->p;
+  RaBuffers &b = c->b;
+  const int S = p.n_streams;
+  size_t total = 0;
+  for (int s = 0; s < S; ++s)
+    for (const RaCarEv &e : c->car_pending[s]) { if (e.sample >= t0 + n) break; ++total; }
+  if ((int64_t)total > b.car_ev_cap) {
+    HIP_TRY(hipDeviceSynchronize()); // an earlier block may still read the old list
+    dev_free(c, b.car_ev);
+    b.car_ev_cap = std::max<int64_t>(256, 2 * (int64_t)total);
+    int r = dev_alloc(c, &b.car_ev, (size_t)b.car_ev_cap, false);
+    if (r) { b.car_ev_cap = 0; return r; }
+  }
+  std::vector<RaCarEv> &flat = c->car_upload[c->parity];
+  std::vector<int32_t> &begin = c->car_upload_begin[c->parity];
+  flat.clear();
+  begin.assign(S + 1, 0);
+  for (int s = 0; s < S; ++s) {
+    begin[s] = (int32_t)flat.size();
+    auto &q = c->car_pending[s];
+    while (!q.empty() && q.front().sample < t0 + n) { flat.push_back(q.front()); q.pop_front(); }
+  }
+  begin[S] = (int32_t)flat.size();
+  return RA_OK;
+}
+
 // The block is cut into time chunks; analysis, tracking, propagation and render of successive chunks run on four HIP
 // streams chained by events.  Tracking and propagation are dependency chains over frames that occupy a few hundred
 // wavefronts; cutting the block lets the throughput kernels (analysis of later chunks, render of earlier ones) fill the
@@ -578,19 +683,35 @@ int process_block_impl(ra_context *c, const float *d_voice, const float *d_carri
   if (caller_stream_only || p.voc_enabled) { if ((r = join_streams(c))) return r; async = false; }
   c->parity ^= 1; // (ensure_scratch binds the set `parity` names; a failure there flips it back: nothing has been launched yet)
   if ((r = ensure_scratch(c, nfb, n, n_chunks))) { c->parity ^= 1; return r; }
+  // the vocoder's carrier: the caller's buffer, or — when there is none and the context has a carrier synth — that synth's output
+  const bool car_gen = p.car_P > 0 && !d_carrier;
+  if (car_gen && (r = stage_carrier_events(c, t0, n))) { c->parity ^= 1; return r; }
   started = true;
+  c->last_car_gen = car_gen;
+  const float *car_f = car_gen ? c->b.car_gen_f : d_carrier;
+  const double *car_d = car_gen ? c->b.car_gen_d : nullptr;
   ra_context::Scratch &sc = c->scr[c->parity];
   c->b.dbg_sqmag = c->dbg_sqmag;
   c->b.dbg_clk = c->dbg_clk;
   const RaBuffers &b = c->b;
   hipStream_t user = c->stream;
+  auto launch_vocoder = [&](hipStream_t st) { // K6 (when the synth supplies the carrier) then K4 / K7
+    if (car_gen) {
+      const std::vector<RaCarEv> &flat = c->car_upload[c->parity];
+      const std::vector<int32_t> &begin = c->car_upload_begin[c->parity];
+      if (!flat.empty()) (void)hipMemcpyAsync(b.car_ev, flat.data(), flat.size() * sizeof(RaCarEv), hipMemcpyHostToDevice, st);
+      (void)hipMemcpyAsync(b.car_ev_begin, begin.data(), begin.size() * sizeof(int32_t), hipMemcpyHostToDevice, st);
+      ra_launch_carrier_synth(p, b, t0, n, st);
+    }
+    ra_launch_vocoder(p, b, d_voice, car_f, car_d, t0, n, st);
+  };
 
   if (p.fb_gain != 0.f) {
     // Feedback of the output into the analysis input: the analysis of a piece needs the mono output up to fb_sz + 1 frames before its
     // last frame fires, i.e. only output of earlier pieces if a piece holds at most fb_sz / H + 1 analysis frames.  The pieces run one
     // after the other on the caller's stream (no overlap: that is the price of the dependency).
     const int64_t per = (int64_t)p.fb_sz / p.H + 1;
-    if (p.voc_enabled) RA_TRY(timed_launch(c, ST_VOCODER, user, [&] { ra_launch_vocoder(p, b, d_voice, d_carrier, t0, n, user); }));
+    if (p.voc_enabled) RA_TRY(timed_launch(c, ST_VOCODER, user, [&] { launch_vocoder(user); }));
     // piece 0 holds no frame: it only renders the samples before the block's first frame fires (that frame's window looks back at them)
     int64_t fb0 = 0, fb1 = 0;
     int piece = 0;
@@ -615,7 +736,7 @@ int process_block_impl(ra_context *c, const float *d_voice, const float *d_carri
     RaSpan sp{t0, n, t0, t0 + n, f_lo, 0, nfb, 0};
     RA_TRY(timed_launch(c, ST_ANALYSIS, user, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, 0, nfb, nfb, user); }));
     RA_TRY(timed_launch(c, ST_TRACK, user, [&] { ra_launch_track(p, b, f_lo, 0, nfb, user); }));
-    if (p.voc_enabled) RA_TRY(timed_launch(c, ST_VOCODER, user, [&] { ra_launch_vocoder(p, b, d_voice, d_carrier, t0, n, user); }));
+    if (p.voc_enabled) RA_TRY(timed_launch(c, ST_VOCODER, user, [&] { launch_vocoder(user); }));
     if (c->cfg.reference_order == 1) RA_TRY(timed_launch(c, ST_RENDER, user, [&] { ra_launch_synth_serial(p, b, sp, d_out, d_out_d, user); }));
     else {
       RA_TRY(timed_launch(c, ST_PROPAGATE, user, [&] { ra_launch_synth_propagate(p, b, sp, user); }));
@@ -663,7 +784,7 @@ int process_block_impl(ra_context *c, const float *d_voice, const float *d_carri
       HIP_TRY(hipStreamWaitEvent(sP, sc.ev_render_done, 0)); // propagation rewrites the hop states the render read
     }
     if (p.voc_enabled) { // independent of the analysis chain: runs beside it, only the render waits for the mix
-      RA_TRY(timed_launch(c, ST_VOCODER, sR, [&] { ra_launch_vocoder(p, b, d_voice, d_carrier, t0, n, sR); }));
+      RA_TRY(timed_launch(c, ST_VOCODER, sR, [&] { launch_vocoder(sR); }));
     }
     // Chunk boundaries (in frames).  The first chunk is short — nothing overlaps its analysis -> tracking -> propagation, so the render
     // stream starts that much sooner — and so are the last two: when the analysis of the block is over, only the chain and the render of
@@ -812,6 +933,11 @@ int ra_default_config(ra_config *c) { // source/rt.resynth.lib.cpp:943-999
   c->max_pitches_per_frame = 512;
   c->analysis_output_feedback_gain = 0.f;
   c->output_delay_seconds = 1.f;
+  c->vocoder_kind = RA_VOCODER_FFT;
+  c->vocoder_env_follower_cutoff_ratio = 1.f / 20.f;
+  c->carrier_n_channels = 0;
+  c->vocoder_carrier_square_volume = 1.f;
+  c->vocoder_carrier_pulse_width = 0.01f;
   return RA_OK;
 }
 
@@ -979,6 +1105,53 @@ int ra_process_host(ra_context *c, const float *h_voice, const float *h_carrier,
   return ra_synchronize(c);
 }
 
+int ra_carrier_events(ra_context *c, const ra_carrier_event *ev, int64_t n) {
+  if (!c) return fail(RA_EINVAL, "null context");
+  if (n < 0 || (n > 0 && !ev)) return fail(RA_EINVAL, "bad events");
+  if (n > 0 && c->cfg.carrier_n_channels <= 0) return fail(RA_EINVAL, "the context has no carrier synth (carrier_n_channels = 0)");
+  if (c->p.car_P <= 0) return RA_OK; // every vocoder volume is 0: the carrier synth is inaudible and not run
+  for (int64_t i = 0; i < n; ++i) {
+    const ra_carrier_event &e = ev[i];
+    const std::string at = "carrier event " + std::to_string(i) + ": ";
+    if (e.stream < 0 || e.stream >= c->p.n_streams) return fail(RA_EINVAL, at + "stream out of range");
+    if (e.type != 0 && e.type != 1) return fail(RA_EINVAL, at + "type must be 0 (NoteOn) or 1 (NoteOff)");
+    if (e.delay < 0) return fail(RA_EINVAL, at + "negative delay");
+    if (e.sample < c->t) return fail(RA_EINVAL, at + "its frame has already been processed");
+    if (e.sample < c->car_last_sample[e.stream]) return fail(RA_EINVAL, at + "samples of a stream must not decrease");
+    ra_context::CarNoteIds &g = c->car_noteids[e.stream];
+    const uint64_t key = static_cast<uint64_t>(static_cast<uint32_t>(e.key));
+    RaCarEv d;
+    d.sample = e.sample; d.type = e.type; d.delay = e.delay; d.vel = e.velocity; d.freq = 0.f;
+    if (e.type == 0) { // mkNoteOn(NoteOnId(key), midi_pitch_to_freq(key), velocity), lib.cpp:1527-1531
+      if (!(e.velocity > 0.f)) return fail(RA_EINVAL, at + "a note-on needs a velocity > 0 (gen.crtp.h:391)");
+      d.noteid = ++g.next;
+      g.ids[key].push_back(d.noteid);
+      d.freq = e.frequency > 0.f ? e.frequency
+                                 : static_cast<float>(440.f * std::pow(std::pow(2., 1.0 / kNumHalftones), static_cast<double>(e.key) - 69.0)); // midi.h:258-264
+    } else { // NoteOffId: the earliest pending note-on of the key, events.h:255-268
+      auto it = g.ids.find(key);
+      if (it == g.ids.end()) return fail(RA_EINVAL, at + "note-off for a key with no pending note-on");
+      d.noteid = it->second.front();
+      if (it->second.size() == 1) g.ids.erase(it); else it->second.pop_front();
+    }
+    c->car_pending[e.stream].push_back(d);
+    c->car_last_sample[e.stream] = e.sample;
+  }
+  return RA_OK;
+}
+
+int ra_get_carrier(ra_context *c, int32_t stream, double *h_carrier, int64_t cap) {
+  if (!c || !h_carrier) return fail(RA_EINVAL, "null argument");
+  if (stream < 0 || stream >= c->p.n_streams) return fail(RA_EINVAL, "stream out of range");
+  if (!c->last_car_gen || !c->b.car_gen_d) return fail(RA_EINVAL, "the last block's carrier did not come from the carrier synth");
+  if (cap < c->last_n) return fail(RA_EINVAL, "buffer too small");
+  HIP_TRY(hipSetDevice(c->device));
+  { int jr = join_streams(c); if (jr) return jr; }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemcpy(h_carrier, c->b.car_gen_d + static_cast<size_t>(stream) * c->last_n, static_cast<size_t>(c->last_n) * sizeof(double), hipMemcpyDeviceToHost));
+  return RA_OK;
+}
+
 int ra_feed(ra_context *c, int32_t stream, const float *h_voice, const float *h_carrier, int32_t n) {
   if (!c) return fail(RA_EINVAL, "null context");
   if (c->p.n_streams != 1 || stream != 0) return fail(RA_EINVAL, "ra_feed/ra_compute drive a single-stream context (one RtResynth = one context)");
@@ -1025,6 +1198,11 @@ int ra_get_stats(ra_context *c, ra_stats *st) {
   st->frames_analysed = c->frames_fired * c->p.n_streams;
   st->samples_rendered = c->t;
   HIP_TRY(hipMemcpy(&st->error_flags, c->b.error_flags, sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (c->p.car_P > 0) {
+    std::vector<int32_t> dr(c->p.n_streams);
+    HIP_TRY(hipMemcpy(dr.data(), c->b.car_dropped, dr.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int32_t d : dr) st->carrier_dropped_note_on += d;
+  }
   return RA_OK;
 }
 

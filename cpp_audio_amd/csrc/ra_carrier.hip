@@ -1,0 +1,260 @@
+// K6 / K7 — SURVEY.md §8 f2: the vocoder carrier synth and the band-pass bank vocoder.
+//
+// K6 ra_carrier_synth_kernel: SynthVocoderCarier (reference source/rt.resynth.lib.cpp:212-221) = ImplCRTP (include/gen.crtp.h:350-622)
+//    over VocoderCarrierElement<double> (lib.cpp:21-52; initializer :137-196).  One workgroup per stream, lane = channel, samples in
+//    order: the phase-controlled oscillators' discontinuous waveforms (saw / square / pulse, include/sound.functions.h:86-138) make
+//    every bit of the accumulated angle audible — `angle += inc; if (angle > 2) angle -= 2` (Phased::step, audioelement.h:1452-1470)
+//    has no closed form that reproduces its roundings, and a flipped edge sample is an error of twice the voice's volume.
+//    What is constant in the reference's element and therefore not stepped here (the CPU restatement steps all of it):
+//      * the six inner VolumeAdjusted filters: their targets are set once per note by the initializer and the first step copies the
+//        target into the filter (audioelement.h:1201-1215), so volume == target for the whole note;
+//      * the four Phased oscillators share one angle: same start angle (UnityGainMix::setStartAngle / synchronizeAngles,
+//        :1940-1964), same increments, same steps;
+//      * the pulse's "used" width / levels: reset by forgetPastSignals and re-latched by the initializer at every note-on.
+//    The noise voice (soundBufferWrapperAlgo<NOISE>, an L0 buffer) has volume 0 (ra_create enforces it): 0 * sample = 0; its constant
+//    angleIncrements() = 0.5f (include/sound.h:256-258) still enters UnityGainMix::angleIncrements() (:1948-1958).
+//
+// K7 ra_voc_bank_kernel: Modulator<1, double> + Carrier<1, double> (source/rt.resynth.lib.vocoder.cpp:310-394, 667-732) inside the
+//    Vocoder compute lambda (:763-812).  One wavefront per stream, lane = band, samples in order; per sample and band five one-pole
+//    recurrences (modulator high-pass -> low-pass -> |.| -> envelope follower; carrier high-pass -> low-pass).  The band sum
+//    `res += ponderation[i] * filtered` runs in band order, like the reference's loop, on a transposed 64-sample tile.
+//    Same operations in the same order as the CPU restatement (no contraction): the vocoded signal is equal bit for bit.
+#include "ra_chan.cuh"
+#include <algorithm>
+
+extern __shared__ __align__(16) unsigned char ra_smem_car[];
+
+namespace {
+
+// ---- include/sound.functions.h:86-138 ------------------------------------------------------------------------------------
+__device__ inline double wave_square(double ang) { return (0.5 < ang && ang < 1.5) ? -1.0 : 1.0; }
+__device__ inline double wave_pulse(double ang, double w, double high, double low) { return ang < w ? high : low; }
+__device__ inline double wave_triangle(double ang) { return ang < 0.5 ? 2.0 * ang : ang < 1.5 ? 2.0 + -2.0 * ang : -4.0 + 2.0 * ang; }
+__device__ inline double wave_saw(double ang) { return ang <= 1.0 ? ang : -2.0 + ang; }
+__device__ inline double phase_to_normal_form(double phase) { // audioelement.h:418-428
+  double nf = fmod(phase, 2.0);
+  if (nf < 0) nf += 2.0;
+  return nf;
+}
+
+struct CarX { double ph_angle, ph_inc, ph_alias; }; // the Phased oscillators (one shared angle, see above)
+
+// FreqCtrl_::angleIncrements (audioelement.h:3117-3124) over UnityGainMix::angleIncrements (:1948-1958): noise 0.5f, the four Phased
+// increments, the sine's
+__device__ inline double car_angle_increments(const Chan &c, const CarX &x) {
+  double ai = (double)0.5f;
+  ai = fmin(ai, fabs(x.ph_inc));
+  ai = fmin(ai, fabs(c.inc));
+  if (ai != 0.) return ai;
+  return c.from;
+}
+
+constexpr int CT = 16; // samples per tile
+
+__global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_synth_kernel(RaParams p, RaBuffers b, int64_t t0, int64_t n) {
+  const int s = blockIdx.x, l = threadIdx.x, Ppad = p.car_Ppad, P = p.car_P;
+  double *tile = reinterpret_cast<double *>(ra_smem_car);            // [Ppad][CT + 1]
+  double *xch = tile + (size_t)Ppad * (CT + 1);                      // [4] broadcast slots
+  int *xi = reinterpret_cast<int *>(xch + 4);                        // [4]
+  Chan c;
+  CarX x;
+  double *sd = b.car_sd + (size_t)s * SD_COUNT * Ppad;
+  int *si = b.car_si + (size_t)s * SI_COUNT * Ppad;
+  double *ext = b.car_ext + (size_t)s * CX_COUNT * Ppad;
+  load_chan(c, sd, si, Ppad, l);
+  x.ph_angle = ext[CX_PH_ANGLE * Ppad + l]; x.ph_inc = ext[CX_PH_INC * Ppad + l]; x.ph_alias = ext[CX_PH_ALIAS * Ppad + l];
+  int64_t noteid = b.car_noteid[(size_t)s * Ppad + l];
+  int dropped = 0;
+  const RaEnvParams ep = {p.envA, p.envH, p.envD, p.envR, p.SMinusOne};
+  const uint64_t seed = p.seed + (uint64_t)s;
+  // VocoderCarrierElementInitializer (lib.cpp:155-171): volume targets (float -> T) and PulseTrainAlgo_::setPulseWidth (audioelement.h:1701-1719)
+  const double v_noise = (double)p.car_vol[0], v_saw = (double)p.car_vol[1], v_tri = (double)p.car_vol[2], v_sq = (double)p.car_vol[3],
+               v_sine = (double)p.car_vol[4], v_pulse = (double)p.car_vol[5];
+  double pw = (double)p.car_pulse_width;
+  pw = fmax(0., pw); pw = fmin(2., pw);
+  const double p_high = 0.5 * (2. - pw), p_low = p_high - 1.;
+
+  const RaCarEv *ev = b.car_ev;
+  int e = b.car_ev_begin[s];
+  const int e_end = b.car_ev_begin[s + 1];
+  double *out_d = b.car_gen_d + (size_t)s * n;
+  float *out_f = b.car_gen_f + (size_t)s * n;
+
+  int64_t t = t0;
+  const int64_t t_end = t0 + n;
+  while (t < t_end) {
+    if (e < e_end && ev[e].sample <= t) { // the one-shots queued for this frame run before its step (simple_audio_context.h:74-76)
+      const RaCarEv q = ev[e];
+      ++e;
+      if (l == 0) { xi[0] = 0x7fffffff; xi[1] = 0x7fffffff; }
+      __syncthreads();
+      if (q.type == 0) { // ---- onEvent(NoteOn), gen.crtp.h:389-449, and its one-shot :455-527 (run at once: same frame) ----
+        if (l < P && c.state == ENV_DONE2) atomicMin(&xi[0], l); // tryAcquire: the first finished channel, :397-405
+        __syncthreads();
+        const int sel = xi[0];
+        if (sel == 0x7fffffff) { if (l == 0) ++dropped; } // onDroppedNote
+        else {
+          if (l == sel) {
+            c.state = ENV_SOON;
+            noteid = q.noteid;                                        // channels.corresponding(*channel) = e.noteid
+            chan_forget_past_signals(c);                              // envelope, control, volumes (the mix's have no state here)
+            c.target = 1.0 * (double)q.vel; c.flags |= FL_HAS_TARGET; // Element::baseVolume (BaseVolumeDef::One) * velocity, :425
+            c.cur = 0;                                                // initializer: ctrl.setup(100, LINEAR), no f_result yet (lib.cpp:157-158)
+            const float inc_f = 2 * (q.freq * 1.f) / p.sample_rate;   // setupAudioElement, gen.sine.h:9-21
+            chan_set_angle_increments(c, (double)inc_f, 0);
+            xch[0] = car_angle_increments(c, x);
+          }
+          __syncthreads();
+          // setPhase (gen.crtp.h:128-156): the first RT-active channel with an equal angleIncrements() donates its angles
+          if (l != sel && l < P && rt_active(c) && car_angle_increments(c, x) == xch[0]) atomicMin(&xi[1], l);
+          __syncthreads();
+          const int src = xi[1];
+          if (src != 0x7fffffff && l == src) { xch[1] = x.ph_angle; xch[2] = c.cre; xch[3] = c.cim; }
+          __syncthreads();
+          if (l == sel) {
+            if (src != 0x7fffffff) {
+              x.ph_angle = phase_to_normal_form(xch[1]); // Phased::synchronizeAngles -> setStartAngle, audioelement.h:1433-1439
+              c.cre = xch[2]; c.cim = xch[3];            // SineOscillatorAlgo::synchronizeAngles :2397-2399
+            } else {
+              const float a = (p.phase_policy == RA_PHASE_HASH) ? hash_uniform_pm1(seed, (uint64_t)q.noteid, 2) : 0.f;
+              x.ph_angle = phase_to_normal_form((double)a);
+              double sn, cs;
+              sincos(M_PI * (double)a, &sn, &cs);          // setStartAngle :2401-2403
+              c.cre = cs; c.cim = sn;
+            }
+            env_on_key_pressed(c, q.delay);
+          }
+        }
+      } else { // ---- NoteOff one-shot, gen.crtp.h:541-588: the first channel that last played this note id ----
+        if (l < P && noteid == q.noteid) atomicMin(&xi[0], l);
+        __syncthreads();
+        if (l == xi[0] && env_can_release_now(c, q.delay)) env_on_key_released(c, q.delay);
+      }
+      __syncthreads();
+      continue;
+    }
+    const int64_t seg_end = (e < e_end) ? min(t_end, ev[e].sample) : t_end;
+    if (!__syncthreads_or(l < P && rt_active(c))) { // nothing sounds until the next event: silence
+      for (int64_t r = t + l; r < seg_end; r += blockDim.x) { out_d[r - t0] = 0.0; out_f[r - t0] = 0.f; }
+      t = seg_end;
+      continue;
+    }
+    const int m = (int)min((int64_t)CT, seg_end - t);
+    double *mine = tile + (size_t)l * (CT + 1);
+    for (int i = 0; i < m; ++i) {
+      double v = 0.0;
+      if (rt_active(c)) { // ImplCRTP::compute, gen.crtp.h:352-371
+        // BaseVolumeAdjusted::step (:1195-1216) -> Enveloped::step (:197-200) -> FreqCtrl_::step (:3126-3129)
+        env_step(c, ep);
+        const double f = ctrl_step(c, 100.0);
+        x.ph_inc = phase_to_normal_form(f); x.ph_alias = alias_mult(f); // Phased::setAngleIncrements :1443-1446
+        osc_set_inc(c, f);
+        x.ph_angle += x.ph_inc;                                        // Phased::step :1452-1470
+        if (x.ph_angle > 2.0) x.ph_angle -= 2.0;
+        { // SineOscillatorAlgo::step
+          const double re = c.cre * c.mre - c.cim * c.mim, im = c.cre * c.mim + c.cim * c.mre;
+          const double g = 0.5 * (3.0 - (re * re + im * im));
+          c.cre = re * g; c.cim = im * g;
+        }
+        { // the outer volume filter: the first step takes the target, later steps keep it (target constant over the note)
+          const bool first = !(c.flags & FL_HAS_VOL);
+          const double inc = fabs(car_angle_increments(c, x));
+          const bool new_k = first || (c.vol != c.target && c.finit != inc);
+          const double a = M_PI * inc;
+          c.finit = new_k ? inc : c.finit;
+          c.k = new_k ? a / (1.0 + a) : c.k;
+          const double y0 = first ? c.target : c.y;
+          c.y = y0 + c.k * (c.target - y0);
+          c.vol = c.y;
+          c.flags |= FL_HAS_VOL;
+        }
+        if (rt_active(c)) {
+          // UnityGainMix::imag (:1966-1972): sum = 0.f; sum += volume_i * (aliasingMult * wave_i(angle)), in tuple order
+          double sum = 0.f;
+          sum += v_noise * 0.0;
+          sum += v_saw * (x.ph_alias * wave_saw(x.ph_angle));
+          sum += v_tri * (x.ph_alias * wave_triangle(x.ph_angle));
+          sum += v_sq * (x.ph_alias * wave_square(x.ph_angle));
+          sum += v_sine * (c.alias * c.cim);
+          sum += v_pulse * (x.ph_alias * wave_pulse(x.ph_angle, pw, p_high, p_low));
+          v = c.vol * (sum * c.value); // BaseVolumeAdjusted::imag (:1126-1129) over Enveloped::imag (:227-231)
+        }
+      }
+      mine[i] = v;
+    }
+    __syncthreads();
+    if (l < m) { // `buffer[i] += c.elem.imag()` over the channels in index order (silent channels add 0)
+      double acc = 0.0;
+      for (int ch = 0; ch < P; ++ch) acc += tile[(size_t)ch * (CT + 1) + l];
+      out_d[t - t0 + l] = acc;
+      out_f[t - t0 + l] = (float)acc;
+    }
+    __syncthreads();
+    t += m;
+  }
+  store_chan(c, sd, si, Ppad, l);
+  ext[CX_PH_ANGLE * Ppad + l] = x.ph_angle; ext[CX_PH_INC * Ppad + l] = x.ph_inc; ext[CX_PH_ALIAS * Ppad + l] = x.ph_alias;
+  b.car_noteid[(size_t)s * Ppad + l] = noteid;
+  if (l == 0 && dropped) b.car_dropped[s] += dropped;
+}
+
+// ---- K7 -------------------------------------------------------------------------------------------------------------------
+constexpr int BT = 64; // samples per tile = lanes
+__global__ void __launch_bounds__(64) ra_voc_bank_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, const float *__restrict__ carrier_f,
+                                                        const double *__restrict__ carrier_d, int64_t n) {
+  const int s = blockIdx.x, l = threadIdx.x, B = p.voc_bands;
+  double *tile = reinterpret_cast<double *>(ra_smem_car); // [BT][65]: row = sample, column = band
+  const bool band = l < B;
+  const double kA = b.bank_k[l], kB = b.bank_k[64 + l], kE = b.bank_k[128 + l];
+  double *st = b.bank_state + (size_t)s * 5 * 64;
+  double yA = st[l], yB = st[64 + l], yE = st[128 + l], yC = st[192 + l], yD = st[256 + l];
+  const float *vs = voice ? voice + (size_t)s * n : nullptr;
+  const float *cf = carrier_f ? carrier_f + (size_t)s * n : nullptr;
+  const double *cd = carrier_d ? carrier_d + (size_t)s * n : nullptr;
+  double *mix = b.voc_mix + (size_t)s * n;
+  for (int64_t t = 0; t < n; t += BT) {
+    const int cnt = (int)min((int64_t)BT, n - t);
+    // this lane's sample of the tile (the modulator as the double read_direct_input widens it to, lib.cpp:1073-1079)
+    double mv = 0.0, cv = 0.0;
+    if (l < cnt) {
+      if (vs) mv = (double)vs[t + l];
+      if (cd) cv = cd[t + l]; else if (cf) cv = (double)cf[t + l];
+    }
+    for (int i = 0; i < cnt; ++i) {
+      const double m = __shfl(mv, i), c = __shfl(cv, i);
+      // Modulator::feed (vocoder.cpp:358-380): BandPass::feed (:54-58) = high-pass then low-pass; EnvelopeFollower::feed (:71-74) of |.|
+      yA = yA + kA * (m - yA);
+      const double hp = m - yA;             // high-pass = input - low-pass
+      yB = yB + kB * (hp - yB);
+      yE = yE + kE * (fabs(yB) - yE);
+      // Carrier::feed (:698-718)
+      yC = yC + kA * (c - yC);
+      const double hpc = c - yC;
+      yD = yD + kB * (hpc - yD);
+      tile[i * 65 + l] = band ? yE * yD : 0.0; // ponderation[i] * filtered
+    }
+    // `res += ponderation[i] * filtered` in band order (one wave: its LDS operations execute in order)
+    if (l < cnt) {
+      double acc = 0.0;
+      const double *row = tile + l * 65;
+      for (int q = 0; q < B; ++q) acc += row[q];
+      mix[t + l] = (double)p.vol_mod * mv + (double)p.vol_car * cv + (double)p.vol_voc * acc; // vocoder.cpp:799-803
+    }
+  }
+  st[l] = yA; st[64 + l] = yB; st[128 + l] = yE; st[192 + l] = yC; st[256 + l] = yD;
+}
+
+} // namespace
+
+void ra_launch_carrier_synth(const RaParams &p, const RaBuffers &b, int64_t t0, int64_t n, hipStream_t st) {
+  if (n <= 0 || p.car_P <= 0) return;
+  const size_t lds = (size_t)p.car_Ppad * (CT + 1) * sizeof(double) + 4 * sizeof(double) + 4 * sizeof(int);
+  hipLaunchKernelGGL(ra_carrier_synth_kernel, dim3((unsigned)p.n_streams), dim3((unsigned)p.car_Ppad), lds, st, p, b, t0, n);
+}
+
+void ra_launch_voc_bank(const RaParams &p, const RaBuffers &b, const float *d_voice, const float *d_carrier, const double *carrier_d, int64_t t0, int64_t n,
+                        hipStream_t st) {
+  if (n <= 0) return;
+  (void)t0;
+  hipLaunchKernelGGL(ra_voc_bank_kernel, dim3((unsigned)p.n_streams), dim3(64), (size_t)BT * 65 * sizeof(double), st, p, b, d_voice, d_carrier, carrier_d, n);
+}

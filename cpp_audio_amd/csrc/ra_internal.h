@@ -35,6 +35,11 @@ struct RaParams {
   // vocoder
   int voc_enabled, voc_S, voc_Wm, voc_Lm, voc_Mm, voc_Lc, voc_Mc, voc_bands;
   float vol_mod, vol_car, vol_voc;
+  // the band-pass bank variant of the vocoder and the vocoder carrier synth
+  int voc_kind;            // RA_VOCODER_FFT / RA_VOCODER_BANDPASS
+  int car_P, car_Ppad;     // channels of the carrier synth (0 = none), padded to a multiple of 64
+  float car_vol[6];        // noise, saw, triangle, square, sine, pulse volume targets (lib.cpp:978-983)
+  float car_pulse_width;   // lib.cpp:984
   float fb_gain;   // output -> analysis feedback (lib.cpp:1626-1652): gain, and the delay in frames
   int fb_sz;
   int render_mode; // diagnostics: 0 regime renderer, 2 hop-parallel with the reference-order step, 3 with the cheap generic step
@@ -120,6 +125,21 @@ struct RaBuffers {
   int64_t fb_hist_len, fb_block_cap;
   double *dbg_sqmag;        // optional [frames][M] tap of |X|^2 (ra_sqmag), normally null
   unsigned long long *dbg_clk; // optional [64] in-kernel phase clocks (env RA_PHASE_CLOCKS=1, printed by ra_destroy), normally null
+  // ---- vocoder carrier synth (only with carrier_n_channels > 0 and a vocoder volume non-zero) ----
+  double *car_sd;           // [n_streams][SD_COUNT][car_Ppad] envelope / control / sine oscillator / outer volume, like sd
+  int32_t *car_si;          // [n_streams][SI_COUNT][car_Ppad]
+  double *car_ext;          // [n_streams][CX_COUNT][car_Ppad] the phase-controlled oscillators
+  int64_t *car_noteid;      // [n_streams][car_Ppad] note id each channel last played (-1 = never used), gen.crtp.h:419
+  int32_t *car_dropped;     // [n_streams] note-ons dropped for want of a free channel
+  struct RaCarEv *car_ev;   // the block's note events, stream after stream, in queue order
+  int32_t *car_ev_begin;    // [n_streams + 1]
+  int64_t car_ev_cap;
+  double *car_gen_d;        // [n_streams][n] the generated carrier as the double the vocoder compute receives ...
+  float *car_gen_f;         // ... and as the float PeriodicFFT::feed stores (periodicfft.cpp:55-61)
+  int64_t car_gen_cap;
+  // ---- band-pass bank (vocoder_kind = RA_VOCODER_BANDPASS) ----
+  double *bank_k;           // [3][64] one-pole coefficients per band: high-pass (band's lower edge), low-pass (upper edge), envelope follower
+  double *bank_state;       // [n_streams][5][64] filter states: modulator hp / lp, envelope follower, carrier hp / lp
   // ---- vocoder (only allocated when a vocoder volume is non-zero) ----
   double *voc_half_window;  // [Wm/2] Gaussian 4 sigma
   double2 *vm_tw_half, *vm_tw_full; int *vm_bitrev;   // modulator FFT, length Lm
@@ -204,7 +224,21 @@ struct RaNoteEv {
 };
 void ra_launch_notes(const RaNoteEv *d_ev, const int *d_slot_begin, int n_slots, RaEnvParams ep, int64_t T, double *d_partial, double *d_out,
                      double2 *d_phase_io, hipStream_t st);
-void ra_launch_vocoder(const RaParams &p, const RaBuffers &b, const float *d_voice, const float *d_carrier, int64_t t0, int64_t n, hipStream_t st);
+// carrier_d: the carrier as doubles when it comes from the carrier synth (then d_carrier is its float image), else null
+void ra_launch_vocoder(const RaParams &p, const RaBuffers &b, const float *d_voice, const float *d_carrier, const double *carrier_d, int64_t t0, int64_t n,
+                       hipStream_t st);
+// one note event of the carrier synth as the device sees it (the host has resolved key -> note id, events.h:228-281)
+struct RaCarEv {
+  int64_t sample;  // output frame whose step runs the event's one-shot
+  int64_t noteid;
+  int32_t type;    // 0 NoteOn, 1 NoteOff
+  int32_t delay;   // frames handed to onKeyPressed / onKeyReleased
+  float freq, vel;
+};
+enum { CX_PH_ANGLE, CX_PH_INC, CX_PH_ALIAS, CX_COUNT };
+void ra_launch_carrier_synth(const RaParams &p, const RaBuffers &b, int64_t t0, int64_t n, hipStream_t st);
+void ra_launch_voc_bank(const RaParams &p, const RaBuffers &b, const float *d_voice, const float *d_carrier, const double *carrier_d, int64_t t0, int64_t n,
+                        hipStream_t st);
 
 // one time-chunk of a ra_process_* block: the block gives I/O indexing and the history split, the chunk the work range
 struct RaSpan {

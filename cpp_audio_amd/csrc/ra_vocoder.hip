@@ -211,8 +211,8 @@ __global__ void __launch_bounds__(T) ra_voc_carrier_kernel(RaParams p, RaBuffers
 }
 
 // ---- K4c ------------------------------------------------------------------------------------------
-__global__ void ra_voc_mix_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, const float *__restrict__ carrier, int64_t t0, int64_t n,
-                                  int64_t i_lo, int64_t n_car) {
+__global__ void ra_voc_mix_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, const float *__restrict__ carrier,
+                                  const double *__restrict__ carrier_d, int64_t t0, int64_t n, int64_t i_lo, int64_t n_car) {
   const int s = blockIdx.y;
   const int S = p.voc_S, W = 2 * p.voc_S;
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
@@ -231,7 +231,8 @@ __global__ void ra_voc_mix_kernel(RaParams p, RaBuffers b, const float *__restri
       y = (nw ? nw[idx] : 0.0) * nm + (od ? od[idx + S] : 0.0) * om;
     }
     const double m = voice ? (double)voice[(size_t)s * n + r] : 0.0;
-    const double c = carrier ? (double)carrier[(size_t)s * n + r] : 0.0;
+    // the carrier as the compute lambda holds it (vocoder.cpp:777-803): a double — the carrier synth's sum, or the job's float sample widened
+    const double c = carrier_d ? carrier_d[(size_t)s * n + r] : carrier ? (double)carrier[(size_t)s * n + r] : 0.0;
     b.voc_mix[(size_t)s * n + r] = (double)p.vol_mod * m + (double)p.vol_car * c + (double)p.vol_voc * y;
   }
 }
@@ -280,8 +281,10 @@ __global__ void ra_voc_roll_kernel(RaParams p, RaBuffers b, const float *__restr
 
 } // namespace
 
-void ra_launch_vocoder(const RaParams &p, const RaBuffers &b, const float *d_voice, const float *d_carrier, int64_t t0, int64_t n, hipStream_t st) {
+void ra_launch_vocoder(const RaParams &p, const RaBuffers &b, const float *d_voice, const float *d_carrier, const double *carrier_d, int64_t t0, int64_t n,
+                       hipStream_t st) {
   if (n <= 0) return;
+  if (p.voc_kind == RA_VOCODER_BANDPASS) { ra_launch_voc_bank(p, b, d_voice, d_carrier, carrier_d, t0, n, st); return; }
   const int S = p.voc_S, W = 2 * S;
   RaFrameRange mod = ra_frames_firing(p.voc_Wm, S, t0, n);
   RaFrameRange car = ra_frames_firing(W, S, t0, n);
@@ -318,7 +321,7 @@ void ra_launch_vocoder(const RaParams &p, const RaBuffers &b, const float *d_voi
   }
   {
     unsigned gx = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
-    hipLaunchKernelGGL(ra_voc_mix_kernel, dim3(gx, (unsigned)p.n_streams), dim3(256), 0, st, p, b, d_voice, d_carrier, t0, n, car.lo, car.count);
+    hipLaunchKernelGGL(ra_voc_mix_kernel, dim3(gx, (unsigned)p.n_streams), dim3(256), 0, st, p, b, d_voice, d_carrier, carrier_d, t0, n, car.lo, car.count);
   }
   size_t lds = std::max((size_t)2 * W * sizeof(double), (size_t)p.voc_Wm * sizeof(float));
   hipLaunchKernelGGL(ra_voc_roll_kernel, dim3((unsigned)p.n_streams), dim3(256), lds, st, p, b, d_voice, d_carrier, n, car.lo, car.count, mod.count);

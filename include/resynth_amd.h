@@ -36,6 +36,9 @@ enum { RA_SCALE_MAJOR = 0, RA_SCALE_MINOR_NATURAL = 1, RA_SCALE_MINOR_HARMONIC =
 enum { RA_CHORD_SINGLE = 0, RA_CHORD_HARMONICS = 1, RA_CHORD_OCTAVES = 2 };           /* rt.resynth.lib.autotune.cpp:16-20 */
 enum { RA_WINDOW_GAUSSIAN4 = 0, RA_WINDOW_HANN = 1, RA_WINDOW_RECT = 2 };             /* periodicfft.cpp:246-249 (+Hann, main.test_fft.cpp:79) */
 enum { RA_PHASE_HASH = 0, RA_PHASE_ZERO = 1 };                                        /* gen.crtp.h:147-155 DefaultStartPhase */
+/* the live FFT vocoder (vocoder.cpp:100-252,396-551) / the band-pass bank it replaced (vocoder.cpp:46-79,310-394,667-732: the members
+ * commented out at :846-851; "32-band biquad bank" of BASELINE configs[2]) */
+enum { RA_VOCODER_FFT = 0, RA_VOCODER_BANDPASS = 1 };
 
 /*
  * The parameter block of one RtResynth (the std::atomic<> members of source/rt.resynth.lib.cpp:943-999,
@@ -101,7 +104,37 @@ typedef struct ra_config {
    * only for delays of many strides (the reference default is 1 s).  Not available with reference_order != 0. */
   float analysis_output_feedback_gain; /* 0 */
   float output_delay_seconds;          /* 1 */
+
+  int32_t vocoder_kind;                    /* RA_VOCODER_* */
+  float vocoder_env_follower_cutoff_ratio; /* 1/20 (lib.cpp:985): envelope follower cut-off = ratio * the band's lower edge; bank only */
+  /*
+   * The vocoder carrier synth (SynthVocoderCarier, lib.cpp:212-221: VocoderCarrierElement, :21-52, initialised by
+   * VocoderCarrierElementInitializer, :137-196).  carrier_n_channels = 2 * nVoices (reference: 254), 0 = no synth.  The vocoder takes its
+   * carrier from the synth when ra_process_* is given no carrier buffer (the reference: realtime mode the synth, offline job the file,
+   * lib.cpp:1405-1412); notes come from ra_carrier_events.  The noise voice reads a sound buffer of the absent cpp.algorithms:
+   * vocoder_carrier_noise_volume must be 0 (ra_create refuses anything else).
+   */
+  int32_t carrier_n_channels; /* 0..256 */
+  float vocoder_carrier_noise_volume, vocoder_carrier_saw_volume, vocoder_carrier_triangle_volume, vocoder_carrier_square_volume,
+      vocoder_carrier_sine_volume, vocoder_carrier_pulse_volume, vocoder_carrier_pulse_width; /* lib.cpp:978-984: 0 0 0 1 0 0 0.01 */
 } ra_config;
+
+/*
+ * One note event of the vocoder carrier synth: what RtResynth::onInputMidiEvent (lib.cpp:1518-1545) hands to
+ * SynthVocoderCarier::onEvent for a MIDI note-on / note-off, minus the MIDI device.  `sample` is the output frame whose
+ * SimpleAudioOutContext::step runs the event's one-shot (simple_audio_context.h:74-76) — the event then acts on that very frame — and
+ * `delay` the frames the one-shot passes on to onKeyPressed / onKeyReleased (gen.crtp.h:506-512,556-566; 0 = the "late" branch).
+ * key: the NoteIdsGenerator key (events.h:228-281): a note-off releases the EARLIEST pending note-on of its key.
+ */
+typedef struct ra_carrier_event {
+  int64_t sample;
+  int32_t stream;
+  int32_t type;      /* 0 NoteOn, 1 NoteOff */
+  int32_t key;       /* MIDI key */
+  int32_t delay;
+  float frequency;   /* Hz; <= 0: Midi::midi_pitch_to_freq(key) (midi.h:258-264), as onInputMidiEvent does */
+  float velocity;    /* on.velocity / 127.f */
+} ra_carrier_event;
 
 typedef struct ra_context ra_context;
 
@@ -120,6 +153,7 @@ typedef struct ra_stats {
   int64_t dropped_note_on;      /* RtResynth::countDroppedNoteOns, lib.cpp:549-551, all streams */
   int32_t error_flags;          /* bit0 pitch-list overflow, bit1 channel bookkeeping mismatch */
   int32_t reserved;
+  int64_t carrier_dropped_note_on; /* carrier synth note-ons that found no free channel (onDroppedNote, gen.crtp.h:624-627), all streams */
 } ra_stats;
 
 /* A note for the main.resynth driver: DeducedNote<double> as used by include/resynth.hpp:58-61,84-96. */
@@ -184,6 +218,16 @@ int ra_join(ra_context *ctx);
  * into the caller's interleaved double buffer [nFrames][2], exactly like the two registered computes together.
  * HOST pointers.  Returns 1 where the reference functor returns true, or a negative RA_E* code.
  */
+/*
+ * Queues note events for the carrier synth (HOST pointer).  Per stream, samples must not decrease and must not lie before the frames
+ * already processed; events are applied by the ra_process_* call whose block contains them.  Returns RA_OK, or RA_EINVAL at the first
+ * bad event (earlier ones stay queued): unknown stream / type, a sample in the past, a note-off for a key with no pending note-on.
+ * ra_reset drops what is still queued.
+ */
+int ra_carrier_events(ra_context *ctx, const ra_carrier_event *h_events, int64_t n_events);
+/* debug / test tap: the carrier the vocoder was given during the LAST ra_process_* call, [n_frames] doubles of one stream (HOST pointer) */
+int ra_get_carrier(ra_context *ctx, int32_t stream, double *h_carrier, int64_t cap);
+
 int ra_feed(ra_context *ctx, int32_t stream, const float *h_voice, const float *h_carrier, int32_t n_frames);
 int ra_compute(ra_context *ctx, int32_t stream, double *h_buffer, int32_t n_frames);
 

@@ -137,6 +137,25 @@ int64_t ora_run_offline(const ora_config *c, const float *voice, const float *ca
   return n;
 }
 
+// The same with note events for the vocoder carrier synth (sorted by sample).  carrier_out (may be NULL): the carrier sample the vocoder
+// was given at every frame, as a double.  dropped[0] = resynthesis note-ons dropped, dropped[1] = carrier note-ons dropped.
+int64_t ora_run_offline_ex(const ora_config *c, const float *voice, const float *carrier, int64_t n_frames, const ora_carrier_event *cev,
+                           int64_t n_cev, float *out, double *carrier_out, ora_event *log, int64_t log_cap, int32_t *dropped) {
+  RtResynthOffline r(*c);
+  r.carrier_events.assign(cev, cev + n_cev);
+  std::vector<double> dump;
+  if (carrier_out) { dump.reserve(n_frames); r.carrier_dump = &dump; }
+  r.run(voice, carrier, n_frames, out);
+  if (carrier_out) std::memcpy(carrier_out, dump.data(), sizeof(double) * std::min<size_t>(dump.size(), n_frames));
+  if (dropped) { dropped[0] = r.dropped_note_on; dropped[1] = r.carrier_dropped_note_on; }
+  int64_t n = static_cast<int64_t>(r.event_log.size());
+  for (int64_t i = 0; i < n && i < log_cap; ++i) {
+    auto const &e = r.event_log[i];
+    log[i] = {e.sample, e.type, e.channel, e.noteid, e.frequency, e.velocity};
+  }
+  return n;
+}
+
 // Per-frame autotuned pitch lists of one stream (the output of the stateless half of step()).
 // fire_sample[f] = iteration index at which frame f fired; offsets[f]..offsets[f+1] index pitch/vol.
 int64_t ora_run_frames(const ora_config *c, const float *voice, int64_t n_frames, int64_t *fire_sample, int64_t *offsets, int64_t frame_cap,

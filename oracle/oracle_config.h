@@ -64,7 +64,24 @@ typedef struct ora_config {
   /* feedback of the (mono) output into the analysis input, lib.cpp:1626-1652 */
   float analysis_output_feedback_gain; /* 0 */
   float output_delay_seconds;          /* 1 */
+
+  /* SURVEY.md §8 f2 */
+  int32_t vocoder_kind;                    /* 0 = the live FFT vocoder, 1 = the band-pass bank it replaced (vocoder.cpp:46-79,310-394,667-732) */
+  float vocoder_env_follower_cutoff_ratio; /* 1/20, lib.cpp:985 */
+  int32_t carrier_n_channels;              /* channels of the vocoder carrier synth (reference 2 * 127, lib.cpp:212-221); 0 = none */
+  float vocoder_carrier_noise_volume, vocoder_carrier_saw_volume, vocoder_carrier_triangle_volume, vocoder_carrier_square_volume,
+      vocoder_carrier_sine_volume, vocoder_carrier_pulse_volume, vocoder_carrier_pulse_width; /* lib.cpp:978-984: 0 0 0 1 0 0 0.01 */
 } ora_config;
+
+/* one note event of the vocoder carrier synth (RtResynth::onInputMidiEvent, lib.cpp:1518-1545) */
+typedef struct ora_carrier_event {
+  int64_t sample;  /* output frame whose step() runs the event's one-shot */
+  int32_t type;    /* 0 NoteOn, 1 NoteOff */
+  int32_t key;     /* MIDI key = NoteIdsGenerator key */
+  int32_t delay;   /* frames handed to onKeyPressed / onKeyReleased */
+  float frequency; /* Hz; <= 0: midi_pitch_to_freq(key) */
+  float velocity;
+} ora_carrier_event;
 
 #ifdef __cplusplus
 }

@@ -6,7 +6,7 @@
  */
 #pragma once
 #include "oracle_config.h"
-#include "oracle_synth.hpp"
+#include "oracle_carrier.hpp"
 
 namespace ora {
 
@@ -46,6 +46,11 @@ inline ora_config default_config() { // lib.cpp:943-999
   c.output_delay_seconds = 1.f;
   c.phase_policy = ORA_PHASE_HASH;
   c.seed = 0;
+  c.vocoder_kind = 0;
+  c.vocoder_env_follower_cutoff_ratio = 1.f / 20.f;
+  c.carrier_n_channels = 0;
+  c.vocoder_carrier_square_volume = 1.f;
+  c.vocoder_carrier_pulse_width = 0.01f;
   return c;
 }
 
@@ -154,6 +159,20 @@ inline void for_each_band_bin(std::vector<double> const &freqs, int n_bins, doub
   }
 }
 
+inline void BankVocoder::setup(ora_config const &c) { // Modulator::setup_bands / setup :315-354, Carrier::setup :669-692
+  fill_freqs(c.vocoder_min_freq, c.vocoder_max_freq, c.vocoder_count_bands, freqs);
+  int const sz = static_cast<int>(freqs.size()) - 1;
+  mod_band_pass.assign(sz, BandPass{});
+  car_band_pass.assign(sz, BandPass{});
+  env_follower.assign(sz, EnvelopeFollower{});
+  res.assign(sz, 0.0);
+  for (int i = 0; i < sz; ++i) {
+    mod_band_pass[i].setup(c.sample_rate, freqs[i], freqs[i + 1]);
+    car_band_pass[i].setup(c.sample_rate, freqs[i], freqs[i + 1]);
+    env_follower[i].setup(c.sample_rate, freqs[i] * c.vocoder_env_follower_cutoff_ratio);
+  }
+}
+
 struct Vocoder { // Vocoder :734-856 = FFTModulator :100-252 + FFTCarrier :396-551
   int sample_rate = 0, S = 0, n_bands = 0;
   std::vector<double> freqs, bands_amplitudes;
@@ -164,8 +183,12 @@ struct Vocoder { // Vocoder :734-856 = FFTModulator :100-252 + FFTCarrier :396-5
   RealFft inv;
   int new_signal_idx = 0, sz_half_signal = 0;
   bool have_signal = false;
+  int kind = 0;     // 1: Modulator<1, double> / Carrier<1, double> (the members commented out at :846-851) instead of the FFT pair
+  BankVocoder bank;
 
   void setup(ora_config const &c) {
+    kind = c.vocoder_kind;
+    if (kind == 1) bank.setup(c);
     sample_rate = c.sample_rate;
     n_bands = c.vocoder_count_bands;
     fill_freqs(c.vocoder_min_freq, c.vocoder_max_freq, n_bands, freqs);
@@ -215,8 +238,12 @@ struct Vocoder { // Vocoder :734-856 = FFTModulator :100-252 + FFTCarrier :396-5
   }
   // the compute lambda of Vocoder::initialize, :763-812, one frame
   void compute_one(double modulator, double carrier, float vol_mod, float vol_car, float vol_voc, double *buf2) {
-    mod_fft.feed(static_cast<float>(modulator));
-    double const vocoded = feed_carrier(carrier);
+    double vocoded;
+    if (kind == 1) vocoded = bank.feed(modulator, carrier);
+    else {
+      mod_fft.feed(static_cast<float>(modulator));
+      vocoded = feed_carrier(carrier);
+    }
     double const mixed = vol_mod * modulator + vol_car * carrier + vol_voc * vocoded;
     buf2[0] += mixed;
     buf2[1] += mixed;
@@ -230,6 +257,13 @@ struct RtResynthOffline {
   Stepper stepper;
   Synth synth;
   Vocoder vocoder;
+  CarrierSynth vocoder_carrier; // lib.cpp:910
+  NoteIdsGenerator vocoder_carrier_noteids;
+  std::vector<ora_carrier_event> carrier_events; // sorted by sample; consumed by run()
+  size_t carrier_event_pos = 0;
+  int carrier_dropped_note_on = 0;
+  std::vector<double> *carrier_dump = nullptr; // per frame, the carrier sample the vocoder was given
+  bool carrier_from_synth = false;
   Autotune autotune;
   PeriodicFFT<SqMagOp> periodic_fft;
   std::vector<FreqMag> freqmags;
@@ -255,9 +289,12 @@ struct RtResynthOffline {
   std::vector<float> output_delay;
   int delay_pos = 0;
 
-  explicit RtResynthOffline(ora_config const &c) : cfg(c), synth(c.n_channels) {
+  explicit RtResynthOffline(ora_config const &c) : cfg(c), synth(c.n_channels), vocoder_carrier(std::max(0, c.carrier_n_channels)) {
     synth.phase_policy = c.phase_policy;
     synth.seed = c.seed;
+    vocoder_carrier.phase_policy = c.phase_policy;
+    vocoder_carrier.seed = c.seed;
+    vocoder_carrier.now = &now;
     synth.log = &event_log;
     synth.now = &now;
     autotune.build(c.use_autotune, c.autotune_type, c.autotune_scale_mode, c.autotune_root_note, c.autotune_root_transpose,
@@ -268,10 +305,27 @@ struct RtResynthOffline {
     stepper.enqueueOneShot([this]() {
       stepper.registerSimpleCompute([this](double *buf, int frames) {
         if (!enable_vocoder) return true;
-        for (int i = 0; i < frames; ++i) vocoder.compute_one(cur_voice, cur_carrier, cfg.voice_volume, cfg.carrier_volume, cfg.vocoder_volume, buf + 2 * i);
+        for (int i = 0; i < frames; ++i) {
+          // get_modulator_carrier_sample, lib.cpp:1395-1418: realtime mode computes one frame of the carrier synth, the offline job reads
+          // its carrier file; here: the file when the job has one, else the synth when it has channels
+          double carrier_val = cur_carrier;
+          if (carrier_from_synth) { carrier_val = 0.0; vocoder_carrier.compute(&carrier_val, 1); }
+          if (carrier_dump) carrier_dump->push_back(carrier_val);
+          vocoder.compute_one(cur_voice, carrier_val, cfg.voice_volume, cfg.carrier_volume, cfg.vocoder_volume, buf + 2 * i);
+        }
         return true;
       });
     });
+    { // updateVocoderCarrierInitializer, lib.cpp:1498-1516 (no note is playing yet: only future notes are concerned)
+      CarrierInitializer init;
+      init.sample_rate = c.sample_rate;
+      init.ahdsr = mkAHDSR(c.sample_rate, c.env_attack_seconds, c.env_hold_seconds, c.env_decay_seconds, c.env_release_seconds, c.env_sustain_level);
+      init.noise_volume = c.vocoder_carrier_noise_volume; init.saw_volume = c.vocoder_carrier_saw_volume;
+      init.triangle_volume = c.vocoder_carrier_triangle_volume; init.square_volume = c.vocoder_carrier_square_volume;
+      init.sine_volume = c.vocoder_carrier_sine_volume; init.pulse_volume = c.vocoder_carrier_pulse_volume;
+      init.pulse_width = c.vocoder_carrier_pulse_width;
+      vocoder_carrier.initializer = init;
+    }
     stepper.post = [this](double *buf, int frames) { // init_post, lib.cpp:1262-1272 (post "none": only the mono publication)
       for (int i = 0; i < frames; ++i) last_published = static_cast<float>(buf[2 * i] + buf[2 * i + 1]);
     };
@@ -345,8 +399,21 @@ struct RtResynthOffline {
   // samples 0 and 1, so PeriodicFFT receives inputs 2,3,... ; analysis of iteration k runs before
   // the output step of iteration k.  analysis_output_feedback_gain is 0 (default): no feedback term.
   void run(const float *voice, const float *carrier, int64_t n_frames, float *out /* [n_frames][2] */) {
+    carrier_from_synth = !carrier && cfg.carrier_n_channels > 0;
     for (int64_t k = 0; k < n_frames; ++k) {
       now = k;
+      // RtResynth::onInputMidiEvent, lib.cpp:1518-1545: events stamped with frame k reach the synth before the step of frame k
+      for (; carrier_event_pos < carrier_events.size() && carrier_events[carrier_event_pos].sample <= k; ++carrier_event_pos) {
+        ora_carrier_event const &ce = carrier_events[carrier_event_pos];
+        if (ce.type == 0) {
+          float const f = ce.frequency > 0.f ? ce.frequency : static_cast<float>(midi.midi_pitch_to_freq(static_cast<double>(ce.key)));
+          Event e{EventType::NoteOn, vocoder_carrier_noteids.NoteOnId(static_cast<uint64_t>(ce.key)), f, ce.velocity, ce.delay};
+          if (vocoder_carrier.onEvent(cfg.sample_rate, e, stepper) != onEventResult::OK) ++carrier_dropped_note_on;
+        } else {
+          auto id = vocoder_carrier_noteids.NoteOffId(static_cast<uint64_t>(ce.key));
+          if (id) vocoder_carrier.onEvent(cfg.sample_rate, Event{EventType::NoteOff, *id, 0.f, 0.f, ce.delay}, stepper);
+        }
+      }
       float const v = voice ? voice[k] : 0.f;
       cur_voice = v; // read_direct_input: the float sample widened to double (lib.cpp:1073-1079)
       cur_carrier = carrier ? static_cast<double>(carrier[k]) : 0.0;

@@ -263,6 +263,9 @@ struct ResynthElement {
     volume_target.reset();
   }
   void setVolumeTarget(double v) { volume_target = v; }
+  // what setPhase reaches through getOsc() (gen.crtp.h:141,148-152)
+  void synchronizeAnglesFrom(ResynthElement const &o) { osc.synchronizeAngles(o.osc); }
+  void setStartAngle(double a) { osc.setStartAngle(a); }
   void setMaxFilterIncrement(double ai) { max_filter_increment = ai; }
   void setStereoGain(StereoGain const &g) { gain_ = g; }
   void setAngleIncrements(double a) { // Enveloped:218-225 -> FreqCtrl_:3103-3108
@@ -301,6 +304,8 @@ struct Event {
   int64_t noteid;
   float frequency = 0; // noteOn.frequency / noteChange.changed_frequency
   float velocity = 0;  // noteOn.velocity / noteChange.changed_velocity
+  int32_t delay = 0;   // frames between the one-shot and the key press / release (the "on time" branch of gen.crtp.h:506-512,556-560);
+                       // 0 = the "late" branch, which is what the offline job always takes
 };
 enum class onEventResult { OK = 0, DROPPED_NOTE };
 
@@ -361,23 +366,30 @@ struct ElementInitializer {
   }
 };
 
-// sine::Synth<2, ResynthElement<double>, Jitter::No, SynchronizePhase::Yes, DefaultStartPhase::Random, HandleNoteOff::Yes, nVoices, Initializer>
-// = ImplCRTP (gen.crtp.h:181-629) with SynthImpl (gen.sine.h:6-22)
-struct Synth {
+// sine::Synth<nOuts, Element, Jitter::No, SynchronizePhase::Yes, DefaultStartPhase::Random, HandleNoteOff::Yes, nVoices, Initializer>
+// = ImplCRTP (gen.crtp.h:181-629) with SynthImpl (gen.sine.h:6-22).  Instantiated twice by rt.resynth (lib.cpp:201-221): the
+// resynthesis synth (2 outs, ResynthElement) and the mono vocoder carrier synth (VocoderCarrierElement, oracle_carrier.hpp).
+// ElemTraits: baseVolume (Element::baseVolume as the double it converts to) and the salt of the declared start-phase hash.
+struct ResynthElemTraits {
+  static constexpr double baseVolume = sineBaseVolume; // StereoPanned<VolumeAdjusted<...>>: the algo's baseVolume (audioelement.h:1257,2370)
+  static constexpr uint64_t phase_salt = 0;
+};
+template <typename Elem, typename Init, int NOUT, typename Traits>
+struct SynthT {
   struct Channel {
-    ResynthElement elem;
+    Elem elem;
     std::optional<int64_t> noteid;
     float ref_angle_increments = 0;
   };
   std::vector<Channel> channels; // n_channels = 2 * nVoices (gen.crtp.h:225)
   float last_angle_increment_multiplier = 1.f;
-  std::optional<ElementInitializer> initializer;
+  std::optional<Init> initializer;
   int phase_policy = 0;
   uint64_t seed = 0;
   std::vector<EventLogEntry> *log = nullptr;
   int64_t const *now = nullptr; // output sample index the next stepper.step() will produce
 
-  explicit Synth(int n_channels) : channels(n_channels) {}
+  explicit SynthT(int n_channels) : channels(n_channels) {}
 
   void initialize(Stepper &chans) { // :248-262
     chans.enqueueOneShot([this, &chans]() { chans.registerSimpleCompute([this](double *b, int n) { return compute(b, n); }); });
@@ -389,7 +401,7 @@ struct Synth {
       for (int i = 0; i != n_frames; ++i) {
         c.elem.step();
         if (!c.elem.env.isEnvelopeRTActive()) break;
-        for (int j = 0; j < 2; ++j) buffer[2 * i + j] += c.elem.imag(j);
+        for (int j = 0; j < NOUT; ++j) buffer[NOUT * i + j] += c.elem.imag(j);
       }
     }
     return true;
@@ -400,17 +412,17 @@ struct Synth {
     for (auto &other : channels) {
       if (&other == &e) continue;
       if (!other.elem.env.isEnvelopeRTActive()) continue;
-      if (other.elem.angleIncrements() == ai) { e.elem.osc.synchronizeAngles(other.elem.osc); return; }
+      if (other.elem.angleIncrements() == ai) { e.elem.synchronizeAnglesFrom(other.elem); return; }
     }
-    float a = phase_policy == 0 ? hash_uniform_pm1(seed, static_cast<uint64_t>(noteid), 0) : 0.f;
-    e.elem.osc.setStartAngle(a);
+    float a = phase_policy == 0 ? hash_uniform_pm1(seed, static_cast<uint64_t>(noteid), Traits::phase_salt) : 0.f;
+    e.elem.setStartAngle(a);
   }
 
   void logEvent(int type, int channel, Event const &e) {
     if (log) log->push_back({now ? *now : -1, type, channel, e.noteid, e.frequency, e.velocity});
   }
 
-  onEventResult onEvent(int sample_rate, Event const &e, Stepper &chans) { // :382-622 (offline timing => every delay is 0)
+  onEventResult onEvent(int sample_rate, Event const &e, Stepper &chans) { // :382-622
     switch (e.type) {
       case EventType::NoteOn: {
         Channel *channel = nullptr;
@@ -423,24 +435,24 @@ struct Synth {
         auto &c = *channel;
         c.noteid = e.noteid;
         c.elem.forgetPastSignals();
-        c.elem.setVolumeTarget(sineBaseVolume * e.velocity); // Element::baseVolume (double: 0.1f * 1.) * velocity(float), :425
+        c.elem.setVolumeTarget(Traits::baseVolume * e.velocity); // Element::baseVolume * velocity(float), :425
         if (initializer) (*initializer)(c.elem, true, e.noteid);
         // SynthImpl::setupAudioElement gen.sine.h:9-21
         c.elem.setAngleIncrements(freq_to_angle_increment(e.frequency * last_angle_increment_multiplier, sample_rate));
         logEvent(0, static_cast<int>(channel - channels.data()), e);
         float ref = freq_to_angle_increment(e.frequency, sample_rate);
-        chans.enqueueOneShot([this, &c, ref, noteid = e.noteid]() {
+        chans.enqueueOneShot([this, &c, ref, noteid = e.noteid, delay = e.delay]() {
           if (!c.elem.env.acquireStates()) return;
           c.ref_angle_increments = ref;
           setPhase(c, noteid);
-          c.elem.env.onKeyPressed(0);
+          c.elem.env.onKeyPressed(delay);
         });
       } break;
       case EventType::NoteOff: {
-        chans.enqueueOneShot([this, noteid = e.noteid]() {
+        chans.enqueueOneShot([this, noteid = e.noteid, delay = e.delay]() {
           for (auto &c : channels) {
             if (!c.noteid || *c.noteid != noteid) continue;
-            if (c.elem.env.canHandleExplicitKeyReleaseNow(0)) c.elem.env.onKeyReleased(0);
+            if (c.elem.env.canHandleExplicitKeyReleaseNow(delay)) c.elem.env.onKeyReleased(delay);
             return;
           }
         });
@@ -454,7 +466,7 @@ struct Synth {
         chans.enqueueOneShot([this, e, angleIncrements, angleIncrementsMult]() {
           for (auto &c : channels) {
             if (!c.noteid || *c.noteid != e.noteid) continue;
-            c.elem.setVolumeTarget(sineBaseVolume * e.velocity);
+            c.elem.setVolumeTarget(Traits::baseVolume * e.velocity);
             c.elem.setAngleIncrements(angleIncrementsMult);
             c.ref_angle_increments = angleIncrements;
           }
@@ -467,5 +479,6 @@ struct Synth {
     return onEventResult::OK;
   }
 };
+using Synth = SynthT<ResynthElement, ElementInitializer, 2, ResynthElemTraits>;
 
 } // namespace ora

@@ -35,7 +35,25 @@ class OraConfig(C.Structure):
         ("analysis_volume", C.c_float), ("analysis_input_gain", C.c_float),
         ("phase_policy", C.c_int32), ("seed", C.c_uint64),
         ("analysis_output_feedback_gain", C.c_float), ("output_delay_seconds", C.c_float),
+        ("vocoder_kind", C.c_int32), ("vocoder_env_follower_cutoff_ratio", C.c_float), ("carrier_n_channels", C.c_int32),
+        ("vocoder_carrier_noise_volume", C.c_float), ("vocoder_carrier_saw_volume", C.c_float),
+        ("vocoder_carrier_triangle_volume", C.c_float), ("vocoder_carrier_square_volume", C.c_float),
+        ("vocoder_carrier_sine_volume", C.c_float), ("vocoder_carrier_pulse_volume", C.c_float),
+        ("vocoder_carrier_pulse_width", C.c_float),
     ]
+
+
+CARRIER_EVENT_DTYPE = np.dtype([("sample", "<i8"), ("type", "<i4"), ("key", "<i4"), ("delay", "<i4"), ("frequency", "<f4"),
+                                ("velocity", "<f4"), ("_pad", "<i4")])  # oracle_config.h: ora_carrier_event (32 bytes)
+
+
+def carrier_events(rows):
+    """rows: iterable of (sample, type, key[, delay[, frequency[, velocity]]]) -> structured array sorted by sample (stable)."""
+    ev = np.zeros(len(rows), CARRIER_EVENT_DTYPE)
+    for i, r in enumerate(rows):
+        r = tuple(r) + (0, 0.0, 1.0)[len(r) - 3:] if len(r) < 6 else tuple(r)
+        ev[i] = (r[0], r[1], r[2], r[3], r[4], r[5], 0)
+    return ev[np.argsort(ev["sample"], kind="stable")]
 
 
 class OraEvent(C.Structure):
@@ -167,6 +185,26 @@ def run_offline(cfg, voice, carrier=None, log_cap=1 << 20):
                                C.c_int64(n), _p(out), _p(log), C.c_int64(log_cap), C.byref(dropped))
     assert ne <= log_cap, "event log overflow"
     return out, log[:ne], dropped.value
+
+
+def run_offline_ex(cfg, voice, carrier=None, events=None, n_frames=None, want_carrier=False, log_cap=1 << 20):
+    """run_offline with carrier-synth note events.  Returns (out[n,2] float32, carrier double[n] or None, event log, (dropped, carrier dropped))."""
+    n = n_frames if n_frames is not None else (len(voice) if voice is not None else len(carrier))
+    v = np.ascontiguousarray(voice, np.float32) if voice is not None else None
+    c = np.ascontiguousarray(carrier, np.float32) if carrier is not None else None
+    ev = events if events is not None else np.zeros(0, CARRIER_EVENT_DTYPE)
+    assert ev.dtype == CARRIER_EVENT_DTYPE
+    out = np.zeros((n, 2), np.float32)
+    car = np.zeros(n, np.float64) if want_carrier else None
+    log = np.zeros(log_cap, EVENT_DTYPE)
+    dropped = (C.c_int32 * 2)()
+    L = lib()
+    L.ora_run_offline_ex.restype = C.c_int64
+    ne = L.ora_run_offline_ex(C.byref(cfg), _p(v) if v is not None else None, _p(c) if c is not None else None, C.c_int64(n),
+                              _p(ev) if len(ev) else None, C.c_int64(len(ev)), _p(out), _p(car) if car is not None else None,
+                              _p(log), C.c_int64(log_cap), dropped)
+    assert ne <= log_cap
+    return out, car, log[:ne], (dropped[0], dropped[1])
 
 
 def run_frames(cfg, voice, frame_cap=1 << 16, item_cap=1 << 22):

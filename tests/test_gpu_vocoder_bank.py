@@ -1,0 +1,226 @@
+"""GPU parity tests for SURVEY.md §8 f2: the band-pass bank vocoder (K7) and the vocoder carrier synth (K6) against the CPU oracle.
+
+Bars: the carrier's phase-controlled voices (saw / triangle / square / pulse) and the bank's vocoded signal are the same IEEE operation
+sequences on both sides -> equal bit for bit; the sine voice differs by libm ulps (sincos of the start angle / increment); the final
+float32 output within 1e-5 RMS per sample (BASELINE.json north_star).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RMS_TOL = 1e-5
+BASE = dict(analysis_volume=0.0, stereo_spread=0.0, seed=77, vocoder_count_bands=32, vocoder_min_freq=100.0, vocoder_max_freq=20000.0)
+
+
+@pytest.fixture(scope="module")
+def api():
+    from cpp_audio_amd import api
+    assert api.lib().ra_device_count() > 0, "no GPU visible: GPU tests cannot run (there is no CPU fallback)"
+    return api
+
+
+@pytest.fixture(scope="module")
+def sig():
+    from cpp_audio_amd import signals
+    return signals
+
+
+def rms(a, b):
+    return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
+
+
+def chord_events(n, stream, rng, n_notes=12, max_delay=0):
+    """(sample, stream, type, key, delay, frequency, velocity) rows: overlapping notes, repeated keys, note-offs in time order."""
+    rows = []
+    for _ in range(n_notes):
+        on = int(rng.integers(0, max(1, n - 2000)))
+        off = on + int(rng.integers(500, max(501, n // 2)))
+        key = int(rng.integers(36, 84))
+        d = int(rng.integers(0, max_delay + 1))
+        rows.append((on, stream, 0, key, d, 0.0, float(rng.uniform(0.2, 1.0))))
+        rows.append((off, stream, 1, key, int(rng.integers(0, max_delay + 1)), 0.0, 0.0))
+    # a key pressed twice before its first release: the note-off goes to the EARLIEST note-on (events.h:255-268)
+    rows.sort(key=lambda r: r[0])
+    # note-offs must follow their note-on: the generator above guarantees off > on per pair, and sorting keeps that
+    return rows
+
+
+def oracle_events(oracle, rows, stream):
+    return oracle.carrier_events([(r[0], r[2], r[3], r[4], r[5], r[6]) for r in rows if r[1] == stream])
+
+
+@pytest.mark.parametrize("bands,ratio", [(32, 1.0 / 20.0), (5, 0.2), (50, 0.05)])
+def test_bank_vocoder_matches_oracle(api, oracle, sig, bands, ratio):
+    n, S = 36000, 3
+    x = sig.make_streams(S, n, base_seed=4000 + bands)
+    car = np.stack([sig.carrier_stream(n, freq=110.0 * (s + 1), kind="saw" if s != 1 else "sine") for s in range(S)])
+    kw = dict(BASE, vocoder_kind=1, vocoder_count_bands=bands, vocoder_env_follower_cutoff_ratio=ratio, voice_volume=0.25, carrier_volume=0.125,
+              vocoder_volume=4.0)
+    with api.Context(api.default_config(**kw), S, 0) as ctx:
+        out = ctx.process_host(x, car)
+        assert ctx.stats().error_flags == 0
+    for s in range(S):
+        ref, _, _ = oracle.run_offline(oracle.default_config(**dict(kw, seed=77 + s)), x[s], car[s])
+        assert np.sqrt(np.mean(ref.astype(np.float64) ** 2)) > 1e-3
+        only_dry = 0.25 * x[s].astype(np.float64) + 0.125 * car[s]
+        assert rms(ref[:, 0], only_dry) > 1e-4, "the vocoded term is audible in the reference output: the test is not vacuous"
+        assert np.array_equal(out[s], ref), f"stream {s}: same operation sequence on both sides, rms {rms(out[s], ref):.3g}"
+
+
+def test_bank_vocoder_block_cut_invariance(api, sig):
+    n, S = 30000, 2
+    x = sig.make_streams(S, n, base_seed=5)
+    car = np.stack([sig.carrier_stream(n, freq=98.0), sig.carrier_stream(n, freq=131.0)])
+    kw = dict(BASE, vocoder_kind=1, voice_volume=0.0, carrier_volume=0.0, vocoder_volume=3.0)
+    with api.Context(api.default_config(**kw), S, 0) as ctx:
+        whole = ctx.process_host(x, car)
+    with api.Context(api.default_config(**kw), S, 0) as ctx:
+        parts, t = [], 0
+        for m in (7, 1, 64, 1000, 4097, 63, n):
+            m = min(m, n - t)
+            if m <= 0:
+                break
+            parts.append(ctx.process_host(x[:, t:t + m], car[:, t:t + m]))
+            t += m
+    assert t == n
+    assert np.array_equal(np.concatenate(parts, axis=1), whole)
+
+
+VOICES = dict(vocoder_carrier_saw_volume=0.3, vocoder_carrier_triangle_volume=0.2, vocoder_carrier_square_volume=0.25,
+              vocoder_carrier_sine_volume=0.0, vocoder_carrier_pulse_volume=0.4, vocoder_carrier_pulse_width=0.3)
+
+
+@pytest.mark.parametrize("case", ["phased", "all_voices", "few_channels", "delays", "envelope"])
+def test_carrier_synth_matches_oracle(api, oracle, case):
+    n, S = 40000, 3
+    kw = dict(BASE, carrier_n_channels=16, carrier_volume=1.0, voice_volume=0.0, vocoder_volume=0.0, **VOICES)
+    n_notes, max_delay = 12, 0
+    if case == "all_voices":
+        kw.update(vocoder_carrier_sine_volume=0.5)
+    elif case == "few_channels":
+        kw.update(carrier_n_channels=3)   # note-ons get dropped (onDroppedNote)
+        n_notes = 20
+    elif case == "delays":
+        max_delay = 300
+    elif case == "envelope":
+        kw.update(env_attack_seconds=0.01, env_hold_seconds=0.005, env_decay_seconds=0.02, env_release_seconds=0.03, env_sustain_level=0.6,
+                  vocoder_carrier_sine_volume=0.5)
+    rng = np.random.default_rng({"phased": 1, "all_voices": 2, "few_channels": 3, "delays": 4, "envelope": 5}[case])
+    rows = []
+    for s in range(S):
+        rows += chord_events(n, s, rng, n_notes=n_notes, max_delay=max_delay)
+    # the same key twice before its release, and two notes of equal frequency (phase synchronisation, gen.crtp.h:128-156)
+    rows += [(1000, 0, 0, 60, 0, 0.0, 0.9), (1500, 0, 0, 60, 0, 0.0, 0.5), (9000, 0, 1, 60, 0, 0.0, 0.0), (15000, 0, 1, 60, 0, 0.0, 0.0),
+             (2000, 1, 0, 200, 0, 440.0, 0.7), (2600, 1, 0, 201, 0, 440.0, 0.6), (20000, 1, 1, 200, 0, 0.0, 0.0), (21000, 1, 1, 201, 0, 0.0, 0.0)]
+    rows.sort(key=lambda r: (r[1], r[0]))
+    with api.Context(api.default_config(**kw), S, 0) as ctx:
+        ctx.carrier_events(rows)
+        out = ctx.process_host(None, None, n_frames=n)
+        cars = [ctx.carrier(n, s) for s in range(S)]
+        st = ctx.stats()
+    assert st.error_flags == 0
+    dropped = 0
+    for s in range(S):
+        ref, car, _, dr = oracle.run_offline_ex(oracle.default_config(**dict(kw, seed=77 + s)), None, None, oracle_events(oracle, rows, s), n_frames=n,
+                                                want_carrier=True)
+        dropped += dr[1]
+        assert np.sqrt(np.mean(car ** 2)) > 1e-2, "the oracle's carrier is silent: the test would be vacuous"
+        if kw["vocoder_carrier_sine_volume"] == 0.0:
+            assert np.array_equal(cars[s], car), f"stream {s}: max diff {np.max(np.abs(cars[s] - car)):.3g} at {np.argmax(np.abs(cars[s] - car))}"
+        else:
+            assert np.max(np.abs(cars[s] - car)) < 1e-11, f"stream {s}: {np.max(np.abs(cars[s] - car)):.3g}"
+        assert rms(out[s], ref) <= RMS_TOL
+    assert st.carrier_dropped_note_on == dropped
+    if case == "few_channels":
+        assert dropped > 0, "the case is meant to exhaust the channels"
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_carrier_synth_feeds_the_vocoder(api, oracle, sig, kind):
+    # BASELINE configs[2] wording: 32 bands, carrier from the synth ("gen.sine") — FFT vocoder (kind 0) and band-pass bank (kind 1)
+    n, S = 30000, 2
+    x = sig.make_streams(S, n, base_seed=99)
+    kw = dict(BASE, vocoder_kind=kind, carrier_n_channels=8, voice_volume=0.1, carrier_volume=0.05, vocoder_volume=2.0,
+              vocoder_carrier_square_volume=0.0, vocoder_carrier_sine_volume=0.6, vocoder_carrier_saw_volume=0.4)
+    rng = np.random.default_rng(3)
+    rows = []
+    for s in range(S):
+        rows += chord_events(n, s, rng, n_notes=6)
+    rows.sort(key=lambda r: (r[1], r[0]))
+    with api.Context(api.default_config(**kw), S, 0) as ctx:
+        ctx.carrier_events(rows)
+        out = ctx.process_host(x)
+        assert ctx.stats().error_flags == 0
+    for s in range(S):
+        ref, _, _, _ = oracle.run_offline_ex(oracle.default_config(**dict(kw, seed=77 + s)), x[s], None, oracle_events(oracle, rows, s))
+        assert np.sqrt(np.mean(ref.astype(np.float64) ** 2)) > 1e-3
+        assert rms(out[s], ref) <= RMS_TOL, f"stream {s}: {rms(out[s], ref):.3g}"
+
+
+def test_carrier_events_across_blocks(api, oracle):
+    # events queued ahead of time are applied by the block that contains them; results do not depend on the block cut
+    n = 24000
+    kw = dict(BASE, carrier_n_channels=8, carrier_volume=1.0, voice_volume=0.0, vocoder_volume=0.0, **VOICES)
+    rows = chord_events(n, 0, np.random.default_rng(11), n_notes=10, max_delay=50)
+    with api.Context(api.default_config(**kw), 1, 0) as ctx:
+        ctx.carrier_events(rows)
+        ctx.process_host(None, None, n_frames=n)
+        whole = ctx.carrier(n)
+    with api.Context(api.default_config(**kw), 1, 0) as ctx:
+        ctx.carrier_events(rows[:7])
+        parts, t = [], 0
+        for i, m in enumerate((5000, 1, 777, 8000, n)):
+            m = min(m, n - t)
+            if i == 2:
+                ctx.carrier_events([r for r in rows[7:]])  # later events may be queued between blocks
+            ctx.process_host(None, None, n_frames=m)
+            parts.append(ctx.carrier(m))
+            t += m
+            if t == n:
+                break
+    # rows[7:] all lie after frame 5001?  not necessarily: guard so that the test stays meaningful
+    if min(r[0] for r in rows[7:]) >= 5001:
+        assert np.array_equal(np.concatenate(parts), whole)
+
+
+def test_configs2_shape_256_streams_bank_and_carrier_synth(api, oracle, sig):
+    # configs[2] at reduced length: 256 streams, 32 bands, carrier synth; spot-check 4 streams against the oracle
+    n, S = 12000, 256
+    x = sig.make_streams(8, n, base_seed=321)
+    x = np.tile(x, (S // 8, 1)) * np.linspace(0.5, 1.0, S, dtype=np.float32)[:, None]
+    kw = dict(BASE, vocoder_kind=1, carrier_n_channels=16, voice_volume=0.0, carrier_volume=0.0, vocoder_volume=3.0,
+              vocoder_carrier_square_volume=0.0, vocoder_carrier_sine_volume=1.0)
+    rows = []
+    for s in range(S):
+        for j, key in enumerate((45 + s % 12, 52 + s % 7, 57 + s % 5, 64)):
+            rows.append((100 + 37 * j + s, s, 0, key, 0, 0.0, 0.8))
+            rows.append((9000 + 11 * j, s, 1, key, 0, 0.0, 0.0))
+    rows.sort(key=lambda r: (r[1], r[0]))
+    with api.Context(api.default_config(**kw), S, 0) as ctx:
+        ctx.carrier_events(rows)
+        out = ctx.process_host(x)
+        assert ctx.stats().error_flags == 0
+    for s in (0, 77, 128, 255):
+        ref, _, _, _ = oracle.run_offline_ex(oracle.default_config(**dict(kw, seed=77 + s)), x[s], None, oracle_events(oracle, rows, s))
+        assert np.sqrt(np.mean(ref.astype(np.float64) ** 2)) > 1e-4
+        assert rms(out[s], ref) <= RMS_TOL, f"stream {s}: {rms(out[s], ref):.3g}"
+
+
+def test_f2_argument_errors(api):
+    with pytest.raises(api.RaError) as e:
+        api.Context(api.default_config(**dict(BASE, carrier_n_channels=4, vocoder_carrier_noise_volume=0.1)), 1, 0)
+    assert e.value.code == -1 and "noise" in str(e.value)
+    with pytest.raises(api.RaError):
+        api.Context(api.default_config(**dict(BASE, vocoder_kind=7)), 1, 0)
+    with api.Context(api.default_config(**dict(BASE, carrier_n_channels=4, carrier_volume=1.0)), 2, 0) as ctx:
+        for bad in ([(0, 2, 0, 60)], [(0, 0, 5, 60)], [(0, 0, 1, 60)], [(10, 0, 0, 60), (5, 0, 0, 61)], [(0, 0, 0, 60, 0, 0.0, 0.0)]):
+            with pytest.raises(api.RaError) as e:
+                ctx.carrier_events(bad)
+            assert e.value.code == -1
+        ctx.process_host(None, None, n_frames=100)
+        with pytest.raises(api.RaError):
+            ctx.carrier_events([(50, 1, 0, 60)])  # frame 50 has been processed
+    with api.Context(api.default_config(**BASE), 1, 0) as ctx:  # no carrier synth
+        with pytest.raises(api.RaError):
+            ctx.carrier_events([(0, 0, 0, 60)])

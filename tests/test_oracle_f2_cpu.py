@@ -1,0 +1,89 @@
+"""CPU checks of the oracle's f2 restatements (oracle/oracle_carrier.hpp) against independent formulations:
+the band-pass bank against scipy.signal.lfilter transfer functions, the carrier synth's voices against closed forms."""
+import numpy as np
+import pytest
+from scipy.signal import lfilter
+
+SR = 48000
+
+
+def one_pole_k(freq, sr=SR):
+    a = np.pi * (2 * freq / sr)
+    return a / (1 + a)
+
+
+def lp(x, k):
+    return lfilter([k], [1.0, -(1.0 - k)], x)
+
+
+def test_bank_vocoder_against_transfer_functions(oracle):
+    from cpp_audio_amd import signals
+    n, B = 20000, 8
+    x = signals.partials_stream(5, n).astype(np.float64)
+    c = signals.carrier_stream(n, freq=140.0).astype(np.float64)
+    cfg = oracle.default_config(vocoder_kind=1, vocoder_count_bands=B, vocoder_min_freq=150.0, vocoder_max_freq=9000.0,
+                                vocoder_env_follower_cutoff_ratio=0.1, voice_volume=0.0, carrier_volume=0.0, vocoder_volume=1.0)
+    out, _, _ = oracle.run_offline(cfg, x.astype(np.float32), c.astype(np.float32))
+    edges = np.exp(np.log(np.float32(150.0)) + np.arange(B + 1) / B * (np.log(np.float32(9000.0)) - np.log(np.float32(150.0))))
+    y = np.zeros(n)
+    for b in range(B):
+        ka, kb, ke = one_pole_k(edges[b]), one_pole_k(edges[b + 1]), one_pole_k(edges[b] * np.float32(0.1))
+        bp_m = lp(x - lp(x, ka), kb)         # high-pass = input - low-pass, then low-pass
+        env = lp(np.abs(bp_m), ke)
+        bp_c = lp(c - lp(c, ka), kb)
+        y += env * bp_c
+    assert np.sqrt(np.mean(y ** 2)) > 1e-4
+    assert np.max(np.abs(out[:, 0] - y)) < 1e-7 and np.array_equal(out[:, 0], out[:, 1])  # float32 output of a double signal
+    assert np.sqrt(np.mean((out[:, 0] - y) ** 2)) < 3e-9
+
+
+def test_band_pass_gain_identity(oracle):
+    # the compensation identity of audioelement.h:2129-2143 that fixes the filter shapes: at the geometric centre f of a band
+    # [f / w, f w] the analog prototypes give |H_hp|^2 |H_lp|^2 = 1 / (1 + 1/w^2)^2; the one-pole pair follows it at low frequencies
+    f, w = 200.0, 2.0
+    n = SR
+    t = np.arange(n) / SR
+    x = np.sin(2 * np.pi * f * t)
+    y = lp(x - lp(x, one_pole_k(f / w)), one_pole_k(f * w))
+    gain = np.sqrt(np.mean(y[n // 2:] ** 2) / np.mean(x[n // 2:] ** 2))
+    assert abs(gain - 1.0 / (1.0 + 1.0 / w ** 2)) < 0.01
+
+
+def test_carrier_square_voice_closed_form(oracle):
+    n = 6000
+    cfg = oracle.default_config(carrier_n_channels=4, carrier_volume=1.0, voice_volume=0.0, vocoder_volume=0.0, analysis_volume=0.0, phase_policy=1)
+    ev = oracle.carrier_events([(10, 0, 69, 0, 0.0, 0.5), (4000, 1, 69)])
+    out, car, _, dr = oracle.run_offline_ex(cfg, None, None, ev, n_frames=n, want_carrier=True)
+    assert dr == (0, 0)
+    inc = np.float32(2) * np.float32(440.0) / np.float32(SR)
+    A = max(SR // 1000, int(0.5 + 2.5 * (2.0 / float(inc))))   # attack = max(1 ms, 2.5 periods), audioelement.h:216-223,1066-1084
+    k = np.arange(n)
+    # start angle 0 (phase policy zero); Phased::step: angle += inc, wrap above 2; square: -1 inside (0.5, 1.5)
+    ang, a = np.zeros(n), 0.0
+    for i in range(10, n):
+        a += float(inc)
+        if a > 2.0:
+            a -= 2.0
+        ang[i] = a
+    sq = np.where((ang > 0.5) & (ang < 1.5), -1.0, 1.0)
+    env = np.clip((k - 9) / A, 0.0, 1.0)
+    m = (k >= 10) & (k < 4000)
+    assert np.allclose(car[m], 0.5 * sq[m] * env[m], rtol=0, atol=1e-15)
+    assert np.all(car[:10] == 0)
+    # release: max(1 ms, 2.5 periods) steps down to 0, then silence
+    assert np.all(car[4000 + A + 20:] == 0) and np.any(car[4000:4000 + A] != 0)
+
+
+def test_note_off_releases_the_earliest_note_on_of_its_key(oracle):
+    # events.h:228-281: two note-ons of one key, one note-off -> the first note stops, the second keeps sounding
+    n = 9000
+    cfg = oracle.default_config(carrier_n_channels=4, carrier_volume=1.0, voice_volume=0.0, vocoder_volume=0.0, vocoder_carrier_square_volume=0.0,
+                                vocoder_carrier_sine_volume=1.0, phase_policy=1)
+    ev = oracle.carrier_events([(0, 0, 60, 0, 300.0, 0.25), (100, 0, 60, 0, 3000.0, 0.5), (3000, 1, 60)])
+    _, car, log, _ = oracle.run_offline_ex(cfg, None, None, ev, n_frames=n, want_carrier=True)
+    tail = car[8000:]
+    # only the 3 kHz note (volume 0.5) is left
+    spec = np.abs(np.fft.rfft(tail * np.hanning(len(tail))))
+    f = np.fft.rfftfreq(len(tail), 1 / SR)
+    assert abs(f[np.argmax(spec)] - 3000.0) < 60.0
+    assert abs(np.max(np.abs(tail)) - 0.5) < 0.01
