@@ -4,14 +4,25 @@
 One "step" = one pass of the whole hot path (analysis + tracking + sine-bank synthesis) over one batch of
 synthetic input: BASELINE.json configs[1] = 256 mono streams x 10 s @ 48 kHz, 4096-pt window, 75 % overlap
 (H = 1024), 64 partials.  Consecutive steps continue the same streams (steady state, SURVEY.md §8d);
-inputs are resident in HBM before the timed region.  N > 1: every rank runs its own 256 streams on its own
-GPU (streams are independent: no collective on the data path), value = all ranks' frames / max-over-ranks time.
+inputs are resident in HBM before the timed region.  N > 1: every rank runs its own streams on its own
+GPU (streams are independent: no collective on the data path; the barrier and the max-over-ranks of the
+timing go over gloo on CPU tensors), value = all ranks' frames / max-over-ranks time.
 
     python bench.py --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+The JSON line also carries, outside the timed region of the headline (N = 1 only):
+  kernels        per kernel: summed launch time per step while the stages overlap (`overlapped_ms`) and with the chip to
+                 itself (`alone_ms`: one extra step with ra_set_pipeline_serial), launches per step, achieved algorithmic GB/s
+  roofline       for the kernel with the largest alone_ms (derived, not asserted)
+  other_configs  configs[2] (FFT vocoder; band-pass bank fed by the carrier synth), configs[3] and configs[1] with
+                 stereo_spread = 1 at BASELINE size: ms_per_step, frames/s, per-kernel ms, error flags
+  cpu_baseline   the oracle on the host cores over a bounded sample, with a parity spot check at bench size
 """
 import argparse
+import hashlib
 import json
+import math
 import os
 import sys
 import time
@@ -27,12 +38,24 @@ FP64_VALU_PEAK_TFLOPS = 78.6   # nominal vector fp64
 # the 1024 SIMDs issue at most 614 G wave-instructions / s.  scripts/ubench/fp64_rate.hip measures 2.3 - 2.4 ns per instruction
 # and SIMD with >= 2 waves resident (~70 % of nominal) and 4.4 ns with one wave.
 VALU_PEAK_GINST = 1024 * 2.4 / 4.0
+SR = 48000
+STAGES = ("analysis", "track", "vocoder", "propagate", "render", "history")
 
 
 def algo_flops_per_frame(N, H, P):
     """FFT 5 N log2 N / H + window/|X|^2/peaks 12 N / H + sine bank 30 P."""
-    import math
     return 5.0 * N * math.log2(N) / H + 12.0 * N / H + 30.0 * P
+
+
+def csrc_sha256():
+    """Hash of the kernel sources the loaded library was built from: PMC counters are only quoted for the build they were taken on."""
+    d = os.path.join(ROOT, "cpp_audio_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".cuh", ".h")) or f == "Makefile":
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def host_cores():
@@ -55,26 +78,31 @@ def host_cores():
     return int(env) if env else cores
 
 
-def measured_counters(kernel, S, n, N, H, P):
-    """Per-step PMC sums of `kernel` from the committed rocprofv3 passes (profiles/r*/traffic.json: separate --pmc runs of FETCH_SIZE,
-    WRITE_SIZE and SQ_INSTS_VALU) — PMC counters cannot be read from inside this process.  None unless a profile of exactly
-    this workload shape exists."""
+def measured_counters(S, n, N, H, P):
+    """Per-step PMC sums from the committed rocprofv3 passes (profiles/r*/traffic.json: separate --pmc runs of FETCH_SIZE, WRITE_SIZE
+    and SQ_INSTS_VALU) — PMC counters cannot be read from inside this process.  Only a profile of exactly this workload shape taken on
+    exactly this build of the kernels (csrc_sha256) counts; anything else returns (None, why)."""
     import glob
+    here = csrc_sha256()
+    why = "no profiles/r*/traffic.json"
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
         try:
             doc = json.load(open(path))
             w = doc["workload"]
             if (w["streams"], w["frames_per_stream"], w["window"], w["stride"], w["partials"]) != (S, n, N, H, P):
+                why = f"{os.path.relpath(path, ROOT)} is for another workload shape"
                 continue
-            return doc["kernels"][kernel], os.path.relpath(path, ROOT)
+            if doc.get("csrc_sha256") != here:
+                why = f"{os.path.relpath(path, ROOT)} was collected on another build (csrc_sha256 {doc.get('csrc_sha256')} != {here})"
+                continue
+            return doc, os.path.relpath(path, ROOT)
         except Exception:
             continue
-    return None, None
+    return None, why
 
 
 def synth_inputs_torch(n_streams, n_frames, sr, seed, device):
     """Seeded synthetic streams of the SURVEY.md §8(d) recipe, generated on the GPU (float32, peak 0.5)."""
-    import math
     import torch
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)
@@ -108,17 +136,124 @@ def synth_inputs_torch(n_streams, n_frames, sr, seed, device):
     return x.to(torch.float32).contiguous()
 
 
+def carrier_saw_torch(S, n, sr, device):
+    """configs[2] carrier from a file: 110 Hz saw (1 % detune per stream), amplitude 0.5."""
+    import torch
+    t = torch.arange(n, dtype=torch.float64, device=device) / sr
+    f = 110.0 * (1.0 + 0.01 * torch.arange(S, dtype=torch.float64, device=device)).unsqueeze(1)
+    return (0.5 * (2.0 * torch.remainder(f * t, 1.0) - 1.0)).to(torch.float32).contiguous()
+
+
+def carrier_chords(S, n_steps_total, n):
+    """configs[2] carrier from the carrier synth: per stream a four-note chord struck anew every second and released 0.8 s later."""
+    rows = []
+    for s in range(S):
+        keys = (45 + s % 12, 52 + s % 7, 57 + s % 5, 64 + s % 3)
+        t = 0
+        while t < n_steps_total * n:
+            for j, k in enumerate(keys):
+                rows.append((t + 97 * j, s, 0, k, 0, 0.0, 0.8))
+            for j, k in enumerate(keys):
+                rows.append((t + int(0.8 * SR) + 11 * j, s, 1, k, 0, 0.0, 0.0))
+            t += SR
+    return rows
+
+
+class Runner:
+    """One context on one GPU, its inputs resident in HBM; step() issues one block the way an offline job does."""
+
+    def __init__(self, api, torch, dev, local_rank, cfg_kw, S, n, seed, carrier=None, stream_ordered=False, total_steps=0):
+        self.api, self.torch, self.S, self.n = api, torch, S, n
+        self.voice = synth_inputs_torch(S, n, SR, seed, dev)
+        self.carrier = carrier_saw_torch(S, n, SR, dev) if carrier == "wav" else None
+        self.out = torch.empty(S, n, 2, dtype=torch.float32, device=dev)
+        self.cfg = api.default_config(sample_rate=SR, **cfg_kw)
+        self.ctx = api.Context(self.cfg, S, local_rank)
+        self.ctx.set_hip_stream(torch.cuda.current_stream().cuda_stream)
+        self.stream_ordered = stream_ordered
+        self.chords = carrier == "synth"
+        self.total_steps = total_steps
+        # set-up, not a step: a 2 s block makes HIP load the code objects and creates the context's internal streams and events, then
+        # the streams are put back to their initial state; the per-block scratch (GBs) is still allocated by the first warm-up step
+        self.ctx.process_device(self.voice.data_ptr(), self.carrier.data_ptr() if self.carrier is not None else 0, min(n, 2 * SR), self.out.data_ptr())
+        self.ctx.synchronize()
+        self.ctx.reset()
+        if self.chords:
+            self.ctx.carrier_events(carrier_chords(S, total_steps, n))
+
+    # Steps are consecutive blocks of the same streams, issued like an offline job issues them (ra_process_device_async): the caller's
+    # stream is not made to wait between blocks, so block k + 1's analysis and tracking overlap block k's rendering; every block still
+    # does all of its work inside the timed region, which ends with a join + device synchronisation.
+    def step(self):
+        self.ctx.process_device(self.voice.data_ptr(), self.carrier.data_ptr() if self.carrier is not None else 0, self.n, self.out.data_ptr(),
+                                overlap=not self.stream_ordered)
+
+    def finish(self):
+        self.ctx.join()
+
+    def kernel_split(self, steps):
+        """(ms per step, launches per step) per stage over `steps` further steps, HIP events on the launch streams."""
+        self.ctx.set_profiling(True)
+        for _ in range(steps):
+            self.step()
+        self.ctx.join()
+        self.ctx.synchronize()
+        kms, calls = self.ctx.kernel_ms()
+        launches = self.ctx.kernel_launches()
+        self.ctx.set_profiling(False)
+        calls = max(calls, 1)
+        return {k: kms[k] / calls for k in STAGES}, {k: launches[k] / calls for k in STAGES}
+
+    def close(self):
+        self.ctx.close()
+        del self.voice, self.out, self.carrier
+        self.torch.cuda.empty_cache()
+
+
+def time_config(api, torch, dev, name, cfg_kw, S, seconds, steps, carrier=None):
+    """An `other_configs` entry: full-size timing of another BASELINE config (same issue mode and clock as the headline)."""
+    n = int(round(seconds * SR))
+    warm = 2
+    r = Runner(api, torch, dev, 0, cfg_kw, S, n, 4321, carrier=carrier, total_steps=warm + steps + 3)
+    for _ in range(warm):
+        r.step()
+    r.finish()
+    r.ctx.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r.step()
+    r.finish()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    r.ctx.synchronize()
+    over, launches = r.kernel_split(2)
+    r.ctx.set_pipeline_serial(True)
+    alone, _ = r.kernel_split(1)
+    r.ctx.set_pipeline_serial(False)
+    st = r.ctx.stats()
+    res = {"config": name, "streams": S, "seconds_per_step": seconds, "steps": steps, "ms_per_step": dt * 1e3, "frames_per_s": S * n / dt,
+           "x_realtime_per_stream": n / SR / dt,
+           "kernel_ms_per_step": {"overlapped": {k: round(v, 3) for k, v in over.items()}, "alone": {k: round(v, 3) for k, v in alone.items()}},
+           "kernel_launches_per_step": launches, "error_flags": int(st.error_flags), "dropped_note_on": int(st.dropped_note_on),
+           "carrier_dropped_note_on": int(st.carrier_dropped_note_on), "out_rms": float(r.out.double().pow(2).mean().sqrt().item())}
+    r.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--streams", type=int, default=256, help="streams per GPU (configs[1]: 256)")
+    ap.add_argument("--streams-total", type=int, default=0, help="total streams, sharded over the ranks (configs[4]: 8000 over 8 GPUs); overrides --streams")
     ap.add_argument("--seconds", type=float, default=10.0, help="audio seconds per stream per step")
     ap.add_argument("--window", type=int, default=4096)
     ap.add_argument("--stride", type=int, default=1024)
     ap.add_argument("--partials", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="only the headline (profiling runs)")
     ap.add_argument("--stream-ordered", action="store_true", help="issue every block with ra_process_device (no overlap between consecutive blocks)")
     ap.add_argument("--cpu-streams", type=int, default=0, help="streams in the CPU baseline sample (0 = all)")
     args = ap.parse_args()
@@ -137,105 +272,124 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        # the data path has no collective (north_star: "no RCCL needed"): the only exchanges are the barriers around the timed region
+        # and the max of one scalar, on CPU tensors
+        dist.init_process_group("gloo")
 
-    from cpp_audio_amd import api
+    from cpp_audio_amd import api, sharding
 
-    sr = 48000
-    S, n = args.streams, int(round(args.seconds * sr))
+    if args.streams_total:
+        lo, hi = sharding.shard_streams(args.streams_total, world, rank)
+        S, first_stream = hi - lo, lo
+    else:
+        S, first_stream = args.streams, rank * args.streams
+    n = int(round(args.seconds * SR))
     N, H, P = args.window, args.stride, args.partials
-    voice = synth_inputs_torch(S, n, sr, 1234 + 100003 * rank, dev)
-    out = torch.empty(S, n, 2, dtype=torch.float32, device=dev)
-    cfg = api.default_config(sample_rate=sr, window_size=N, stride=H, n_channels=P, analysis_volume=1.0, stereo_spread=0.0,
-                             carrier_volume=0.0, seed=1234 + 100003 * rank)
-    ctx = api.Context(cfg, S, local_rank)
-    ctx.set_hip_stream(torch.cuda.current_stream().cuda_stream)
-    # set-up, not a step: a 2 s block makes HIP load the code objects and creates the context's internal streams and events, then the
-    # streams are put back to their initial state; the per-block scratch (GBs) is still allocated by the first warm-up step
-    ctx.process_device(voice.data_ptr(), 0, min(n, 2 * sr), out.data_ptr())
-    ctx.synchronize()
-    ctx.reset()
+    head_kw = dict(window_size=N, stride=H, n_channels=P, analysis_volume=1.0, stereo_spread=0.0, carrier_volume=0.0, seed=1234 + first_stream)
+    run = Runner(api, torch, dev, local_rank, head_kw, S, n, 1234 + 100003 * rank, stream_ordered=args.stream_ordered)
+    ctx, voice, out = run.ctx, run.voice, run.out
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Steps are consecutive blocks of the same streams.  They are issued like an offline job issues them (ra_process_device_async): the
-    # caller's stream is not made to wait between blocks, so block k + 1's analysis and tracking overlap block k's rendering; every block
-    # still does all of its work inside the timed region, which ends with a join + device synchronisation.  --stream-ordered issues each
-    # block with ra_process_device instead (the stream waits for every block: nothing of block k + 1 starts before block k is done).
-    def step():
-        ctx.process_device(voice.data_ptr(), 0, n, out.data_ptr(), overlap=not args.stream_ordered)
-
     for _ in range(args.warmup):
-        step()
-    ctx.join()
+        run.step()
+    run.finish()
     ctx.synchronize()
     ctx.set_profiling(True)   # HIP events on the launch stream around every kernel (ra_set_profiling)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-    ctx.join()
+        run.step()
+    run.finish()
     barrier()
     dt = time.perf_counter() - t0
     ctx.synchronize()         # raises on device-side error flags
     kms, calls = ctx.kernel_ms()
-    ctx_launches = ctx.kernel_launches()
+    launches = ctx.kernel_launches()
     ctx.set_profiling(False)
     st = ctx.stats()
+    total_streams = S
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        tt = torch.tensor([dt, float(S)], dtype=torch.float64)
+        mx = tt.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        dt, total_streams = float(mx[0].item()), int(round(tt[1].item()))
 
     out_rms = float(out.double().pow(2).mean().sqrt().item())
     frames_per_step_gpu = S * n
-    total_frames = frames_per_step_gpu * args.steps * world
-    value = total_frames / dt
+    value = total_streams * n * args.steps / dt
+    ms_per_step = dt / args.steps * 1e3
 
     result = None
     if rank == 0:
-        launches = ctx_launches
-        synth_ms = (kms["propagate"] + kms["render"]) / max(calls, 1)
-        # the sine-bank renderer carries ~75 % of the path's VALU work; the analysis launches overlap it and their
-        # event-to-event time is mostly waiting for CU slots, so "largest summed duration" would not name the kernel that bounds the step
-        dom = "render" if kms["render"] > 0 else max(kms, key=kms.get)
-        dom_launches = max(launches[dom], 1)
-        dom_ms = kms[dom] / dom_launches                       # average duration of ONE launch (HIP events on its stream)
-        launches_per_step = dom_launches / max(calls, 1)
-        algo_bytes = ALGO_BYTES_PER_FRAME * frames_per_step_gpu / launches_per_step   # a launch covers 1 / launches_per_step of the block
-        achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        calls = max(calls, 1)
+        over_ms = {k: kms[k] / calls for k in STAGES}
+        lps = {k: launches[k] / calls for k in STAGES}
+        # every kernel with the chip to itself: one more step, its stages serialised on one stream (outside the timed region)
+        ctx.set_pipeline_serial(True)
+        alone_ms, _ = run.kernel_split(1)
+        ctx.set_pipeline_serial(False)
+        mono = head_kw["stereo_spread"] == 0.0
+        KNAME = {"analysis": "ra_analysis_kernel", "track": "ra_track_kernel", "vocoder": "ra_voc_*_kernel", "propagate": "ra_synth_propagate_kernel",
+                 "render": "ra_synth_render_mono_kernel" if mono else "ra_synth_render_kernel", "history": "ra_roll_history_kernel"}
         flops = algo_flops_per_frame(N, H, P)
-        KNAME = {"analysis": "ra_analysis_kernel", "track": "ra_track_kernel", "vocoder": "ra_voc_*_kernel",
-                 "propagate": "ra_synth_propagate_kernel", "render": "ra_synth_render_mono_kernel", "history": "ra_roll_history_kernel"}
-        pmc, pmc_src = measured_counters(KNAME[dom], S, n, N, H, P)
-        traffic = (2.0 * pmc["FETCH_SIZE_KB"] + pmc["WRITE_SIZE_KB"]) * 1024.0 / pmc.get("launches", 1) if pmc else None
+        pmc_doc, pmc_src = measured_counters(S, n, N, H, P)
+        kernels = {}
+        for k in STAGES:
+            if lps[k] == 0:
+                continue
+            per_launch_alone = alone_ms[k] / lps[k]
+            per_launch_over = over_ms[k] / lps[k]
+            algo_bytes = ALGO_BYTES_PER_FRAME * frames_per_step_gpu / lps[k]   # a launch covers 1 / launches_per_step of the block
+            e = {"kernel": KNAME[k], "launches_per_step": lps[k], "alone_ms_per_step": alone_ms[k], "overlapped_ms_per_step": over_ms[k],
+                 "alone_ms_per_launch": per_launch_alone, "overlapped_ms_per_launch": per_launch_over,
+                 "algorithmic_GBs_alone": algo_bytes / (per_launch_alone * 1e-3) / 1e9 if per_launch_alone > 0 else None}
+            c = pmc_doc["kernels"].get(KNAME[k]) if pmc_doc else None
+            if c:
+                e["hbm_bytes_per_launch"] = (2.0 * c["FETCH_SIZE_KB"] + c["WRITE_SIZE_KB"]) * 1024.0 / c.get("launches", 1)
+                if "SQ_INSTS_VALU" in c and alone_ms[k] > 0:
+                    e["valu_insts_per_step"] = c["SQ_INSTS_VALU"]
+                    e["issue_frac_alone"] = c["SQ_INSTS_VALU"] / (alone_ms[k] * 1e-3) / 1e9 / VALU_PEAK_GINST
+            kernels[k] = e
+        # the dominant kernel is derived: the one that needs the chip longest when it has it to itself
+        dom = max((k for k in kernels if k != "history"), key=lambda k: kernels[k]["alone_ms_per_step"])
+        d = kernels[dom]
+        dom_ms = d["overlapped_ms_per_launch"]          # HIP events over the timed region, on the stream the kernel is launched on
+        algo_bytes = ALGO_BYTES_PER_FRAME * frames_per_step_gpu / d["launches_per_step"]
+        achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        total_valu = sum(c.get("SQ_INSTS_VALU", 0.0) for c in pmc_doc["kernels"].values()) if pmc_doc else None
         valu = {"algorithmic_flop_per_frame": flops,
-                "achieved_tflops_fp64": flops * frames_per_step_gpu / (synth_ms * 1e-3 + 1e-30) / 1e12 if synth_ms > 0 else None,
-                "peak_tflops_fp64_vector": FP64_VALU_PEAK_TFLOPS}
-        if pmc and "SQ_INSTS_VALU" in pmc:  # issue-slot view of the same kernel: wave-instructions / s against 1 per 4 cycles per SIMD
-            ginst = pmc["SQ_INSTS_VALU"] / (kms[dom] / max(calls, 1) * 1e-3) / 1e9
-            valu.update({"kernel": KNAME[dom], "valu_insts_per_step": pmc["SQ_INSTS_VALU"], "valu_insts_per_frame_channel":
-                         pmc["SQ_INSTS_VALU"] * 64.0 / (frames_per_step_gpu * P), "issue_rate_ginst_s": ginst,
-                         "peak_issue_rate_ginst_s": VALU_PEAK_GINST, "issue_frac": ginst / VALU_PEAK_GINST, "counters_from": pmc_src})
+                "achieved_tflops_fp64": flops * frames_per_step_gpu / (ms_per_step * 1e-3) / 1e12,   # whole-step flops / step time
+                "frac_of_peak_fp64_vector": flops * frames_per_step_gpu / (ms_per_step * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                "peak_tflops_fp64_vector": FP64_VALU_PEAK_TFLOPS, "peak_issue_rate_ginst_s": VALU_PEAK_GINST}
+        if total_valu:
+            valu.update({"valu_insts_per_step_all_kernels": total_valu, "step_issue_frac": total_valu / (ms_per_step * 1e-3) / 1e9 / VALU_PEAK_GINST,
+                         "render_valu_insts_per_channel_sample": pmc_doc["kernels"].get(KNAME["render"], {}).get("SQ_INSTS_VALU", 0.0) * 64.0 / (frames_per_step_gpu * P),
+                         "counters_from": pmc_src})
+        else:
+            valu["counters"] = f"null: {pmc_src}"
         result = {
             "metric": "audio frames/sec (48 kHz, 4096-pt FFT, 64 partials) per GPU; CPU ref x",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if not args.streams_total else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic", "issue": "stream-ordered" if args.stream_ordered else "overlapped blocks (ra_process_device_async)",
             "config": {"workload": f"configs[1]: {S} mono streams/GPU x {args.seconds:g} s @ 48 kHz, window {N} (Gaussian 4 sigma) / FFT {N}, "
                                    f"stride {H} (75% overlap), {P} partials, analysis_volume 1, stereo_spread 0, post none",
-                       "streams_per_gpu": S, "frames_per_stream_per_step": n, "sharding": f"streams x{world}, no collective"},
-            "x_realtime_per_stream": value / (sr * S * world),
+                       "streams_per_gpu": S, "streams_total": total_streams, "frames_per_stream_per_step": n, "sharding": f"streams x{world}, no collective"},
+            "x_realtime_per_stream": value / (SR * total_streams),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": KNAME[dom],
-                         "kernel_ms_per_launch": dom_ms, "launches_per_step": launches_per_step, "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "the path is fp64-VALU issue bound, not HBM bound (SURVEY.md §8d): see valu.issue_frac"},
+                         "traffic": d.get("hbm_bytes_per_launch"), "kernel": d["kernel"],
+                         "kernel_selected_by": "largest alone_ms_per_step among kernels{} (each stage serialised on one stream, one extra step)",
+                         "kernel_ms_per_launch": dom_ms, "launches_per_step": d["launches_per_step"], "algorithmic_bytes_per_launch": algo_bytes,
+                         "traffic_source": pmc_src if pmc_doc else f"null: {pmc_src}",
+                         "note": "the path is fp64-VALU issue bound, not HBM bound (SURVEY.md §8d): see valu and kernels{}.issue_frac_alone"},
             "valu": valu,
-            "kernel_ms_per_step": {k: v / max(calls, 1) for k, v in kms.items()},
-            "kernel_launches_per_step": {k: v / max(calls, 1) for k, v in launches.items()},
+            "kernels": kernels,
+            "csrc_sha256": csrc_sha256(),
             "checks": {"out_rms": out_rms, "dropped_note_on": int(st.dropped_note_on), "error_flags": int(st.error_flags)},
         }
 
@@ -247,9 +401,9 @@ def main():
         cs = args.cpu_streams or S   # the oracle is fast enough to take the whole batch (~10 s of CPU work on 16 cores)
         cn = n
         hv = voice[:cs, :cn].cpu().numpy()
-        ocfg = oracle_lib.default_config(sample_rate=sr, window_size=N, stride=H, n_channels=P, analysis_volume=1.0, stereo_spread=0.0,
-                                         carrier_volume=0.0, seed=1234)
-        oracle_lib.run_offline_batch(ocfg, hv[:1, :sr], n_threads=1)  # page in
+        okw = {k: v for k, v in head_kw.items()}
+        ocfg = oracle_lib.default_config(sample_rate=SR, **okw)
+        oracle_lib.run_offline_batch(ocfg, hv[:1, :SR], n_threads=1)  # page in
         t1 = time.perf_counter()
         ref = oracle_lib.run_offline_batch(ocfg, hv, n_threads=cores)
         cdt = time.perf_counter() - t1
@@ -257,18 +411,40 @@ def main():
         oracle_lib.run_offline_batch(ocfg, hv[:1], n_threads=1)
         cdt1 = time.perf_counter() - t1
         # the same sample through the GPU path, from a fresh context, as a parity spot check at bench size
-        with api.Context(cfg, cs, local_rank) as c2:
+        with api.Context(run.cfg, cs, local_rank) as c2:
             got = c2.process_host(hv)
         err = np.sqrt(np.mean((got.astype(np.float64) - ref) ** 2, axis=(1, 2)))
         result["cpu_baseline"] = {"value": cs * cn / cdt, "unit": "frames/s", "cores": cores, "kind": "port",
-                                  "sample": f"{cs} of the {S} streams x {cn / sr:g} s, oracle (g++ -O2, double), one std::thread per core",
+                                  "sample": f"{cs} of the {S} streams x {cn / SR:g} s, oracle (g++ -O2, double), one std::thread per core",
                                   "single_core_frames_per_s": cn / cdt1, "seconds": cdt,
                                   "gpu_vs_oracle_max_rms": float(err.max())}
         result["gpu_over_cpu"] = value / (cs * cn / cdt)
+        del ref, got, hv
+
+    run.close()
+    # the other BASELINE configs at full size, under the same clock (N = 1 only; not part of `value`)
+    if rank == 0 and world == 1 and not args.no_other_configs:
+        parity = dict(analysis_volume=1.0, stereo_spread=0.0, carrier_volume=0.0, seed=1234)
+        voc = dict(parity, analysis_volume=0.0, voice_volume=0.0, carrier_volume=0.0, vocoder_volume=1.0, vocoder_count_bands=32, vocoder_min_freq=100.0,
+                   vocoder_max_freq=20000.0, vocoder_modulator_window_size_seconds=0.10, vocoder_stride_seconds=0.005)
+        others = []
+        try:
+            others.append(time_config(api, torch, dev, "configs[1] with stereo_spread = 1 (the reference default): 256 streams, N 4096, H 1024, P 64",
+                                      dict(parity, window_size=N, stride=H, n_channels=P, stereo_spread=1.0), 256, 10.0, 3))
+            others.append(time_config(api, torch, dev, "configs[2] FFT vocoder: 256 streams, 32 bands, S = 241, modulator FFT 8192, carrier FFT 512, carrier from a file",
+                                      voc, 256, 10.0, 3, carrier="wav"))
+            others.append(time_config(api, torch, dev, "configs[2] band-pass bank (vocoder_kind 1): 256 streams, 32 bands, carrier from the carrier synth (sine + saw voices, 16 channels)",
+                                      dict(voc, vocoder_kind=1, carrier_n_channels=16, vocoder_carrier_square_volume=0.0, vocoder_carrier_sine_volume=0.7,
+                                           vocoder_carrier_saw_volume=0.3), 256, 10.0, 3, carrier="synth"))
+            others.append(time_config(api, torch, dev, "configs[3]: 1000 stereo = 2000 mono streams, N = 8192, H = 2048, P = 128, autotune major / C",
+                                      dict(parity, window_size=8192, stride=2048, n_channels=128, use_autotune=1, autotune_type=0, autotune_scale_mode=0,
+                                           autotune_root_note=0), 2000, 10.0, 2))
+        except Exception as e:  # a failure here must not cost the headline line
+            others.append({"error": repr(e)})
+        result["other_configs"] = others
 
     if rank == 0:
         print(json.dumps(result))
-    ctx.close()
     if world > 1:
         dist.destroy_process_group()
 

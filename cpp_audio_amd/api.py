@@ -80,7 +80,7 @@ EXPORTED_SYMBOLS = [
     "ra_synchronize",
     "ra_feed", "ra_compute", "ra_get_stats", "ra_get_events", "ra_get_frame_pitches", "ra_resynth_notes", "ra_sqmag",
     "ra_set_profiling", "ra_get_kernel_ms", "ra_get_kernel_launches", "ra_render_note",
-    "ra_carrier_events", "ra_get_carrier",
+    "ra_carrier_events", "ra_get_carrier", "ra_set_pipeline_serial",
 ]
 
 _lib = None
@@ -115,6 +115,7 @@ def lib():
         L.ra_resynth_notes.restype = C.c_int64
         L.ra_sqmag.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]
         L.ra_set_profiling.argtypes = [C.c_void_p, C.c_int32]
+        L.ra_set_pipeline_serial.argtypes = [C.c_void_p, C.c_int32]
         L.ra_get_kernel_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
         L.ra_get_kernel_launches.argtypes = [C.c_void_p, C.c_void_p]
         L.ra_carrier_events.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
@@ -237,6 +238,10 @@ class Context:
 
     def set_profiling(self, enable=True):
         _check(lib().ra_set_profiling(self._h, 1 if enable else 0))
+
+    def set_pipeline_serial(self, on=True):
+        """Measurement aid: run a block's stages one after the other (each kernel alone on the chip) instead of overlapped."""
+        _check(lib().ra_set_pipeline_serial(self._h, 1 if on else 0))
 
     def kernel_ms(self):
         """({'analysis','track','vocoder','propagate','render','history'} -> accumulated ms, number of calls)."""

@@ -71,6 +71,7 @@ struct ra_context {
   std::vector<int64_t> car_last_sample;
   std::vector<RaCarEv> car_upload[2];   // host images of the blocks' event lists (kept until the set is reused)
   std::vector<int32_t> car_upload_begin[2];
+  bool pipeline_serial = false;         // measurement aid (ra_set_pipeline_serial): same chunks and launches, all on the caller's stream
   bool last_car_gen = false;            // the last block's carrier came from the synth (ra_get_carrier)
   // a block failed after it had started to change stream state (launches issued, histories rolled): the streams are then neither at the
   // block's start nor at its end, and every entry point returns RA_EINTERNAL until ra_reset
@@ -767,7 +768,8 @@ int process_block_impl(ra_context *c, const float *d_voice, const float *d_carri
     // streams of one priority share ROCm's 4 hardware queues; with flat priorities the analysis rides on the caller's stream instead so that
     // no two stages end up behind each other on one queue
     if (prio_mode == 0) sA = user;
-    static const bool one_queue = std::getenv("RA_PIPELINE_SERIAL") != nullptr; // tuning aid: same chunks, no overlap
+    static const bool one_queue_env = std::getenv("RA_PIPELINE_SERIAL") != nullptr; // tuning aid: same chunks, no overlap
+    const bool one_queue = one_queue_env || c->pipeline_serial;
     if (one_queue) sA = sT = sP = sR = user;
     if (sA == user) { if ((r = join_streams(c))) return r; async = false; } // tuning modes that use the caller's stream cannot overlap blocks
     HIP_TRY(hipEventRecord(c->ev_fork, user));
@@ -1033,6 +1035,14 @@ int ra_set_profiling(ra_context *c, int32_t enable) {
   c->profiling = enable != 0;
   for (int i = 0; i < 6; ++i) { c->kernel_ms[i] = 0; c->kernel_launches[i] = 0; }
   c->kernel_calls = 0;
+  return RA_OK;
+}
+
+int ra_set_pipeline_serial(ra_context *c, int32_t on) {
+  if (!c) return fail(RA_EINVAL, "null context");
+  HIP_TRY(hipSetDevice(c->device));
+  { int jr = join_streams(c); if (jr) return jr; }
+  c->pipeline_serial = on != 0;
   return RA_OK;
 }
 

@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_synth_kernel(RaPar
   const RaEnvParams ep = {p.envA, p.envH, p.envD, p.envR, p.SMinusOne};
   const uint64_t seed = p.seed + (uint64_t)s;
   // VocoderCarrierElementInitializer (lib.cpp:155-171): volume targets (float -> T) and PulseTrainAlgo_::setPulseWidth (audioelement.h:1701-1719)
-  const double v_noise = (double)p.car_vol[0], v_saw = (double)p.car_vol[1], v_tri = (double)p.car_vol[2], v_sq = (double)p.car_vol[3],
+  const double v_saw = (double)p.car_vol[1], v_tri = (double)p.car_vol[2], v_sq = (double)p.car_vol[3],
                v_sine = (double)p.car_vol[4], v_pulse = (double)p.car_vol[5];
   double pw = (double)p.car_pulse_width;
   pw = fmax(0., pw); pw = fmin(2., pw);
@@ -80,12 +80,17 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_synth_kernel(RaPar
   double *out_d = b.car_gen_d + (size_t)s * n;
   float *out_f = b.car_gen_f + (size_t)s * n;
 
+  RaPhaseClock clk(b.dbg_clk, l == 0);
   int64_t t = t0;
   const int64_t t_end = t0 + n;
+  // the next event's frame stays in a register: a global load per tile would have to wait for the tile's output stores to drain
+  constexpr int64_t kNever = 0x7fffffffffffffffll;
+  int64_t next_ev = (e < e_end) ? ev[e].sample : kNever;
   while (t < t_end) {
-    if (e < e_end && ev[e].sample <= t) { // the one-shots queued for this frame run before its step (simple_audio_context.h:74-76)
+    if (next_ev <= t) { // the one-shots queued for this frame run before its step (simple_audio_context.h:74-76)
       const RaCarEv q = ev[e];
       ++e;
+      next_ev = (e < e_end) ? ev[e].sample : kNever;
       if (l == 0) { xi[0] = 0x7fffffff; xi[1] = 0x7fffffff; }
       __syncthreads();
       if (q.type == 0) { // ---- onEvent(NoteOn), gen.crtp.h:389-449, and its one-shot :455-527 (run at once: same frame) ----
@@ -133,7 +138,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_synth_kernel(RaPar
       __syncthreads();
       continue;
     }
-    const int64_t seg_end = (e < e_end) ? min(t_end, ev[e].sample) : t_end;
+    const int64_t seg_end = min(t_end, next_ev);
     if (!__syncthreads_or(l < P && rt_active(c))) { // nothing sounds until the next event: silence
       for (int64_t r = t + l; r < seg_end; r += blockDim.x) { out_d[r - t0] = 0.0; out_f[r - t0] = 0.f; }
       t = seg_end;
@@ -141,14 +146,59 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_synth_kernel(RaPar
     }
     const int m = (int)min((int64_t)CT, seg_end - t);
     double *mine = tile + (size_t)l * (CT + 1);
+    clk.lap<0>();
+    // A tile in which every sounding channel just holds its note — envelope at its sustain level with no release falling due, control
+    // and oscillators at the note's increment, volume at its target — is the common case: its step is the oscillators and the mix, the
+    // envelope only counts (EnvelopeCRT::step, audioelement.h:702-731,965-968).  Anything else takes the general step below.
+    const bool act = l < P && rt_active(c);
+    const bool holds = c.state == ENV_PRESSED && c.ahdstate < 0 && c.counter >= 1 && (c.reldelay < 0 || c.reldelay >= m) && (c.flags & FL_HAS_FRES) &&
+                       c.fres == c.to && c.inc == c.to && (c.flags & FL_HAS_VOL) && c.vol == c.target;
+    if (__syncthreads_and(!act || holds)) {
+      if (act) {
+        double ang = x.ph_angle, cre = c.cre, cim = c.cim;
+        const double inc = x.ph_inc, al = x.ph_alias, mre = c.mre, mim = c.mim, sal = c.alias, vol = c.vol, val = c.value;
+        // a lane's samples form two recurrences (angle; phasor) with the mix hanging off them: unrolled, so that the mix of one sample
+        // issues in the shadow of the next sample's recurrence (one wave per SIMD: nothing else hides the fp64 latency)
+        auto one = [&](int i) {
+          ang += inc;                                                // Phased::step :1452-1470
+          if (ang > 2.0) ang -= 2.0;
+          const double re = cre * mre - cim * mim, im = cre * mim + cim * mre; // SineOscillatorAlgo::step
+          const double g = 0.5 * (3.0 - (re * re + im * im));
+          cre = re * g; cim = im * g;
+          double sum = 0.f;                                          // UnityGainMix::imag, as below
+          if (v_saw != 0.) sum += v_saw * (al * wave_saw(ang));
+          if (v_tri != 0.) sum += v_tri * (al * wave_triangle(ang));
+          if (v_sq != 0.) sum += v_sq * (al * wave_square(ang));
+          if (v_sine != 0.) sum += v_sine * (sal * cim);
+          if (v_pulse != 0.) sum += v_pulse * (al * wave_pulse(ang, pw, p_high, p_low));
+          mine[i] = vol * (sum * val);
+        };
+        if (m == CT) {
+#pragma unroll
+          for (int i = 0; i < CT; ++i) one(i);
+        } else {
+          for (int i = 0; i < m; ++i) one(i);
+        }
+        x.ph_angle = ang; c.cre = cre; c.cim = cim;
+        c.counter += m;
+        if (c.reldelay >= 0) c.reldelay -= m;
+      } else {
+        for (int i = 0; i < m; ++i) mine[i] = 0.0;
+      }
+      clk.lap<3>();
+    } else
     for (int i = 0; i < m; ++i) {
       double v = 0.0;
       if (rt_active(c)) { // ImplCRTP::compute, gen.crtp.h:352-371
         // BaseVolumeAdjusted::step (:1195-1216) -> Enveloped::step (:197-200) -> FreqCtrl_::step (:3126-3129)
-        env_step(c, ep);
+        // the envelope while it holds its sustain level (most of a note): EnvelopeCRT::step only counts (audioelement.h:702-731,965-968)
+        if (c.state == ENV_PRESSED && c.ahdstate < 0 && c.reldelay < 0 && c.counter >= 1) ++c.counter;
+        else env_step(c, ep);
         const double f = ctrl_step(c, 100.0);
-        x.ph_inc = phase_to_normal_form(f); x.ph_alias = alias_mult(f); // Phased::setAngleIncrements :1443-1446
-        osc_set_inc(c, f);
+        if (c.inc != f) { // both setAngleIncrements are functions of f alone: evaluated when f moves (the sine's own test, audioelement.h:2405)
+          x.ph_inc = phase_to_normal_form(f); x.ph_alias = alias_mult(f); // Phased::setAngleIncrements :1443-1446
+          osc_set_inc(c, f);
+        }
         x.ph_angle += x.ph_inc;                                        // Phased::step :1452-1470
         if (x.ph_angle > 2.0) x.ph_angle -= 2.0;
         { // SineOscillatorAlgo::step
@@ -156,42 +206,48 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_synth_kernel(RaPar
           const double g = 0.5 * (3.0 - (re * re + im * im));
           c.cre = re * g; c.cim = im * g;
         }
-        { // the outer volume filter: the first step takes the target, later steps keep it (target constant over the note)
-          const bool first = !(c.flags & FL_HAS_VOL);
-          const double inc = fabs(car_angle_increments(c, x));
-          const bool new_k = first || (c.vol != c.target && c.finit != inc);
-          const double a = M_PI * inc;
-          c.finit = new_k ? inc : c.finit;
-          c.k = new_k ? a / (1.0 + a) : c.k;
-          const double y0 = first ? c.target : c.y;
-          c.y = y0 + c.k * (c.target - y0);
+        // the outer volume filter: the first step takes the target (setInitialValue, then feed(target)); afterwards volume == target for
+        // the whole note and feed(target) returns it unchanged, whatever the coefficient
+        if (!(c.flags & FL_HAS_VOL)) {
+          const double inc = fabs(car_angle_increments(c, x)), a = M_PI * inc;
+          c.finit = inc; c.k = a / (1.0 + a);
+          c.y = c.target + c.k * (c.target - c.target);
           c.vol = c.y;
           c.flags |= FL_HAS_VOL;
+        } else if (c.vol != c.target) { // (unreachable while targets only change at note-on; kept for the reference's shape)
+          const double inc = fabs(car_angle_increments(c, x));
+          if (c.finit != inc) { c.finit = inc; const double a = M_PI * inc; c.k = a / (1.0 + a); }
+          c.y = c.y + c.k * (c.target - c.y);
+          c.vol = c.y;
         }
         if (rt_active(c)) {
-          // UnityGainMix::imag (:1966-1972): sum = 0.f; sum += volume_i * (aliasingMult * wave_i(angle)), in tuple order
+          // UnityGainMix::imag (:1966-1972): sum = 0.f; sum += volume_i * (aliasingMult * wave_i(angle)), in tuple order.  A voice whose
+          // volume is 0 adds +-0 to a sum that started at +0: skipped (workgroup-uniform tests)
           double sum = 0.f;
-          sum += v_noise * 0.0;
-          sum += v_saw * (x.ph_alias * wave_saw(x.ph_angle));
-          sum += v_tri * (x.ph_alias * wave_triangle(x.ph_angle));
-          sum += v_sq * (x.ph_alias * wave_square(x.ph_angle));
-          sum += v_sine * (c.alias * c.cim);
-          sum += v_pulse * (x.ph_alias * wave_pulse(x.ph_angle, pw, p_high, p_low));
+          if (v_saw != 0.) sum += v_saw * (x.ph_alias * wave_saw(x.ph_angle));
+          if (v_tri != 0.) sum += v_tri * (x.ph_alias * wave_triangle(x.ph_angle));
+          if (v_sq != 0.) sum += v_sq * (x.ph_alias * wave_square(x.ph_angle));
+          if (v_sine != 0.) sum += v_sine * (c.alias * c.cim);
+          if (v_pulse != 0.) sum += v_pulse * (x.ph_alias * wave_pulse(x.ph_angle, pw, p_high, p_low));
           v = c.vol * (sum * c.value); // BaseVolumeAdjusted::imag (:1126-1129) over Enveloped::imag (:227-231)
         }
       }
       mine[i] = v;
     }
+    clk.lap<1>();
     __syncthreads();
     if (l < m) { // `buffer[i] += c.elem.imag()` over the channels in index order (silent channels add 0)
       double acc = 0.0;
+#pragma unroll 8
       for (int ch = 0; ch < P; ++ch) acc += tile[(size_t)ch * (CT + 1) + l];
       out_d[t - t0 + l] = acc;
       out_f[t - t0 + l] = (float)acc;
     }
     __syncthreads();
+    clk.lap<2>();
     t += m;
   }
+  clk.flush(8);
   store_chan(c, sd, si, Ppad, l);
   ext[CX_PH_ANGLE * Ppad + l] = x.ph_angle; ext[CX_PH_INC * Ppad + l] = x.ph_inc; ext[CX_PH_ALIAS * Ppad + l] = x.ph_alias;
   b.car_noteid[(size_t)s * Ppad + l] = noteid;
@@ -200,6 +256,12 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_synth_kernel(RaPar
 
 // ---- K7 -------------------------------------------------------------------------------------------------------------------
 constexpr int BT = 64; // samples per tile = lanes
+__device__ inline double readlane_f64(double v, int lane) { // lane is wave-uniform
+  const long long u = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u & 0xffffffffll), lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)u >> 32), lane);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 __global__ void __launch_bounds__(64) ra_voc_bank_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, const float *__restrict__ carrier_f,
                                                         const double *__restrict__ carrier_d, int64_t n) {
   const int s = blockIdx.x, l = threadIdx.x, B = p.voc_bands;
@@ -212,16 +274,23 @@ __global__ void __launch_bounds__(64) ra_voc_bank_kernel(RaParams p, RaBuffers b
   const float *cf = carrier_f ? carrier_f + (size_t)s * n : nullptr;
   const double *cd = carrier_d ? carrier_d + (size_t)s * n : nullptr;
   double *mix = b.voc_mix + (size_t)s * n;
-  for (int64_t t = 0; t < n; t += BT) {
-    const int cnt = (int)min((int64_t)BT, n - t);
-    // this lane's sample of the tile (the modulator as the double read_direct_input widens it to, lib.cpp:1073-1079)
-    double mv = 0.0, cv = 0.0;
-    if (l < cnt) {
+  // this lane's sample of a tile (the modulator as the double read_direct_input widens it to, lib.cpp:1073-1079); the next tile's
+  // samples are requested before the current tile is computed, so that no load has to wait behind the tile's output stores
+  auto fetch = [&](int64_t t, double &mv, double &cv) {
+    mv = 0.0; cv = 0.0;
+    if (t + l < n) {
       if (vs) mv = (double)vs[t + l];
       if (cd) cv = cd[t + l]; else if (cf) cv = (double)cf[t + l];
     }
-    for (int i = 0; i < cnt; ++i) {
-      const double m = __shfl(mv, i), c = __shfl(cv, i);
+  };
+  double mv_next, cv_next;
+  fetch(0, mv_next, cv_next);
+  for (int64_t t = 0; t < n; t += BT) {
+    const int cnt = (int)min((int64_t)BT, n - t);
+    const double mv = mv_next, cv = cv_next;
+    fetch(t + BT, mv_next, cv_next);
+    auto sample = [&](int i) {
+      const double m = readlane_f64(mv, i), c = readlane_f64(cv, i); // wave-uniform: scalar operands of the recurrences
       // Modulator::feed (vocoder.cpp:358-380): BandPass::feed (:54-58) = high-pass then low-pass; EnvelopeFollower::feed (:71-74) of |.|
       yA = yA + kA * (m - yA);
       const double hp = m - yA;             // high-pass = input - low-pass
@@ -232,6 +301,12 @@ __global__ void __launch_bounds__(64) ra_voc_bank_kernel(RaParams p, RaBuffers b
       const double hpc = c - yC;
       yD = yD + kB * (hpc - yD);
       tile[i * 65 + l] = band ? yE * yD : 0.0; // ponderation[i] * filtered
+    };
+    if (cnt == BT) {
+#pragma unroll 8
+      for (int i = 0; i < BT; ++i) sample(i);
+    } else {
+      for (int i = 0; i < cnt; ++i) sample(i);
     }
     // `res += ponderation[i] * filtered` in band order (one wave: its LDS operations execute in order)
     if (l < cnt) {

@@ -238,6 +238,10 @@ int ra_compute(ra_context *ctx, int32_t stream, double *h_buffer, int32_t n_fram
  * propagation, synthesis render (compute), history copy} over `calls` ra_process_* calls since profiling was enabled.
  */
 int ra_set_profiling(ra_context *ctx, int32_t enable);
+/* Measurement aid: with on != 0 the stages of a block (same chunks, same launches) run one after the other on the caller's stream
+ * instead of overlapping on the context's internal streams, so that ra_get_kernel_ms reports what each kernel costs with the chip to
+ * itself.  Results are identical either way. */
+int ra_set_pipeline_serial(ra_context *ctx, int32_t on);
 int ra_get_kernel_ms(ra_context *ctx, double *ms6, int64_t *calls);
 /* number of kernel launches behind each entry of ms6 (a block is cut into pipeline chunks: several launches per stage and call) */
 int ra_get_kernel_launches(ra_context *ctx, int64_t *launches6);

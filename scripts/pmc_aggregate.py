@@ -1,10 +1,12 @@
 """Builds traffic.json (per-kernel PMC sums of the LAST bench step) and kernel_stats.csv (ra_* rows of rocprofv3 --stats) from the
-directory scripts/collect_profiles.sh filled."""
+directory scripts/collect_profiles.sh filled.  The workload block and the kernel-source hash come from the bench line collected
+beside the counters (bench.json): bench.py quotes the counters only for exactly that shape and build."""
 import csv, glob, json, os, sys
 
 out = sys.argv[1]
-KERNELS = ("ra_analysis_kernel", "ra_track_kernel", "ra_synth_propagate_kernel", "ra_synth_render_mono_kernel", "ra_synth_render_kernel",
-           "ra_roll_history_kernel")
+STAGE = {"ra_analysis_kernel": "analysis", "ra_track_kernel": "track", "ra_synth_propagate_kernel": "propagate", "ra_synth_render_mono_kernel": "render",
+         "ra_synth_render_kernel": "render", "ra_roll_history_kernel": "history"}
+KERNELS = tuple(STAGE)
 
 
 def short(name):
@@ -14,21 +16,23 @@ def short(name):
     return None
 
 
+bench = json.load(open(os.path.join(out, "bench.json")))
+LAUNCHES = {k: v["launches_per_step"] for k, v in bench["kernels"].items()}
+cfgw = bench["config"]
+import re
+m = re.search(r"window (\d+) .*stride (\d+) .* (\d+) partials", cfgw["workload"])
+workload = {"streams": cfgw["streams_per_gpu"], "frames_per_stream": cfgw["frames_per_stream_per_step"], "window": int(m.group(1)),
+            "stride": int(m.group(2)), "partials": int(m.group(3))}
 kern = {}
-STAGE = {"ra_analysis_kernel": "analysis", "ra_track_kernel": "track", "ra_synth_propagate_kernel": "propagate", "ra_synth_render_mono_kernel": "render",
-         "ra_synth_render_kernel": "render", "ra_roll_history_kernel": "history"}
-try:
-    LAUNCHES = json.load(open(os.path.join(out, "bench.json")))["kernel_launches_per_step"]
-except Exception:
-    LAUNCHES = {}
-for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
+counters = sorted(os.path.basename(d)[4:] for d in glob.glob(os.path.join(out, "pmc_*")) if os.path.isdir(d))
+for ctr in counters:
     files = glob.glob(os.path.join(out, "pmc_" + ctr, "**", "*counter_collection.csv"), recursive=True)
     if not files:
         print("no counter file for", ctr)
         continue
     rows = list(csv.DictReader(open(files[0])))
-    # one row per dispatch (and counter).  The bench ran its set-up block, 1 warm-up step and 1 timed step: keep the dispatches of the
-    # timed step = the last kernel_launches_per_step[stage] of each kernel (from the bench line collected beside this)
+    # one row per dispatch (and counter).  The bench ran its set-up block, 1 warm-up step, 1 timed step and the serialised extra step
+    # (kernels{}.alone): the timed step's dispatches of a kernel are the launches_per_step before the last launches_per_step
     per = {}
     for r in rows:
         k = short(r["Kernel_Name"])
@@ -36,17 +40,19 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
             per.setdefault(k, []).append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
     for k, lst in per.items():
         lst.sort()
-        nl = int(round(LAUNCHES.get(STAGE[k], len(lst) // 2))) or 1
-        last = lst[-nl:]
+        nl = int(round(LAUNCHES.get(STAGE[k], 0))) or 1
+        last = lst[-2 * nl:-nl] if len(lst) >= 2 * nl else lst[-nl:]
         d = kern.setdefault(k, {})
-        d[ctr if ctr == "SQ_INSTS_VALU" else ctr + "_KB"] = sum(v for _, v in last)
+        d[ctr + "_KB" if ctr in ("FETCH_SIZE", "WRITE_SIZE") else ctr] = sum(v for _, v in last)
         d["launches"] = len(last)
 doc = {
-    "collected_with": "rocprofv3 --kernel-trace --pmc <one counter per run: FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU> -- python3 bench.py --steps 1 "
-                      "--warmup 1 --no-cpu-baseline ; sums over the launches of the timed step (scripts/collect_profiles.sh, scripts/pmc_aggregate.py)",
+    "collected_with": "rocprofv3 --kernel-trace --pmc <one counter per run> -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline "
+                      "--no-other-configs ; sums over the launches of the timed step (scripts/collect_profiles.sh, scripts/pmc_aggregate.py)",
     "units": "FETCH/WRITE in KB as reported by rocprofv3; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 — the x2 is the gfx950 correction of "
-             "MI355X_MICROARCH.md §HBM for streaming reads; SQ_INSTS_VALU in wave-instructions",
-    "workload": {"streams": 256, "frames_per_stream": 480000, "window": 4096, "stride": 1024, "partials": 64},
+             "MI355X_MICROARCH.md §HBM for streaming reads; SQ_INSTS_VALU in wave-instructions; SQ_WAVES waves launched; SQ_BUSY_CYCLES / "
+             "SQ_WAVE_CYCLES summed over SEs as rocprofv3 reports them; SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE in cycles",
+    "workload": workload,
+    "csrc_sha256": bench.get("csrc_sha256"),
     "kernels": kern,
 }
 json.dump(doc, open(os.path.join(out, "traffic.json"), "w"), indent=1)
