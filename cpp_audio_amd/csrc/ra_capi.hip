@@ -189,7 +189,7 @@ int validate(const ra_config &c, int32_t n_streams) {
   if (c.vocoder_count_bands < 1 || c.vocoder_count_bands > 50) return fail(RA_EINVAL, "vocoder_count_bands must be in 1..50");
   if (c.window_kind < 0 || c.window_kind > 2) return fail(RA_EINVAL, "unknown window_kind");
   if (c.autotune_factor < 0) return fail(RA_EINVAL, "autotune_factor must be >= 0");
-  if (c.analysis_output_feedback_gain != 0.f && c.reference_order != 0) return fail(RA_EINVAL, "analysis_output_feedback_gain needs reference_order 0");
+  if (c.analysis_output_feedback_gain != 0.f && c.reference_order > 1) return fail(RA_EINVAL, "analysis_output_feedback_gain needs reference_order 0 or 1");
   if (c.analysis_output_feedback_gain != 0.f && !(c.output_delay_seconds >= 0.f && c.output_delay_seconds <= 60.f)) return fail(RA_EINVAL, "output_delay_seconds must be in 0..60");
   if (c.vocoder_kind != RA_VOCODER_FFT && c.vocoder_kind != RA_VOCODER_BANDPASS) return fail(RA_EINVAL, "unknown vocoder_kind");
   if (c.vocoder_kind == RA_VOCODER_BANDPASS && !(c.vocoder_env_follower_cutoff_ratio > 0.f)) return fail(RA_EINVAL, "vocoder_env_follower_cutoff_ratio must be > 0");
@@ -725,8 +725,11 @@ int process_block_impl(ra_context *c, const float *d_voice, const float *d_carri
         RA_TRY(timed_launch(c, ST_ANALYSIS, user, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, sp.fb0, sp.nfb, nfb, user); }));
         RA_TRY(timed_launch(c, ST_TRACK, user, [&] { ra_launch_track(p, b, f_lo, sp.fb0, sp.nfb, user); }));
       }
-      RA_TRY(timed_launch(c, ST_PROPAGATE, user, [&] { ra_launch_synth_propagate(p, b, sp, user); }));
-      RA_TRY(timed_launch(c, ST_RENDER, user, [&] { ra_launch_synth_render(p, b, sp, d_out, d_out_d, user); }));
+      if (c->cfg.reference_order == 1) RA_TRY(timed_launch(c, ST_RENDER, user, [&] { ra_launch_synth_serial(p, b, sp, d_out, d_out_d, user); }));
+      else {
+        RA_TRY(timed_launch(c, ST_PROPAGATE, user, [&] { ra_launch_synth_propagate(p, b, sp, user); }));
+        RA_TRY(timed_launch(c, ST_RENDER, user, [&] { ra_launch_synth_render(p, b, sp, d_out, d_out_d, user); }));
+      }
       fb0 = fb1;
       fb1 = std::min(nfb, fb0 + per);
       ++piece;

@@ -82,7 +82,8 @@ __device__ inline SynConst syn_const(const RaParams &p, int s) {
 // samples [t, seg_end) of stream s: step every active channel, mix, write.  Workgroup-uniform control flow.
 template <bool FAST>
 __device__ inline void render_range(Chan &c, const SynLds &L, const SynConst &k, const RaParams &p, int s, int l, int64_t t, int64_t seg_end, int64_t t0,
-                                    int64_t n, const double *__restrict__ mix, float *__restrict__ out, double *__restrict__ out_d) {
+                                    int64_t n, const double *__restrict__ mix, float *__restrict__ out, double *__restrict__ out_d,
+                                    float *__restrict__ fb_mono = nullptr) {
   const int Ppad = p.Ppad, stride1 = Ppad + 1;
   const double inv_dur = 1.0 / k.dur;
   while (t < seg_end) {
@@ -107,11 +108,14 @@ __device__ inline void render_range(Chan &c, const SynLds &L, const SynConst &k,
         for (int q = c0; q < c1; ++q) acc += row[q];
       }
       acc += __shfl_down(acc, 32);
-      if (l < 32 && fr < m) {
-        const int64_t rel = (t - t0) + fr;
-        if (mix) acc += mix[rel];  // the vocoder compute runs after the synth compute (lib.cpp:1353,1377)
+      const bool w = l < 32 && fr < m;
+      const int64_t rel = (t - t0) + fr;
+      if (w && mix) acc += mix[rel];  // the vocoder compute runs after the synth compute (lib.cpp:1353,1377)
+      const double other = __shfl_xor(acc, 16); // the same frame's other output channel
+      if (w) {
         if (out) out[((size_t)s * n + rel) * 2 + ch] = (float)acc; // simple_audio_context.h:105-109
         if (out_d) out_d[((size_t)s * n + rel) * 2 + ch] = acc;
+        if (fb_mono && ch == 0) fb_mono[rel] = (float)(acc + other); // the post processor's publication, lib.cpp:1262-1272, pubsub.cpp:92
       }
     }
     __syncthreads();
@@ -556,7 +560,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_serial_kernel(RaPara
   int64_t t = sp.ct0;
   for (int64_t i = 0; i <= sp.nfb; ++i) {
     const int64_t seg_end = (i < sp.nfb) ? ra_fire_sample(p.N, p.H, sp.f_lo + sp.fb0 + i) : sp.ct1;
-    render_range<false>(c, L, k, p, s, l, t, seg_end, sp.t0, sp.n, mix, out, out_d);
+    render_range<false>(c, L, k, p, s, l, t, seg_end, sp.t0, sp.n, mix, out, out_d, b.fb_block ? b.fb_block + (size_t)s * sp.n : nullptr);
     t = seg_end;
     if (i == sp.nfb) break;
     const RaCmd cmd = b.cmd[((size_t)s * b.frames_cap + sp.fb0 + i) * Ppad + l];

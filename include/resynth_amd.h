@@ -101,7 +101,7 @@ typedef struct ra_config {
    * analysis_input_gain * voice[k] + analysis_output_feedback_gain * mono_out[k - 1 - delay], delay = int(0.5 + output_delay_seconds *
    * sample_rate) frames, mono_out = float(L + R) of the final mix.  With a non-zero gain a block is processed in sequential pieces of
    * delay / stride + 1 analysis frames (the analysis of a piece needs the output of the pieces before it): correct for any delay, fast
-   * only for delays of many strides (the reference default is 1 s).  Not available with reference_order != 0. */
+   * only for delays of many strides (the reference default is 1 s).  Available with reference_order 0 and 1. */
   float analysis_output_feedback_gain; /* 0 */
   float output_delay_seconds;          /* 1 */
 

@@ -56,11 +56,15 @@ struct Midi { // midi.h:234-268 with tuning_stretch = 1
   // the same for analysed peaks: log2 as the explicit sequence of oracle_math.hpp (its last bits decide events, see there)
   std::optional<double> frequency_to_midi_pitch_analysis(double freq) const {
     if (freq <= 0) return {};
+    if (libm_mode()) return A_pitch + (num_halftones_per_octave / tuning_stretch) * std::log2(freq / freq_A);
     return A_pitch + (num_halftones_per_octave / tuning_stretch) * det_log2(freq / freq_A);
   }
   // the same for the frequency of an event (lib.cpp:320): the power as the explicit sequence of oracle_math.hpp, so that the float it is
   // rounded to is reproducible (libm powers differ by an ulp now and then: a different float about once in 1e8 events)
-  double midi_pitch_to_freq_event(double pitch) const { return freq_A * det_pow(half_tone_ratio, pitch - A_pitch); }
+  double midi_pitch_to_freq_event(double pitch) const {
+    if (libm_mode()) return midi_pitch_to_freq(pitch);
+    return freq_A * det_pow(half_tone_ratio, pitch - A_pitch);
+  }
   double midi_pitch_to_freq(double pitch) const { // midi.h:258-264
     return freq_A * std::pow(half_tone_ratio, pitch - A_pitch);
   }

@@ -12,6 +12,8 @@ using namespace ora;
 extern "C" {
 
 void ora_default_config(ora_config *c) { *c = default_config(); }
+// 0: explicit log2 / log10 / exp10 / pow (bit-comparable with the product); 1: the platform libm as the reference's text calls it
+void ora_set_libm_mode(int on) { libm_mode() = on ? 1 : 0; }
 
 int ora_even_window_size_frames(float seconds, int sr) { return even_window_size_frames(seconds, sr); }
 int ora_window_center_stride_frames(float seconds, int sr) { return window_center_stride_frames(seconds, sr); }

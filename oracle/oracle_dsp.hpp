@@ -186,8 +186,11 @@ struct SqMagFft {
 // Decision: 10 log10(x) with x floored at 1e-300 (keeps exact zeros finite); 10^(dB/20).  On the analysis path (peak dB values, peak
 // volumes) the logarithm and the power are the explicit sequences of oracle_math.hpp — events depend on their last bits, see there;
 // the note driver's volume (resynth.hpp:86, continuous only) keeps the libm power, as the product's host code does.
-inline double sqmag_to_db(double x) { return 10.0 * det_log10(x > 1e-300 ? x : 1e-300); }
-inline double db_to_mag_analysis(double db) { return det_exp10(db / 20.0); }
+inline double sqmag_to_db(double x) {
+  if (libm_mode()) return 10.0 * std::log10(x > 1e-300 ? x : 1e-300);
+  return 10.0 * det_log10(x > 1e-300 ? x : 1e-300);
+}
+inline double db_to_mag_analysis(double db) { return libm_mode() ? std::pow(10.0, db / 20.0) : det_exp10(db / 20.0); }
 inline double db_to_mag(double db) { return std::pow(10.0, db / 20.0); }
 
 struct FreqMag { double freq; double mag_db; };

@@ -17,6 +17,13 @@
 
 namespace ora {
 
+// Independent-arithmetic mode (tests only): 0 = the explicit sequences below (what the product evaluates: events comparable bit for bit),
+// 1 = the platform libm exactly as the reference's text calls it — std::log2 (include/midi.h:223-232), 10 * std::log10 and
+// std::pow(10, dB / 20) for SqMagToDb / DbToMag (call sites lib.cpp:1594, algo.cpp:25), std::pow for midi_pitch_to_freq (midi.h:258-264).
+// Mode 1 shares no transcendental code with the product: a mistake common to oracle_math.hpp and ra_math.cuh would show up as a pitch
+// error beyond a few ulps (tests/test_gpu_parity.py::test_against_the_libm_oracle).  Set before a run, not during one.
+inline int &libm_mode() { static int m = 0; return m; }
+
 inline double bits_to_double(uint64_t u) { double d; std::memcpy(&d, &u, sizeof d); return d; }
 inline uint64_t double_to_bits(double d) { uint64_t u; std::memcpy(&u, &d, sizeof u); return u; }
 

@@ -106,6 +106,17 @@ def lib():
     return _lib
 
 
+class libm_mode:
+    """with oracle_lib.libm_mode(): ... — the oracle evaluates log2 / log10 / pow with the platform libm, as the reference's text does
+    (independent of the product's explicit series); outside, the explicit series (bit-comparable events)."""
+
+    def __enter__(self):
+        lib().ora_set_libm_mode(1)
+
+    def __exit__(self, *a):
+        lib().ora_set_libm_mode(0)
+
+
 def default_config(**kw):
     c = OraConfig()
     lib().ora_default_config(C.byref(c))

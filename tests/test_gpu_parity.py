@@ -512,3 +512,121 @@ def test_output_feedback_into_the_analysis(api, oracle, sig, delay_s, gain, seco
         quiet = min(n, 1024 + 1 + sz)
         assert rms(whole[s][:quiet], ref0[:quiet]) <= 1e-8
     assert fed_back
+
+
+@pytest.mark.parametrize("delay_s,gain,seconds", [(0.05, 0.15, 1.0), (0.0, 0.1, 0.3), (1.0, 0.8, 2.5), (0.0123, -0.15, 0.8)])
+def test_output_feedback_in_reference_order(api, oracle, sig, delay_s, gain, seconds):
+    # The loop's semantics — delay line, the start-up pairing input k <-> output k - 1 - delay (pubsub.cpp:151-200), the float32
+    # publication — pinned with the sample-serial kernel, whose operation order is the restatement's: the float32 outputs agree bit for bit
+    # except where a libm ulp (sincos of a phase) lands on a float rounding boundary, and every event is identical.  (An off-by-one in the
+    # pairing or the delay shows as 1e-3-level differences, not 1e-7.)  The 1e-4 bar of test_output_feedback_into_the_analysis is
+    # therefore about the hop-parallel renderer's rounding-level differences going round the loop, not about the loop.
+    kw = dict(window_size=1024, stride=256, n_channels=16, analysis_output_feedback_gain=gain, output_delay_seconds=delay_s, reference_order=1)
+    gcfg, k = both_configs(api, oracle, **kw)
+    n = int(seconds * 48000)
+    x = sig.make_streams(2, n, base_seed=31)
+    with api.Context(gcfg, 2, 0) as ctx:
+        whole = ctx.process_host(x)
+        st = ctx.stats()
+        evs = [ctx.events(s) for s in range(2)]
+        ctx.reset()
+        cut = n // 3 + 17
+        parts = np.concatenate([ctx.process_host(x[:, :cut]), ctx.process_host(x[:, cut:])], axis=1)
+    assert st.error_flags == 0
+    assert np.array_equal(parts, whole), "reference order: independent of the block cut, bit for bit"
+    for s in range(2):
+        ref, ev, _ = oracle.run_offline(oracle.default_config(**dict(k, seed=k["seed"] + s)), x[s])
+        assert np.sqrt(np.mean(ref.astype(np.float64) ** 2)) > 1e-4
+        assert np.mean(whole[s] == ref) > 0.999, np.mean(whole[s] == ref)
+        assert np.max(np.abs(whole[s].astype(np.float64) - ref)) < 2e-6
+        assert rms(whole[s], ref) < 1e-7
+        # the last block's events (the whole run here) against the restatement's
+        ev = ev[ev["type"] != 3]
+        assert len(ev) == len(evs[s])
+        for f in ("sample", "type", "channel", "noteid"):
+            assert np.array_equal(ev[f], evs[s][f]), f
+
+
+def ulp_distance(a, b):
+    """|a - b| in units of the spacing at a (float64 arrays)."""
+    return np.abs(a - b) / np.spacing(np.maximum(np.abs(a), 1e-300))
+
+
+@pytest.mark.parametrize("shape", ["configs1", "configs3"])
+def test_against_the_libm_oracle(api, oracle, sig, shape):
+    # The product's decision path evaluates log2 / log10 / 10^x / pow as explicit series (ra_math.cuh), and so does the oracle the other
+    # tests compare with (oracle_math.hpp, same text) — a mistake common to both would be invisible there.  Here the oracle calls the
+    # platform libm exactly as the reference's text does (std::log2, midi.h:223-232; log10 / pow for SqMagToDb / DbToMag; std::pow for
+    # midi_pitch_to_freq): no transcendental code is shared.  Bars: every pitch within 16 ulp and every volume within 64 ulp (7e-15 relative) of the libm
+    # values (measured: 6 and 18) — a peak's pitch goes through the parabola over three dB values, p = (a - c) / 2 (a - 2 b + c), whose cancellation multiplies
+    # the <= 2.7 ulp of the logarithms by up to an order of magnitude, whereas a wrong series coefficient would show at 1e-10 or more;
+    # events identical (float payloads within 1 float ulp) and audio within 1e-5 RMS on every stream whose decisions do not sit
+    # on a tie — a tracked pitch distance within 1e-9 of max_track_pitches, or an interval volume within 1e-9 relative of min_volume —
+    # such streams are counted and reported instead (with autotune they are the rule: pitches on a semitone grid, distance exactly 1).
+    if shape == "configs1":
+        kw, S, n = {}, 6, 96000
+    else:
+        kw, S, n = dict(window_size=8192, stride=2048, n_channels=128, use_autotune=1, autotune_type=0, autotune_scale_mode=0, autotune_root_note=0), 3, 96000
+    x = sig.make_streams(S, n, base_seed=2024)
+    gcfg, k = both_configs(api, oracle, **kw)
+    with api.Context(gcfg, S, 0) as ctx:
+        out = ctx.process_host(x)
+        assert ctx.stats().error_flags == 0
+        evs = [ctx.events(s) for s in range(S)]
+        fps = [ctx.frame_pitches(s) for s in range(S)]
+    ties, compared = 0, 0
+    worst_p = worst_v = 0.0
+    with oracle.libm_mode():
+        for s in range(S):
+            ocfg = oracle.default_config(**dict(k, seed=k["seed"] + s))
+            ref, ev, _ = oracle.run_offline(ocfg, x[s])
+            fire, offs, pitch, vol = oracle.run_frames(ocfg, x[s])
+            gfire, goffs, gpitch, gvol = fps[s]
+            assert np.array_equal(fire, gfire)
+            same_lists = np.array_equal(offs, goffs)
+            if same_lists:
+                worst_p = max(worst_p, float(np.max(ulp_distance(pitch, gpitch), initial=0.0)))
+                worst_v = max(worst_v, float(np.max(ulp_distance(vol, gvol), initial=0.0)))
+            # does any decision of this stream sit on a tie?
+            tie = not same_lists
+            mt = float(gcfg.max_track_pitches)
+            for f in range(len(fire) - 1):
+                a, b = pitch[offs[f]:offs[f + 1]], pitch[offs[f + 1]:offs[f + 2]]
+                if len(a) and len(b):
+                    d = np.abs(np.abs(a[:, None] - b[None, :]) - mt)
+                    if np.min(d) < 1e-9:
+                        tie = True
+                        break
+            if tie:
+                ties += 1
+                continue
+            compared += 1
+            ev = ev[ev["type"] != 3]
+            gev = evs[s]
+            assert len(ev) == len(gev), f"stream {s}"
+            for f in ("sample", "type", "channel", "noteid"):
+                assert np.array_equal(ev[f], gev[f]), f"stream {s}: {f}"
+            for f in ("frequency", "velocity"):
+                assert np.all(np.abs(ev[f].astype(np.float64) - gev[f]) <= np.spacing(np.abs(ev[f]).astype(np.float32)).astype(np.float64)), f
+            assert rms(out[s], ref) <= RMS_TOL
+    print(f"libm oracle [{shape}]: {compared} streams compared event for event, {ties} with a decision on a tie; worst pitch {worst_p:.2f} ulp, volume {worst_v:.2f} ulp")
+    assert worst_p <= 16.0 and worst_v <= 64.0
+    if shape == "configs1":
+        assert compared == S, "without autotune no stream is expected to sit on a tie"
+
+
+def test_lds_limits_are_checked_at_create(api, oracle, sig):
+    # ADVICE r1: max_pitches_per_frame up to 4096 is accepted only while the per-workgroup LDS of the analysis and tracking kernels fits
+    x = sig.make_streams(1, 24000)
+    gcfg, k = both_configs(api, oracle, max_pitches_per_frame=2048)   # tracking: 2048 * 40 + 64 * 88 B > the 64 KB default
+    with api.Context(gcfg, 1, 0) as ctx:
+        out = ctx.process_host(x)
+        assert ctx.stats().error_flags == 0
+    ref, _, _ = oracle.run_offline(oracle.default_config(**k), x[0])
+    assert rms(out[0], ref) <= RMS_TOL
+    with pytest.raises(api.RaError) as e:
+        api.Context(api.default_config(**dict(PARITY_KW, max_pitches_per_frame=4096, pitch_harmonize_pre_autotune=7.0)), 1, 0)
+    assert e.value.code == -1 and "LDS" in str(e.value)
+    with pytest.raises(api.RaError) as e:
+        api.Context(api.default_config(**dict(PARITY_KW, max_pitches_per_frame=4096, window_size=16384, stride=4096)), 1, 0)
+    assert e.value.code == -1 and "LDS" in str(e.value)
