@@ -1,8 +1,7 @@
 """GPU test of the C++ host shims: compiles tests/host/test_shims.cpp against libresynth_amd.so, runs it, and checks the
-raw outputs it leaves behind against the CPU oracle."""
+raw outputs it leaves behind against the CPU oracle.  The compiler and the compiled programs are started by the session's helper
+process (conftest.run_program), never by this — possibly GPU-initialised — process."""
 import os
-import subprocess
-
 import numpy as np
 import pytest
 
@@ -10,13 +9,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_reference_shaped_drivers_run_on_the_hip_backend(oracle, tmp_path):
+def test_reference_shaped_drivers_run_on_the_hip_backend(oracle, tmp_path, run_program):
     lib_dir = os.path.join(ROOT, "cpp_audio_amd")
     exe = tmp_path / "test_shims"
-    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "host", "test_shims.cpp"), "-o", str(exe),
-                           "-L", lib_dir, "-lresynth_amd", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"])
-    p = subprocess.run([str(exe), str(tmp_path)], capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stdout + p.stderr
+    rc, so, se = run_program(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "host", "test_shims.cpp"), "-o", str(exe),
+                              "-L", lib_dir, "-lresynth_amd", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"])
+    assert rc == 0, so + se
+    rc, so, se = run_program([str(exe), str(tmp_path)])
+    assert rc == 0, so + se
     voice = np.fromfile(tmp_path / "voice.f32", np.float32)
     out_a = np.fromfile(tmp_path / "out_a.f32", np.float32).reshape(-1, 2)
     cfg = oracle.default_config(window_size=1024, stride=256, n_channels=16, analysis_volume=1.0, stereo_spread=0.0, carrier_volume=0.0, seed=99)
@@ -28,24 +28,25 @@ def test_reference_shaped_drivers_run_on_the_hip_backend(oracle, tmp_path):
     assert len(notes) == len(nref) and np.sqrt(np.mean((notes - nref) ** 2)) <= 1e-9
 
 
-def test_offline_job_file_runs_end_to_end(oracle, tmp_path):
+def test_offline_job_file_runs_end_to_end(oracle, tmp_path, run_program):
     """rt.resynth.job flow (params.cpp:183-386, lib.cpp:1185-1235): job config JSON -> WAV in -> preset JSON -> GPU -> stereo float32 WAV."""
     import json
     from scipy.io import wavfile
     from cpp_audio_amd import signals
     lib_dir = os.path.join(ROOT, "cpp_audio_amd")
     exe = tmp_path / "preset_tool"
-    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "host", "preset_tool.cpp"), "-o", str(exe),
-                           "-L", lib_dir, "-lresynth_amd", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"])
+    rc, so, se = run_program(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "host", "preset_tool.cpp"), "-o", str(exe),
+                              "-L", lib_dir, "-lresynth_amd", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"])
+    assert rc == 0, so + se
     sr = 48000
     voice = np.ascontiguousarray(signals.make_streams(1, int(1.5 * sr), sr, base_seed=5, kind="speech")[0], np.float32)
     wavfile.write(tmp_path / "voice.wav", sr, voice)
     job = {"preset_file": os.path.join(ROOT, "tests", "golden", "preset_example.json"), "input_voice_file": str(tmp_path / "voice.wav"),
            "input_carrier_file": "", "output_file": str(tmp_path / "out.wav"), "post": "none"}
     (tmp_path / "job.json").write_text(json.dumps(job))
-    p = subprocess.run([str(exe), "job", str(tmp_path / "job.json"), "16", "77"], capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stdout + p.stderr
-    st = dict(l.split() for l in p.stdout.strip().splitlines())
+    rc, so, se = run_program([str(exe), "job", str(tmp_path / "job.json"), "16", "77"])
+    assert rc == 0, so + se
+    st = dict(l.split() for l in so.strip().splitlines())
     assert int(st["error_flags"]) == 0 and int(st["samples_rendered"]) == len(voice)
     sr2, out = wavfile.read(tmp_path / "out.wav")
     assert sr2 == sr and out.dtype == np.float32 and out.shape == (len(voice), 2)
