@@ -48,7 +48,7 @@ class RaConfig(C.Structure):
         ("vocoder_carrier_noise_volume", C.c_float), ("vocoder_carrier_saw_volume", C.c_float),
         ("vocoder_carrier_triangle_volume", C.c_float), ("vocoder_carrier_square_volume", C.c_float),
         ("vocoder_carrier_sine_volume", C.c_float), ("vocoder_carrier_pulse_volume", C.c_float),
-        ("vocoder_carrier_pulse_width", C.c_float),
+        ("vocoder_carrier_pulse_width", C.c_float), ("post", C.c_int32),
     ]
 
 
@@ -80,7 +80,7 @@ EXPORTED_SYMBOLS = [
     "ra_synchronize",
     "ra_feed", "ra_compute", "ra_get_stats", "ra_get_events", "ra_get_frame_pitches", "ra_resynth_notes", "ra_sqmag",
     "ra_set_profiling", "ra_get_kernel_ms", "ra_get_kernel_launches", "ra_render_note",
-    "ra_carrier_events", "ra_get_carrier", "ra_set_pipeline_serial",
+    "ra_carrier_events", "ra_get_carrier", "ra_set_pipeline_serial", "ra_deduce_notes",
 ]
 
 _lib = None
@@ -113,6 +113,8 @@ def lib():
         L.ra_get_frame_pitches.restype = C.c_int64
         L.ra_resynth_notes.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]
         L.ra_resynth_notes.restype = C.c_int64
+        L.ra_deduce_notes.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]
+        L.ra_deduce_notes.restype = C.c_int64
         L.ra_sqmag.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]
         L.ra_set_profiling.argtypes = [C.c_void_p, C.c_int32]
         L.ra_set_pipeline_serial.argtypes = [C.c_void_p, C.c_int32]
@@ -289,6 +291,19 @@ def sqmag(windows, window_kind=0, device=0):
     _check(lib().ra_sqmag(_p(w), n, N, window_kind, device, _p(out), C.byref(fl)))
     assert fl.value == L
     return out, L
+
+
+NOTE_DTYPE = np.dtype([("start_frame", "<i4"), ("end_frame", "<i4"), ("frequency", "<f8"), ("amplitude_db", "<f8")])
+
+
+def deduce_notes(signal, sr, half_window_size, window_center_stride, window_kind=0, device=0):
+    """ra_deduce_notes: mono float32 signal -> structured array of notes (start_frame, end_frame, frequency, amplitude_db)."""
+    x = np.ascontiguousarray(signal, np.float32)
+    n = _check(lib().ra_deduce_notes(_p(x), len(x), sr, half_window_size, window_kind, window_center_stride, device, None, 0))
+    notes = np.zeros(n, NOTE_DTYPE)
+    if n:
+        _check(lib().ra_deduce_notes(_p(x), len(x), sr, half_window_size, window_kind, window_center_stride, device, _p(notes), n))
+    return notes
 
 
 def resynth_notes(start, end, freq, amp_db, stride, sr, device=0):

@@ -193,6 +193,7 @@ int validate(const ra_config &c, int32_t n_streams) {
   if (c.analysis_output_feedback_gain != 0.f && !(c.output_delay_seconds >= 0.f && c.output_delay_seconds <= 60.f)) return fail(RA_EINVAL, "output_delay_seconds must be in 0..60");
   if (c.vocoder_kind != RA_VOCODER_FFT && c.vocoder_kind != RA_VOCODER_BANDPASS) return fail(RA_EINVAL, "unknown vocoder_kind");
   if (c.vocoder_kind == RA_VOCODER_BANDPASS && !(c.vocoder_env_follower_cutoff_ratio > 0.f)) return fail(RA_EINVAL, "vocoder_env_follower_cutoff_ratio must be > 0");
+  if (c.post != RA_POST_NONE && c.post != RA_POST_LIMIT) return fail(RA_EINVAL, "unknown post (RA_POST_NONE / RA_POST_LIMIT)");
   if (c.carrier_n_channels < 0 || c.carrier_n_channels > RA_MAX_CHANNELS) return fail(RA_EINVAL, "carrier_n_channels must be in 0..256");
   if (c.carrier_n_channels > 0 && c.vocoder_carrier_noise_volume != 0.f)
     return fail(RA_EINVAL, "vocoder_carrier_noise_volume must be 0: the noise voice plays a sound buffer of cpp.algorithms, which is absent (DESIGN.md §8)");
@@ -362,6 +363,7 @@ int build_tables(ra_context *c) {
   p.fb_gain = cfg.analysis_output_feedback_gain;
   p.fb_sz = std::max(0, static_cast<int>(0.5f + cfg.output_delay_seconds * cfg.sample_rate)); // lib.cpp:1638-1639
   p.voc_enabled = (cfg.voice_volume != 0.f || cfg.carrier_volume != 0.f || cfg.vocoder_volume != 0.f) ? 1 : 0;
+  p.post_limit = cfg.post == RA_POST_LIMIT ? 1 : 0;
   p.voc_kind = cfg.vocoder_kind;
   p.car_P = p.voc_enabled ? cfg.carrier_n_channels : 0; // nothing hears the carrier synth while every vocoder volume is 0
   p.car_Ppad = ((p.car_P + 63) / 64) * 64;
@@ -417,6 +419,7 @@ int alloc_state(ra_context *c) {
     if ((r = dev_alloc(c, &b.voc_sig_prev, S * 4 * p.voc_S))) return r;
   }
   if (p.voc_enabled && p.voc_kind == RA_VOCODER_BANDPASS && (r = dev_alloc(c, &b.bank_state, S * 5 * 64))) return r;
+  if (p.post_limit && (r = dev_alloc(c, &b.lim_state, S * 2))) return r;
   if (p.car_P > 0) {
     if ((r = dev_alloc(c, &b.car_sd, S * SD_COUNT * p.car_Ppad))) return r;
     if ((r = dev_alloc(c, &b.car_si, S * SI_COUNT * p.car_Ppad))) return r;
@@ -441,6 +444,11 @@ int init_state(ra_context *c) {
   HIP_TRY(hipMemsetAsync(b.chan_held, 0, S * p.P * sizeof(int32_t), c->stream));
   HIP_TRY(hipMemsetAsync(b.chan_minch, 0, S * p.P * sizeof(int32_t), c->stream));
   HIP_TRY(hipMemsetAsync(b.error_flags, 0, sizeof(int32_t), c->stream));
+  if (b.lim_state) { // Limiter{}: compression = target = 1
+    std::vector<double> one(S * 2, 1.0);
+    HIP_TRY(hipMemcpyAsync(b.lim_state, one.data(), one.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
   if (b.bank_state) HIP_TRY(hipMemsetAsync(b.bank_state, 0, S * 5 * 64 * sizeof(double), c->stream)); // Filter<> starts from rest
   if (p.car_P > 0) { // fresh elements: envelopes Done2, Phased angle 0 / increments 0 / aliasing gain 1, sine phasor 1 (audioelement.h:1473-1476,2438-2441)
     std::vector<double> sd(S * SD_COUNT * p.car_Ppad, 0.0), ext(S * CX_COUNT * p.car_Ppad, 0.0);
@@ -530,6 +538,12 @@ int ensure_scratch(ra_context *c, int64_t nfb, int64_t n, int n_chunks) {
   b.frames_cap = sc.frames_cap; b.seg_cap = sc.seg_cap;
   b.pl_pitch = sc.pl_pitch; b.pl_vol = sc.pl_vol; b.pl_key = sc.pl_key; b.pl_count = sc.pl_count;
   b.cmd = sc.cmd; b.cmd_non = sc.cmd_non; b.seg_sd = sc.seg_sd; b.seg_si = sc.seg_si;
+  if (p.post_limit && n > b.post_cap) {
+    HIP_TRY(hipDeviceSynchronize());
+    dev_free(c, b.post_d);
+    b.post_cap = n;
+    if ((r = dev_alloc(c, &b.post_d, (size_t)p.n_streams * n * 2, false))) return r;
+  }
   if (p.fb_gain != 0.f && n > b.fb_block_cap) {
     HIP_TRY(hipDeviceSynchronize());
     dev_free(c, b.fb_block);
@@ -664,7 +678,8 @@ int stage_carrier_events(ra_context *c, int64_t t0, int64_t n) {
 // streams chained by events.  Tracking and propagation are dependency chains over frames that occupy a few hundred
 // wavefronts; cutting the block lets the throughput kernels (analysis of later chunks, render of earlier ones) fill the
 // rest of the chip meanwhile.  Results do not depend on the cut (each chunk continues the carried state exactly).
-int process_block_impl(ra_context *c, const float *d_voice, const float *d_carrier, int64_t n, float *d_out, double *d_out_d, bool async, bool &started) {
+int process_block_impl(ra_context *c, const float *d_voice, const float *d_carrier, int64_t n, float *d_out_final, double *d_out_d_caller, bool async, bool &started,
+                       bool apply_post) {
   if (n <= 0) return RA_OK;
   HIP_TRY(hipSetDevice(c->device));
   RaParams &p = c->p;
@@ -696,6 +711,10 @@ int process_block_impl(ra_context *c, const float *d_voice, const float *d_carri
   c->b.dbg_clk = c->dbg_clk;
   const RaBuffers &b = c->b;
   hipStream_t user = c->stream;
+  // post "limit": the render leaves the double mix in post_d and the limiter kernel produces the float output (and the mono publication)
+  const bool limit = p.post_limit && apply_post && d_out_final;
+  float *d_out = limit ? nullptr : d_out_final;
+  double *d_out_d = limit ? b.post_d : d_out_d_caller;
   auto launch_vocoder = [&](hipStream_t st) { // K6 (when the synth supplies the carrier) then K4 / K7
     if (car_gen) {
       const std::vector<RaCarEv> &flat = c->car_upload[c->parity];
@@ -730,6 +749,7 @@ int process_block_impl(ra_context *c, const float *d_voice, const float *d_carri
         RA_TRY(timed_launch(c, ST_PROPAGATE, user, [&] { ra_launch_synth_propagate(p, b, sp, user); }));
         RA_TRY(timed_launch(c, ST_RENDER, user, [&] { ra_launch_synth_render(p, b, sp, d_out, d_out_d, user); }));
       }
+      if (limit) RA_TRY(timed_launch(c, ST_HISTORY, user, [&] { ra_launch_limiter(p, b, sp.ct0 - t0, sp.ct1 - t0, n, d_out_final, user); }));
       fb0 = fb1;
       fb1 = std::min(nfb, fb0 + per);
       ++piece;
@@ -746,6 +766,7 @@ int process_block_impl(ra_context *c, const float *d_voice, const float *d_carri
       RA_TRY(timed_launch(c, ST_PROPAGATE, user, [&] { ra_launch_synth_propagate(p, b, sp, user); }));
       RA_TRY(timed_launch(c, ST_RENDER, user, [&] { ra_launch_synth_render(p, b, sp, d_out, d_out_d, user); }));
     }
+    if (limit) RA_TRY(timed_launch(c, ST_HISTORY, user, [&] { ra_launch_limiter(p, b, 0, n, n, d_out_final, user); }));
   } else {
     static const int prio_mode = std::getenv("RA_PIPELINE_PRIO") ? std::atoi(std::getenv("RA_PIPELINE_PRIO")) : 1;
     if (!c->pipe_ready) {
@@ -849,6 +870,7 @@ int process_block_impl(ra_context *c, const float *d_voice, const float *d_carri
       HIP_TRY(hipStreamWaitEvent(sR, c->ev_chunk[2][i], 0));
       RA_TRY(timed_launch(c, ST_RENDER, sR, [&] { ra_launch_synth_render(p, b, sp, d_out, d_out_d, sR); }));
     }
+    if (limit) RA_TRY(timed_launch(c, ST_HISTORY, sR, [&] { ra_launch_limiter(p, b, 0, n, n, d_out_final, sR); })); // behind the block's last render
     // the window history for the next block: after this block's last analysis read of it, before the next block's first (same stream)
     RA_TRY(timed_launch(c, ST_HISTORY, sA, [&] { ra_launch_roll_history(p, b, d_voice, n, sA); }));
     HIP_TRY(hipEventRecord(sc.ev_track_done, sT));
@@ -869,10 +891,10 @@ int process_block_impl(ra_context *c, const float *d_voice, const float *d_carri
 
 // A block either completes, or fails before it touched any stream state (bad argument, allocation failure: the call can be retried), or
 // fails midway: then the context is poisoned until ra_reset (include/resynth_amd.h).
-int process_block(ra_context *c, const float *d_voice, const float *d_carrier, int64_t n, float *d_out, double *d_out_d, bool async = false) {
+int process_block(ra_context *c, const float *d_voice, const float *d_carrier, int64_t n, float *d_out, double *d_out_d, bool async = false, bool apply_post = true) {
   if (c->poisoned) return fail(RA_EINTERNAL, "an earlier block failed midway: the streams are in an undefined state until ra_reset");
   bool started = false;
-  const int r = process_block_impl(c, d_voice, d_carrier, n, d_out, d_out_d, async, started);
+  const int r = process_block_impl(c, d_voice, d_carrier, n, d_out, d_out_d, async, started, apply_post);
   if (r && started) c->poisoned = true;
   return r;
 }
@@ -1187,7 +1209,7 @@ int ra_compute(ra_context *c, int32_t stream, double *h_buffer, int32_t n) {
   if (r) return r;
   HIP_TRY(hipMemcpyAsync(c->st_voice, c->pending_voice.data(), n * sizeof(float), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->st_carrier, c->pending_carrier.data(), n * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  r = process_block(c, c->st_voice, c->st_carrier, n, nullptr, c->st_out_d);
+  r = process_block(c, c->st_voice, c->st_carrier, n, nullptr, c->st_out_d, false, false); // a compute's contribution: not post-processed
   if (r) return r;
   double tmp[RA_N_FRAMES_PER_BUFFER * 2];
   HIP_TRY(hipMemcpyAsync(tmp, c->st_out_d, n * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1316,6 +1338,85 @@ int ra_sqmag(const float *h_windows, int32_t n_windows, int32_t window_size, int
   ra_destroy(c);
   g_last_error = keep;
   return r;
+}
+
+// deduceNotesSlow as main.resynth uses it (main.resynth.cpp:39-46): see include/resynth_amd.h for what is built and why.
+int64_t ra_deduce_notes(const float *h_signal, int64_t n, int32_t sample_rate, int32_t half_window_size, int32_t window_kind, int32_t stride,
+                        int32_t device, ra_note *h_notes, int64_t cap) {
+  if (!h_signal || n < 0) return fail(RA_EINVAL, "bad signal");
+  if (half_window_size < 1 || stride < 1) return fail(RA_EINVAL, "bad half window size / stride");
+  if (cap < 0 || (cap > 0 && !h_notes)) return fail(RA_EINVAL, "bad notes buffer");
+  ra_config cfg;
+  ra_default_config(&cfg);
+  cfg.sample_rate = sample_rate;
+  cfg.window_size = 2 * half_window_size;
+  cfg.stride = stride;
+  cfg.window_kind = window_kind;
+  cfg.n_channels = 2;
+  cfg.min_volume = 0.f;            // every peak is kept ...
+  cfg.nearby_distance_tones = 0.f; // ... as an interval of its own: the frame lists are the peaks (pitch, 10^(dB/20)) in ascending pitch
+  cfg.analysis_volume = 0.f;       // nothing is synthesised
+  cfg.carrier_volume = 0.f;
+  cfg.max_pitches_per_frame = std::min(4096, std::max(64, fft_length_for(cfg.window_size) / 4));
+  ra_context *c = nullptr;
+  int r = ra_create(&cfg, 1, device, &c);
+  if (r) return r;
+  // PeriodicFFT swallows input samples 0 and 1 in the offline job: two leading zeros put frame h on signal[h * stride ...)
+  std::vector<float> in(static_cast<size_t>(n) + 2, 0.f), out((static_cast<size_t>(n) + 2) * 2);
+  std::memcpy(in.data() + 2, h_signal, sizeof(float) * static_cast<size_t>(n));
+  r = ra_process_host(c, in.data(), nullptr, n + 2, out.data());
+  std::vector<int64_t> fire, offs;
+  std::vector<double> pitch, vol;
+  int64_t nf = 0;
+  if (!r) {
+    nf = c->last_nfb;
+    fire.resize(nf + 1); offs.resize(nf + 2);
+    size_t items = static_cast<size_t>(nf) * c->p.maxr + 1;
+    pitch.resize(items); vol.resize(items);
+    int64_t got = ra_get_frame_pitches(c, 0, fire.data(), offs.data(), nf + 1, pitch.data(), vol.data(), static_cast<int64_t>(items));
+    if (got < 0) r = static_cast<int>(got);
+  }
+  std::string keep = g_last_error;
+  ra_destroy(c);
+  g_last_error = keep;
+  if (r) return r;
+  // linking, with track_pitches' scan (algo.cpp:256-305): open notes and peaks both ascend in pitch
+  struct Open { int32_t start, last; double last_pitch, sum_v, sum_pv, max_db; };
+  std::vector<Open> open, next;
+  std::vector<ra_note> notes;
+  auto close = [&](const Open &o) {
+    const double mean_pitch = o.sum_pv / o.sum_v;
+    notes.push_back({o.start, o.last, 440.0 * std::pow(2.0, (mean_pitch - 69.0) / 12.0), o.max_db});
+  };
+  for (int64_t h = 0; h < nf; ++h) {
+    next.clear();
+    size_t it = 0;
+    std::vector<char> cont(open.size(), 0);
+    for (int64_t i = offs[h]; i < offs[h + 1]; ++i) {
+      const double pt = pitch[i], v = vol[i];
+      if (!(v > 0.0)) continue;
+      const double db = 20.0 * std::log10(v);
+      int match = -1;
+      for (; it != open.size(); ++it) {
+        if (open[it].last_pitch < pt - 1.0) continue;
+        if (open[it].last_pitch <= pt + 1.0) { match = static_cast<int>(it); ++it; }
+        break;
+      }
+      if (match >= 0) {
+        Open o = open[match];
+        cont[match] = 1;
+        o.last = static_cast<int32_t>(h); o.last_pitch = pt; o.sum_v += v; o.sum_pv += pt * v; o.max_db = std::max(o.max_db, db);
+        next.push_back(o);
+      } else next.push_back({static_cast<int32_t>(h), static_cast<int32_t>(h), pt, v, pt * v, db});
+    }
+    for (size_t j = 0; j < open.size(); ++j) if (!cont[j]) close(open[j]);
+    std::stable_sort(next.begin(), next.end(), [](const Open &a, const Open &b) { return a.last_pitch < b.last_pitch; }); // sort_by_current_pitch, algo.cpp:434-439
+    open.swap(next);
+  }
+  for (const Open &o : open) close(o);
+  const int64_t total = static_cast<int64_t>(notes.size());
+  for (int64_t i = 0; i < total && i < cap; ++i) h_notes[i] = notes[i];
+  return total;
 }
 
 // One note on one driver-(A) element, starting from a given oscillator phasor.  This is what the element duck-type shim

@@ -40,6 +40,7 @@ struct RaParams {
   int car_P, car_Ppad;     // channels of the carrier synth (0 = none), padded to a multiple of 64
   float car_vol[6];        // noise, saw, triangle, square, sine, pulse volume targets (lib.cpp:978-983)
   float car_pulse_width;   // lib.cpp:984
+  int post_limit;          // post: "limit" (lib.cpp:1247-1258): the double mix goes through the limiter kernel before the float cast
   float fb_gain;   // output -> analysis feedback (lib.cpp:1626-1652): gain, and the delay in frames
   int fb_sz;
   int render_mode; // diagnostics: 0 regime renderer, 2 hop-parallel with the reference-order step, 3 with the cheap generic step
@@ -125,6 +126,10 @@ struct RaBuffers {
   int64_t fb_hist_len, fb_block_cap;
   double *dbg_sqmag;        // optional [frames][M] tap of |X|^2 (ra_sqmag), normally null
   unsigned long long *dbg_clk; // optional [64] in-kernel phase clocks (env RA_PHASE_CLOCKS=1, printed by ra_destroy), normally null
+  // ---- post: "limit" ----
+  double *post_d;           // [n_streams][n][2] the double mix of the block, read by the limiter kernel
+  int64_t post_cap;
+  double *lim_state;        // [n_streams][2] compression, target
   // ---- vocoder carrier synth (only with carrier_n_channels > 0 and a vocoder volume non-zero) ----
   double *car_sd;           // [n_streams][SD_COUNT][car_Ppad] envelope / control / sine oscillator / outer volume, like sd
   int32_t *car_si;          // [n_streams][SI_COUNT][car_Ppad]
@@ -236,6 +241,7 @@ struct RaCarEv {
   float freq, vel;
 };
 enum { CX_PH_ANGLE, CX_PH_INC, CX_PH_ALIAS, CX_COUNT };
+void ra_launch_limiter(const RaParams &p, const RaBuffers &b, int64_t r0, int64_t r1, int64_t n, float *d_out, hipStream_t st);
 void ra_launch_carrier_synth(const RaParams &p, const RaBuffers &b, int64_t t0, int64_t n, hipStream_t st);
 void ra_launch_voc_bank(const RaParams &p, const RaBuffers &b, const float *d_voice, const float *d_carrier, const double *carrier_d, int64_t t0, int64_t n,
                         hipStream_t st);

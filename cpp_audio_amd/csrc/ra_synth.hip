@@ -560,7 +560,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_serial_kernel(RaPara
   int64_t t = sp.ct0;
   for (int64_t i = 0; i <= sp.nfb; ++i) {
     const int64_t seg_end = (i < sp.nfb) ? ra_fire_sample(p.N, p.H, sp.f_lo + sp.fb0 + i) : sp.ct1;
-    render_range<false>(c, L, k, p, s, l, t, seg_end, sp.t0, sp.n, mix, out, out_d, b.fb_block ? b.fb_block + (size_t)s * sp.n : nullptr);
+    render_range<false>(c, L, k, p, s, l, t, seg_end, sp.t0, sp.n, mix, out, out_d, (b.fb_block && !p.post_limit) ? b.fb_block + (size_t)s * sp.n : nullptr);
     t = seg_end;
     if (i == sp.nfb) break;
     const RaCmd cmd = b.cmd[((size_t)s * b.frames_cap + sp.fb0 + i) * Ppad + l];
@@ -638,7 +638,7 @@ __device__ inline void render_segment(const RaParams &p, const RaBuffers &b, con
     else render_range<true>(c, L, k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
   } else render_range_fast<MONO>(c, reinterpret_cast<double *>(ra_smem_syn) + (size_t)wy * Ppad * (MONO ? TROW_MONO : TROW), k, p, s, l, seg_begin, seg_end,
                                  sp.t0, sp.n, mix, out, out_d, b.error_flags,
-                                 b.fb_block ? b.fb_block + (size_t)s * sp.n : nullptr, clk);
+                                 (b.fb_block && !p.post_limit) ? b.fb_block + (size_t)s * sp.n : nullptr, clk); // with post "limit" the limiter publishes
   if (clk.dst) { // workgroup lifetime: maximum and a histogram in steps of 200 k ticks
     const unsigned long long d = __builtin_readcyclecounter() - wg_t0;
     atomicMax(clk.dst + 39, d);

@@ -245,10 +245,7 @@ struct Preset {
 
 // the keys of saveAsPreset / restorePreset this build has no use for (read and written, never applied)
 inline const std::vector<std::string> &unsupported_keys() {
-  static const std::vector<std::string> k = {
-      "pitch_wheel_multiplier", "vocoder_carrier_noise_volume", "vocoder_carrier_saw_volume", "vocoder_carrier_triangle_volume",
-      "vocoder_carrier_square_volume", "vocoder_carrier_sine_volume", "vocoder_carrier_pulse_volume", "vocoder_carrier_pulse_width",
-      "vocoder_env_follower_cutoff_ratio"};
+  static const std::vector<std::string> k = {"pitch_wheel_multiplier"}; // (MIDI pitch wheel: no MIDI device on this path)
   return k;
 }
 
@@ -299,6 +296,14 @@ inline void apply_preset(const Preset &p, ra_config &cfg) {
   read_param(p.int32_params, "autotune_root_note_halftones_transpose", cfg.autotune_root_transpose);
   read_param(p.enum_params, "autotune_chord_frequencies", cfg.autotune_chord_frequencies);
   read_param(p.uint64_params, "autotune_bit_chord", cfg.autotune_bit_chord);
+  read_param(p.float_params, "vocoder_carrier_noise_volume", cfg.vocoder_carrier_noise_volume);
+  read_param(p.float_params, "vocoder_carrier_saw_volume", cfg.vocoder_carrier_saw_volume);
+  read_param(p.float_params, "vocoder_carrier_triangle_volume", cfg.vocoder_carrier_triangle_volume);
+  read_param(p.float_params, "vocoder_carrier_square_volume", cfg.vocoder_carrier_square_volume);
+  read_param(p.float_params, "vocoder_carrier_sine_volume", cfg.vocoder_carrier_sine_volume);
+  read_param(p.float_params, "vocoder_carrier_pulse_volume", cfg.vocoder_carrier_pulse_volume);
+  read_param(p.float_params, "vocoder_carrier_pulse_width", cfg.vocoder_carrier_pulse_width);
+  read_param(p.float_params, "vocoder_env_follower_cutoff_ratio", cfg.vocoder_env_follower_cutoff_ratio);
   read_param(p.float_params, "vocoder_modulator_window_size_seconds", cfg.vocoder_modulator_window_size_seconds);
   read_param(p.float_params, "vocoder_stride_seconds", cfg.vocoder_stride_seconds);
   read_param(p.int32_params, "vocoder_count_bands", cfg.vocoder_count_bands);
@@ -347,14 +352,14 @@ inline Preset save_as_preset(const ra_config &cfg, const Preset *carry = nullptr
   p.int32_params["autotune_root_note_halftones_transpose"] = cfg.autotune_root_transpose;
   p.enum_params["autotune_chord_frequencies"] = cfg.autotune_chord_frequencies;
   p.uint64_params["autotune_bit_chord"] = cfg.autotune_bit_chord;
-  p.float_params["vocoder_carrier_noise_volume"] = carried("vocoder_carrier_noise_volume", 0.f);
-  p.float_params["vocoder_carrier_saw_volume"] = carried("vocoder_carrier_saw_volume", 0.f);
-  p.float_params["vocoder_carrier_triangle_volume"] = carried("vocoder_carrier_triangle_volume", 0.f);
-  p.float_params["vocoder_carrier_square_volume"] = carried("vocoder_carrier_square_volume", 1.f);
-  p.float_params["vocoder_carrier_sine_volume"] = carried("vocoder_carrier_sine_volume", 0.f);
-  p.float_params["vocoder_carrier_pulse_volume"] = carried("vocoder_carrier_pulse_volume", 0.f);
-  p.float_params["vocoder_carrier_pulse_width"] = carried("vocoder_carrier_pulse_width", 0.01f);
-  p.float_params["vocoder_env_follower_cutoff_ratio"] = carried("vocoder_env_follower_cutoff_ratio", 1.f / 20.f);
+  p.float_params["vocoder_carrier_noise_volume"] = cfg.vocoder_carrier_noise_volume;
+  p.float_params["vocoder_carrier_saw_volume"] = cfg.vocoder_carrier_saw_volume;
+  p.float_params["vocoder_carrier_triangle_volume"] = cfg.vocoder_carrier_triangle_volume;
+  p.float_params["vocoder_carrier_square_volume"] = cfg.vocoder_carrier_square_volume;
+  p.float_params["vocoder_carrier_sine_volume"] = cfg.vocoder_carrier_sine_volume;
+  p.float_params["vocoder_carrier_pulse_volume"] = cfg.vocoder_carrier_pulse_volume;
+  p.float_params["vocoder_carrier_pulse_width"] = cfg.vocoder_carrier_pulse_width;
+  p.float_params["vocoder_env_follower_cutoff_ratio"] = cfg.vocoder_env_follower_cutoff_ratio;
   p.float_params["vocoder_modulator_window_size_seconds"] = cfg.vocoder_modulator_window_size_seconds;
   p.float_params["vocoder_stride_seconds"] = cfg.vocoder_stride_seconds;
   p.int32_params["vocoder_count_bands"] = cfg.vocoder_count_bands;
@@ -407,8 +412,7 @@ struct OfflineJobConfig {
 // The flow of the reference's offline job executable: job config -> RtResynthOfflineJob (WAV files) -> preset -> RtResynth(job).
 // `base` carries what a preset does not (n_channels, seeds, phase policy...); paths in the config are used as written.
 inline ra_stats run_offline_job(const OfflineJobConfig &jc, ra_config base, int device = 0) {
-  if (jc.post != Postprocessing::None)
-    throw std::runtime_error("job config: post 'limit' (cpp.algorithms Limiter, lib.cpp:1247-1258) is not built; parity runs use 'none'");
+  base.post = jc.post == Postprocessing::Limit ? RA_POST_LIMIT : RA_POST_NONE; // init_post(job.getPostprocessing()), lib.cpp:1198,1245-1275
   wav::OfflineJob job(jc.input_voice_file, jc.input_carrier_file, jc.output_file);
   base.sample_rate = job.get_samplerate();
   if (!jc.preset_file.empty()) apply_preset(Preset::from_file(jc.preset_file), base);

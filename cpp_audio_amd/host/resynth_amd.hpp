@@ -135,6 +135,42 @@ void resynth(std::vector<Note> const &notes, int const stride, int const samplin
   wav::write_f64(path_wav.string(), out.data(), out.size(), 1, sampling_rate);
 }
 
+// The body of testDeduceNotes (source/main.resynth.cpp:5-81) without its BMP plot: WAV -> deduceNotesSlow -> drop notes more than
+// 60 dB below the loudest one or without a frequency (:53-71) -> resynth() -> mono float64 WAV.  Defaults as in the reference: a
+// Gaussian half window of 400 points truncated at 4 sigma, window_center_stride 400 (:6,27).  The reference hands resynth() a literal
+// 44100 (its file's rate, :79); here it is the input file's sample rate.  Returns the notes that were rendered.
+struct DeducedNote { int32_t startFrame, endFrame; double frequency, amplitude; };
+inline std::vector<DeducedNote> deduce_notes(const std::vector<float> &mono, int sample_rate, int half_window_size = 400, int window_center_stride = 400,
+                                             int window_kind = RA_WINDOW_GAUSSIAN4, int device = 0) {
+  int64_t n = check(ra_deduce_notes(mono.data(), static_cast<int64_t>(mono.size()), sample_rate, half_window_size, window_kind, window_center_stride, device,
+                                    nullptr, 0));
+  std::vector<ra_note> raw(static_cast<size_t>(n));
+  if (n) check(ra_deduce_notes(mono.data(), static_cast<int64_t>(mono.size()), sample_rate, half_window_size, window_kind, window_center_stride, device, raw.data(), n));
+  std::vector<DeducedNote> notes(raw.size());
+  for (size_t i = 0; i < raw.size(); ++i) notes[i] = {raw[i].start_frame, raw[i].end_frame, raw[i].frequency, raw[i].amplitude_db};
+  return notes;
+}
+inline std::vector<DeducedNote> resynth_wav(const std::filesystem::path &in_wav, const std::filesystem::path &out_wav, int half_window_size = 400,
+                                            int window_center_stride = 400, int device = 0) {
+  wav::Data d = wav::read(in_wav.string());
+  if (d.samples.empty()) throw std::runtime_error("resynth_wav: no channel in '" + in_wav.string() + "'");
+  std::vector<float> mono(d.samples[0].begin(), d.samples[0].end()); // deinterlaced.begin(): the first channel (main.resynth.cpp:39)
+  std::vector<DeducedNote> notes = deduce_notes(mono, d.sample_rate, half_window_size, window_center_stride, RA_WINDOW_GAUSSIAN4, device);
+  std::vector<DeducedNote> filtered;
+  if (!notes.empty()) {
+    constexpr double maxDbSpan = 60.;
+    double max_mag = notes[0].amplitude;
+    for (auto const &v : notes) max_mag = std::max(max_mag, v.amplitude);
+    for (auto const &v : notes) {
+      if (v.amplitude < max_mag - maxDbSpan) continue;
+      if (v.frequency == 0) continue;
+      filtered.push_back(v);
+    }
+  }
+  resynth(filtered, window_center_stride, d.sample_rate, out_wav);
+  return filtered;
+}
+
 // ---- element duck type ------------------------------------------------------------------------------------------------------
 // Stands in for Enveloped<VolumeAdjusted<SineOscillatorAlgo<double>>, AHDSREnvelope<...>> in resynth.hpp's manual loop.
 // The reference drives an element with a burst of setters followed by onKeyPressed(0) / onKeyReleased(delay) and then only

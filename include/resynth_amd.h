@@ -39,6 +39,7 @@ enum { RA_PHASE_HASH = 0, RA_PHASE_ZERO = 1 };                                  
 /* the live FFT vocoder (vocoder.cpp:100-252,396-551) / the band-pass bank it replaced (vocoder.cpp:46-79,310-394,667-732: the members
  * commented out at :846-851; "32-band biquad bank" of BASELINE configs[2]) */
 enum { RA_VOCODER_FFT = 0, RA_VOCODER_BANDPASS = 1 };
+enum { RA_POST_NONE = 0, RA_POST_LIMIT = 1 };                                         /* Postprocessing, rt.resynth.lib.params.cpp:152-176 */
 
 /*
  * The parameter block of one RtResynth (the std::atomic<> members of source/rt.resynth.lib.cpp:943-999,
@@ -117,6 +118,12 @@ typedef struct ra_config {
   int32_t carrier_n_channels; /* 0..256 */
   float vocoder_carrier_noise_volume, vocoder_carrier_saw_volume, vocoder_carrier_triangle_volume, vocoder_carrier_square_volume,
       vocoder_carrier_sine_volume, vocoder_carrier_pulse_volume, vocoder_carrier_pulse_width; /* lib.cpp:978-984: 0 0 0 1 0 0 0.01 */
+
+  /* RA_POST_*: the job config's "post" (RtResynth::init_post, lib.cpp:1245-1275).  RA_POST_LIMIT runs every output frame through the
+   * limiter before the mono publication and the float cast; the Limiter itself is cpp.algorithms code that is absent here: its
+   * behaviour is this build's own declared decision (parity unpinned).  ra_compute (the ComputeFunc boundary) is never
+   * post-processed: post-processing belongs to SimpleAudioOutContext::step, after the computes. */
+  int32_t post;
 } ra_config;
 
 /*
@@ -262,6 +269,24 @@ int64_t ra_get_frame_pitches(ra_context *ctx, int32_t stream, int64_t *h_fire_sa
  */
 int64_t ra_resynth_notes(const ra_note *notes, int32_t n_notes, int32_t stride, int32_t sample_rate, int32_t device, double *h_out,
                          int64_t cap);
+
+/*
+ * Replaces deduceNotesSlow(begin, end, sample_rate, windowed_signal_stride = 1, half_window, window_center_stride, zero_padding_factor = 1,
+ * c_diffHalfToneApartLog2Freqs) as main.resynth calls it (source/main.resynth.cpp:39-46): the notes of a mono signal, for ra_resynth_notes.
+ * deduceNotesSlow is cpp.algorithms code that is absent here (PARITY UNPINNED); what is built:
+ *   - frame h = the 2 * half_window_size samples from h * window_center_stride on, windowed (window_kind, the half window mirrored),
+ *     zero padded to the next power of two, |X|^2, local maxima refined by the parabola through three dB values — the very analysis of
+ *     the rt.resynth path (findFrequenciesSqMag + extractLocalMaxFreqsMags), run by the same kernel;
+ *   - peaks are linked into notes frame by frame with the rule of track_pitches (rt.resynth.lib.algo.cpp:256-305): peaks and open notes in
+ *     ascending pitch, a peak continues the first not-yet-continued note within half a tone... (threshold: one semitone of pitch =
+ *     c_diffHalfToneApartLog2Freqs in log2 frequency), else it opens a note; a note no peak continued is closed;
+ *   - a note's frequency is the volume-weighted mean pitch of its peaks (PonderateByVolume, lib.cpp:400-403) converted back to Hz, its
+ *     amplitude the largest of their dB values; start / end frame = the first / last frame it was seen in (hop units, resynth.hpp:58-61).
+ * Notes come out ordered by closing frame, then pitch.  h_signal: HOST pointer, mono float32.  Returns the number of notes (all of them
+ * counted, the first `cap` stored; h_notes may be NULL to query) or a negative RA_E* code.
+ */
+int64_t ra_deduce_notes(const float *h_signal, int64_t n_frames, int32_t sample_rate, int32_t half_window_size, int32_t window_kind,
+                        int32_t window_center_stride, int32_t device, ra_note *h_notes, int64_t cap);
 
 /* audioelement::AHDSR (include/audioelement.h:314-335) in frames; every interpolation is itp::LINEAR on this path */
 typedef struct ra_ahdsr {

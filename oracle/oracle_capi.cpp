@@ -214,4 +214,14 @@ int64_t ora_resynth_notes(const int32_t *start, const int32_t *end, const double
   return n;
 }
 
+// deduceNotesSlow as decided in oracle_resynth.hpp; returns the number of notes, stores the first cap
+int64_t ora_deduce_notes(const float *x, int64_t n, int32_t sr, int32_t half_window_size, int32_t window_kind, int32_t stride, int32_t *start,
+                         int32_t *end, double *freq, double *amp_db, int64_t cap) {
+  std::vector<DeducedNote> notes;
+  deduce_notes(x, n, sr, half_window_size, window_kind, stride, notes);
+  int64_t total = static_cast<int64_t>(notes.size());
+  for (int64_t i = 0; i < total && i < cap; ++i) { start[i] = notes[i].startFrame; end[i] = notes[i].endFrame; freq[i] = notes[i].frequency; amp_db[i] = notes[i].amplitude; }
+  return total;
+}
+
 } // extern "C"

@@ -71,6 +71,7 @@ typedef struct ora_config {
   int32_t carrier_n_channels;              /* channels of the vocoder carrier synth (reference 2 * 127, lib.cpp:212-221); 0 = none */
   float vocoder_carrier_noise_volume, vocoder_carrier_saw_volume, vocoder_carrier_triangle_volume, vocoder_carrier_square_volume,
       vocoder_carrier_sine_volume, vocoder_carrier_pulse_volume, vocoder_carrier_pulse_width; /* lib.cpp:978-984: 0 0 0 1 0 0 0.01 */
+  int32_t post; /* 0 none, 1 limit (params.cpp:152-176, lib.cpp:1245-1275) */
 } ora_config;
 
 /* one note event of the vocoder carrier synth (RtResynth::onInputMidiEvent, lib.cpp:1518-1545) */

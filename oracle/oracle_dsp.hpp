@@ -225,6 +225,23 @@ struct OnePoleLowPass {
   double filtered() const { return y; }
 };
 
+// Limiter<double> (lib.cpp:908, 1253-1258): default-constructed, feedOneFrame(CArray<2, double>) in place, "compressed and limited",
+// getTargetCompressionLevel() (:891).  Everything else is cpp.algorithms.  Decision: a stereo-linked feed-forward limiter whose constants
+// are in frames — the gain both channels need for a 0.95 ceiling; a target that drops to it at once and recovers by 2e-5 of the
+// remaining distance per frame; the applied compression following its target by 1 % per frame; the product clipped to [-1, 1].
+struct Limiter {
+  double compression = 1.0, target = 1.0;
+  void feedOneFrame(double *a) {
+    double const peak = std::max(std::abs(a[0]), std::abs(a[1]));
+    double needed = 1.0;
+    if (peak > 0.95) needed = 0.95 / peak;
+    target = needed < target ? needed : target + (1.0 - target) * 2e-5;
+    compression = compression + (target - compression) * 0.01;
+    for (int j = 0; j < 2; ++j) a[j] = std::min(1.0, std::max(-1.0, a[j] * compression));
+  }
+  double getTargetCompressionLevel() const { return target; }
+};
+
 // itp::interpolate(LINEAR, t, b, c, d) (audioelement.h:733-737, 994-998): Penner form.
 inline double itp_linear(double t, double b, double c, double d) { return c * t / d + b; }
 

@@ -257,6 +257,7 @@ struct RtResynthOffline {
   Stepper stepper;
   Synth synth;
   Vocoder vocoder;
+  Limiter limiter;              // lib.cpp:908
   CarrierSynth vocoder_carrier; // lib.cpp:910
   NoteIdsGenerator vocoder_carrier_noteids;
   std::vector<ora_carrier_event> carrier_events; // sorted by sample; consumed by run()
@@ -326,7 +327,8 @@ struct RtResynthOffline {
       init.pulse_width = c.vocoder_carrier_pulse_width;
       vocoder_carrier.initializer = init;
     }
-    stepper.post = [this](double *buf, int frames) { // init_post, lib.cpp:1262-1272 (post "none": only the mono publication)
+    stepper.post = [this](double *buf, int frames) { // init_post, lib.cpp:1245-1275: the limiter (post "limit"), then the mono publication
+      if (cfg.post == 1) for (int i = 0; i < frames; ++i) limiter.feedOneFrame(buf + 2 * i);
       for (int i = 0; i < frames; ++i) last_published = static_cast<float>(buf[2 * i] + buf[2 * i + 1]);
     };
     periodic_fft.op.window_kind = c.window_kind;
@@ -482,6 +484,57 @@ inline void resynth_notes(std::vector<DeducedNote> const &notes, int stride, int
     ae->env.onKeyReleased(stride + note.endFrame - note.startFrame);
   }
   while (!recordFrame()) {}
+}
+
+// ---- deduceNotesSlow as main.resynth calls it (main.resynth.cpp:39-46) -------------------------------------------------------
+// cpp.algorithms code, absent: PARITY UNPINNED.  Certain from the call site: a half window (mirrored into a full one), a hop
+// (`window_center_stride`), zero padding factor 1, a "half tone apart in log2 frequency" constant, and the result type
+// DeducedNote{startFrame, endFrame (hop units, resynth.hpp:58-61), frequency (Hz; 0 is possible: filtered at main.resynth.cpp:66-68),
+// amplitude (dB: :55-65, resynth.hpp:86)}.  Decision (the same as the product's, include/resynth_amd.h: ra_deduce_notes): the rt.resynth
+// analysis per frame, then track_pitches' scan links peaks within one semitone into notes; frequency = volume-weighted mean pitch in
+// Hz, amplitude = the largest dB, frames = first / last sighting.
+inline void deduce_notes(const float *x, int64_t n, int sample_rate, int half_window_size, int window_kind, int stride, std::vector<DeducedNote> &out) {
+  out.clear();
+  Midi midi;
+  SqMagOp op;
+  op.window_kind = window_kind;
+  int const N = 2 * half_window_size;
+  op.init_data(N);
+  std::vector<double> win(N);
+  std::vector<FreqMag> peaks;
+  struct Open { int32_t start, last; double last_pitch, sum_v, sum_pv, max_db; };
+  std::vector<Open> open, next;
+  auto close = [&](Open const &o) { out.push_back({o.start, o.last, 440.0 * std::pow(2.0, (o.sum_pv / o.sum_v - 69.0) / 12.0), o.max_db}); };
+  for (int32_t h = 0; static_cast<int64_t>(h) * stride + N <= n; ++h) {
+    for (int i = 0; i < N; ++i) win[i] = static_cast<double>(x[static_cast<int64_t>(h) * stride + i]);
+    op(win.data(), N);
+    extract_local_max_freqs_mags(sample_rate, op.result, peaks);
+    next.clear();
+    std::vector<char> cont(open.size(), 0);
+    size_t it = 0;
+    for (auto const &pk : peaks) {
+      auto pitch = midi.frequency_to_midi_pitch_analysis(pk.freq);
+      if (!pitch) continue;
+      double const v = db_to_mag_analysis(pk.mag_db);
+      if (!(v > 0.0)) continue;
+      int match = -1;
+      for (; it != open.size(); ++it) { // track_pitches, algo.cpp:256-305, with a threshold of one semitone
+        if (open[it].last_pitch < *pitch - 1.0) continue;
+        if (open[it].last_pitch <= *pitch + 1.0) { match = static_cast<int>(it); ++it; }
+        break;
+      }
+      if (match >= 0) {
+        Open o = open[match];
+        cont[match] = 1;
+        o.last = h; o.last_pitch = *pitch; o.sum_v += v; o.sum_pv += *pitch * v; o.max_db = std::max(o.max_db, pk.mag_db);
+        next.push_back(o);
+      } else next.push_back({h, h, *pitch, v, *pitch * v, pk.mag_db});
+    }
+    for (size_t j = 0; j < open.size(); ++j) if (!cont[j]) close(open[j]);
+    std::stable_sort(next.begin(), next.end(), [](Open const &a, Open const &b) { return a.last_pitch < b.last_pitch; });
+    open.swap(next);
+  }
+  for (auto const &o : open) close(o);
 }
 
 } // namespace ora

@@ -39,7 +39,7 @@ class OraConfig(C.Structure):
         ("vocoder_carrier_noise_volume", C.c_float), ("vocoder_carrier_saw_volume", C.c_float),
         ("vocoder_carrier_triangle_volume", C.c_float), ("vocoder_carrier_square_volume", C.c_float),
         ("vocoder_carrier_sine_volume", C.c_float), ("vocoder_carrier_pulse_volume", C.c_float),
-        ("vocoder_carrier_pulse_width", C.c_float),
+        ("vocoder_carrier_pulse_width", C.c_float), ("post", C.c_int32),
     ]
 
 
@@ -252,6 +252,21 @@ def resynth_notes(start, end, freq, amp_db, stride, sr, cap=1 << 24):
                                 C.c_int32(sr), _p(out), C.c_int64(cap))
     assert n <= cap
     return out[:n]
+
+
+def deduce_notes(x, sr, half_window_size, stride, window_kind=0, cap=1 << 20):
+    """(start, end, freq, amp_db) arrays of the notes the oracle deduces from the mono float32 signal x."""
+    x = np.ascontiguousarray(x, np.float32)
+    st = np.zeros(cap, np.int32)
+    en = np.zeros(cap, np.int32)
+    fr = np.zeros(cap, np.float64)
+    am = np.zeros(cap, np.float64)
+    L = lib()
+    L.ora_deduce_notes.restype = C.c_int64
+    n = L.ora_deduce_notes(_p(x), C.c_int64(len(x)), C.c_int32(sr), C.c_int32(half_window_size), C.c_int32(window_kind), C.c_int32(stride),
+                           _p(st), _p(en), _p(fr), _p(am), C.c_int64(cap))
+    assert n <= cap
+    return st[:n], en[:n], fr[:n], am[:n]
 
 
 def det_math(x, which):
