@@ -81,6 +81,7 @@ EXPORTED_SYMBOLS = [
     "ra_feed", "ra_compute", "ra_get_stats", "ra_get_events", "ra_get_frame_pitches", "ra_resynth_notes", "ra_sqmag",
     "ra_set_profiling", "ra_get_kernel_ms", "ra_get_kernel_launches", "ra_render_note",
     "ra_carrier_events", "ra_get_carrier", "ra_set_pipeline_serial", "ra_deduce_notes",
+    "ra_voice_default_config", "ra_voice_create", "ra_voice_destroy", "ra_voice_events", "ra_voice_process_host", "ra_voice_dropped_note_ons",
 ]
 
 _lib = None
@@ -304,6 +305,76 @@ def deduce_notes(signal, sr, half_window_size, window_center_stride, window_kind
     if n:
         _check(lib().ra_deduce_notes(_p(x), len(x), sr, half_window_size, window_kind, window_center_stride, device, _p(notes), n))
     return notes
+
+
+class RaVoiceConfig(C.Structure):
+    """Mirror of include/resynth_amd.h:ra_voice_config (the SWEEP program of gen.voice, de-normalised)."""
+    _fields_ = [("sample_rate", C.c_int32), ("n_channels", C.c_int32), ("length_ms", C.c_float), ("length_exponent", C.c_float),
+                ("xfade_length_seconds", C.c_float), ("low_freq", C.c_float), ("high_freq", C.c_float), ("sine_gain", C.c_float),
+                ("loudness_level", C.c_float), ("loudness_compensation_amount", C.c_float), ("loudness_ref_freq_index", C.c_int32),
+                ("pan", C.c_float), ("random_pan", C.c_int32), ("seed", C.c_uint64)]
+
+
+VOICE_EVENT_DTYPE = np.dtype([("sample", "<i8"), ("stream", "<i4"), ("type", "<i4"), ("noteid", "<i8"), ("frequency", "<f4"), ("velocity", "<f4")])
+
+
+def voice_default_config(**kw):
+    c = RaVoiceConfig()
+    _check(lib().ra_voice_default_config(C.byref(c)))
+    for k, v in kw.items():
+        if not hasattr(c, k):
+            raise AttributeError(k)
+        setattr(c, k, v)
+    return c
+
+
+class Voice:
+    """n_streams gen.voice synths in SWEEP mode on one GPU (ra_voice_create .. ra_voice_destroy)."""
+
+    def __init__(self, cfg, n_streams, device=0):
+        self.n_streams = int(n_streams)
+        self._h = C.c_void_p()
+        L = lib()
+        L.ra_voice_create.argtypes = [C.POINTER(RaVoiceConfig), C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        L.ra_voice_destroy.argtypes = [C.c_void_p]
+        L.ra_voice_destroy.restype = None
+        L.ra_voice_events.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.ra_voice_process_host.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        L.ra_voice_dropped_note_ons.argtypes = [C.c_void_p]
+        L.ra_voice_dropped_note_ons.restype = C.c_int64
+        _check(L.ra_voice_create(C.byref(cfg), self.n_streams, int(device), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().ra_voice_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def events(self, rows):
+        """rows: (sample, stream, type, noteid, frequency, velocity)."""
+        ev = np.zeros(len(rows), VOICE_EVENT_DTYPE)
+        for i, r in enumerate(rows):
+            ev[i] = tuple(r)
+        _check(lib().ra_voice_events(self._h, _p(ev), len(ev)))
+
+    def process(self, n_frames):
+        out = np.empty((self.n_streams, int(n_frames), 2), np.float32)
+        _check(lib().ra_voice_process_host(self._h, int(n_frames), _p(out)))
+        return out
+
+    def dropped_note_ons(self):
+        return _check(lib().ra_voice_dropped_note_ons(self._h))
 
 
 def resynth_notes(start, end, freq, amp_db, stride, sr, device=0):

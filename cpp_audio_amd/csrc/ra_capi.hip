@@ -1548,4 +1548,167 @@ int64_t ra_resynth_notes(const ra_note *notes, int32_t n_notes, int32_t stride, 
   return T;
 }
 
+// ---- gen.voice, SWEEP mode --------------------------------------------------------------------------------------------------------
+struct ra_voice {
+  ra_voice_config cfg;
+  RaVoiceParams p;
+  int device = 0, n_streams = 0, Ppad = 0;
+  int64_t t = 0;
+  void *state = nullptr;
+  int32_t *dropped = nullptr, *ev_begin = nullptr;
+  RaVoiceEv *ev = nullptr;
+  int64_t ev_cap = 0;
+  float *out = nullptr;
+  int64_t out_cap = 0;
+  std::vector<std::deque<RaVoiceEv>> pending;
+  std::vector<int64_t> last_sample;
+};
+
+int ra_voice_default_config(ra_voice_config *c) {
+  if (!c) return fail(RA_EINVAL, "null config");
+  std::memset(c, 0, sizeof(*c));
+  c->sample_rate = 48000;
+  c->n_channels = 16;
+  c->length_ms = 73.f; c->length_exponent = 5.f; c->xfade_length_seconds = 0.0109f; // make_sweep(LINEAR, 73, 5, 0.0109, ...), gen.voice.h:752-754
+  c->low_freq = 100.f; c->high_freq = 20000.f;
+  c->sine_gain = 1.f;                                                               // make_common, gen.voice.h:497-529
+  c->loudness_level = 30.f; c->loudness_compensation_amount = 1.f; c->loudness_ref_freq_index = 5; // include/loudness_init_values.h
+  c->pan = 0.f; c->random_pan = 0;
+  return RA_OK;
+}
+
+int ra_voice_create(const ra_voice_config *cfg, int32_t n_streams, int32_t device, ra_voice **out) {
+  if (!cfg || !out) return fail(RA_EINVAL, "null argument");
+  *out = nullptr;
+  const ra_voice_config &c = *cfg;
+  if (n_streams < 1) return fail(RA_EINVAL, "n_streams must be >= 1");
+  if (c.sample_rate < 1000) return fail(RA_EINVAL, "sample_rate is too small");
+  if (c.n_channels < 1 || c.n_channels > RA_MAX_CHANNELS) return fail(RA_EINVAL, "n_channels must be in 1..256");
+  if (!(c.low_freq > 0.f) || !(c.high_freq > 0.f)) return fail(RA_EINVAL, "the sweep's ends must be positive frequencies (LogRamp, audioelement.h:2566-2567)");
+  if (!(c.length_ms > 0.f) || !(c.length_exponent >= 0.f) || c.length_exponent > 7.f) return fail(RA_EINVAL, "bad length / length exponent");
+  if (!(c.xfade_length_seconds >= 0.f)) return fail(RA_EINVAL, "bad xfade length");
+  if (c.loudness_ref_freq_index < 0 || c.loudness_ref_freq_index > 15) return fail(RA_EINVAL, "loudness_ref_freq_index must be in 0..15");
+  if (!(c.loudness_compensation_amount >= 0.f && c.loudness_compensation_amount <= 1.f)) return fail(RA_EINVAL, "loudness_compensation_amount must be in 0..1");
+  RaVoiceParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.sample_rate = c.sample_rate;
+  p.P = c.n_channels;
+  p.xfade_len = static_cast<int>(0.5f + (c.xfade_length_seconds * c.sample_rate));       // setEnvelopeCharacTime, gen.voice.h:893
+  const int min_dt = c.sample_rate / 1000;                                                  // setAHDSR, audioelement.h:923-952
+  p.envA = std::max(p.xfade_len, min_dt);
+  p.envR = std::max(p.xfade_len, min_dt);
+  { // SoundEngine::do_initialize + create_sweep's node 0 (soundengine.h:700-713,1001-1044): length * 2^exponent, in frames
+    if (ms_to_frames(c.length_ms, c.sample_rate) <= 0) return fail(RA_EINVAL, "length is too small");
+    float len = c.length_ms;
+    len *= std::pow(2.f, c.length_exponent);
+    const float n_frames = static_cast<float>(ms_to_frames(len, c.sample_rate));
+    if (!(n_frames > 0.f)) return fail(RA_EINVAL, "length is too small");
+    p.n_frames = n_frames;
+    p.start_sample = 0.f * n_frames; // phase_ratio1 (never set in SWEEP mode: 0) * n_frames
+    if (static_cast<int>(.5f + p.n_frames) - p.xfade_len < 0) return fail(RA_EINVAL, "the sweep is shorter than its cross-fade (soundengine.h:796)");
+  }
+  p.inc_low = static_cast<double>(2 * c.low_freq / c.sample_rate);   // freq_to_angle_increment<float>, sound.functions.h:58-62
+  p.inc_high = static_cast<double>(2 * c.high_freq / c.sample_rate);
+  p.base_volume = (static_cast<double>(0.1f) * 1.) / static_cast<double>(0.1f); // LoudnessVolumeAdjusted::baseVolume, audioelement.h:1279,2370
+  p.sine_gain = c.sine_gain;
+  p.log_ratio = c.loudness_compensation_amount;
+  p.pan = c.pan; p.random_pan = c.random_pan ? 1 : 0; p.seed = c.seed;
+  { // include/loudness.h:199-229
+    int li = static_cast<int>(c.loudness_level * .1f) - 2;
+    li = std::max(0, li); li = std::min(8, li);
+    for (int i = 0; i < 29; ++i) { p.loud_freqs[i] = kLoudFreqs[i]; p.loud_elv[i] = equal_loudness_volume(i, (li + 2) * 10.f); }
+    p.max_db = p.loud_elv[c.loudness_ref_freq_index];
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(RA_ENODEVICE, "no HIP device visible (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(RA_EINVAL, "device ordinal out of range");
+  HIP_TRY(hipSetDevice(device));
+  ra_voice *v = new ra_voice();
+  v->cfg = c; v->p = p; v->device = device; v->n_streams = n_streams; v->Ppad = ((p.P + 63) / 64) * 64;
+  v->pending.assign(n_streams, {});
+  v->last_sample.assign(n_streams, 0);
+  const int count = n_streams * v->Ppad;
+  hipError_t e = hipMalloc(&v->state, ra_voice_state_bytes() * count);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v->dropped), sizeof(int32_t) * n_streams);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v->ev_begin), sizeof(int32_t) * (n_streams + 1));
+  if (e == hipSuccess) e = hipMemset(v->dropped, 0, sizeof(int32_t) * n_streams);
+  if (e == hipSuccess) { ra_voice_launch_init(v->state, count, nullptr); e = hipDeviceSynchronize(); }
+  if (e != hipSuccess) { ra_voice_destroy(v); return fail(RA_EHIP, std::string("ra_voice_create: ") + hipGetErrorString(e)); }
+  *out = v;
+  return RA_OK;
+}
+
+void ra_voice_destroy(ra_voice *v) {
+  if (!v) return;
+  (void)hipSetDevice(v->device);
+  (void)hipDeviceSynchronize();
+  (void)hipFree(v->state); (void)hipFree(v->dropped); (void)hipFree(v->ev_begin); (void)hipFree(v->ev); (void)hipFree(v->out);
+  delete v;
+}
+
+int ra_voice_events(ra_voice *v, const ra_voice_event *ev, int64_t n) {
+  if (!v) return fail(RA_EINVAL, "null context");
+  if (n < 0 || (n > 0 && !ev)) return fail(RA_EINVAL, "bad events");
+  for (int64_t i = 0; i < n; ++i) {
+    const ra_voice_event &e = ev[i];
+    const std::string at = "voice event " + std::to_string(i) + ": ";
+    if (e.stream < 0 || e.stream >= v->n_streams) return fail(RA_EINVAL, at + "stream out of range");
+    if (e.type != 0 && e.type != 1) return fail(RA_EINVAL, at + "type must be 0 (NoteOn) or 1 (NoteOff)");
+    if (e.sample < v->t) return fail(RA_EINVAL, at + "its frame has already been processed");
+    if (e.sample < v->last_sample[e.stream]) return fail(RA_EINVAL, at + "samples of a stream must not decrease");
+    if (e.type == 0 && !(e.velocity > 0.f)) return fail(RA_EINVAL, at + "a note-on needs a velocity > 0 (gen.crtp.h:391)");
+    if (e.type == 0 && !(e.frequency > 0.f)) return fail(RA_EINVAL, at + "a note-on needs a frequency > 0 (soundengine.h:1012-1015)");
+    RaVoiceEv d;
+    d.sample = e.sample; d.noteid = e.noteid; d.type = e.type; d.pad = 0; d.freq = e.frequency; d.vel = e.velocity;
+    v->pending[e.stream].push_back(d);
+    v->last_sample[e.stream] = e.sample;
+  }
+  return RA_OK;
+}
+
+int ra_voice_process_host(ra_voice *v, int64_t n, float *h_out) {
+  if (!v) return fail(RA_EINVAL, "null context");
+  if (n < 0 || (n > 0 && !h_out)) return fail(RA_EINVAL, "bad output");
+  if (n == 0) return RA_OK;
+  HIP_TRY(hipSetDevice(v->device));
+  const int S = v->n_streams;
+  std::vector<RaVoiceEv> flat;
+  std::vector<int32_t> begin(S + 1, 0);
+  for (int s = 0; s < S; ++s) {
+    begin[s] = static_cast<int32_t>(flat.size());
+    auto &q = v->pending[s];
+    while (!q.empty() && q.front().sample < v->t + n) { flat.push_back(q.front()); q.pop_front(); }
+  }
+  begin[S] = static_cast<int32_t>(flat.size());
+  if (static_cast<int64_t>(flat.size()) > v->ev_cap) {
+    (void)hipFree(v->ev);
+    v->ev = nullptr;
+    v->ev_cap = std::max<int64_t>(256, 2 * static_cast<int64_t>(flat.size()));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&v->ev), sizeof(RaVoiceEv) * v->ev_cap));
+  }
+  if (n > v->out_cap) {
+    (void)hipFree(v->out);
+    v->out = nullptr;
+    v->out_cap = n;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&v->out), sizeof(float) * 2 * static_cast<size_t>(S) * n));
+  }
+  if (!flat.empty()) HIP_TRY(hipMemcpy(v->ev, flat.data(), sizeof(RaVoiceEv) * flat.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(v->ev_begin, begin.data(), sizeof(int32_t) * begin.size(), hipMemcpyHostToDevice));
+  ra_voice_launch(v->p, v->state, v->ev, v->ev_begin, v->dropped, S, v->t, n, v->out, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(h_out, v->out, sizeof(float) * 2 * static_cast<size_t>(S) * n, hipMemcpyDeviceToHost));
+  v->t += n;
+  return RA_OK;
+}
+
+int64_t ra_voice_dropped_note_ons(ra_voice *v) {
+  if (!v) return fail(RA_EINVAL, "null context");
+  HIP_TRY(hipSetDevice(v->device));
+  std::vector<int32_t> d(v->n_streams);
+  HIP_TRY(hipMemcpy(d.data(), v->dropped, sizeof(int32_t) * d.size(), hipMemcpyDeviceToHost));
+  int64_t tot = 0;
+  for (int32_t x : d) tot += x;
+  return tot;
+}
+
 } // extern "C"

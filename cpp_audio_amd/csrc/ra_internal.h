@@ -255,6 +255,24 @@ struct RaSpan {
   int64_t seg0;       // first slot of this chunk's nfb + 1 segments in seg_sd / seg_si
 };
 
+// ---- gen.voice, SWEEP mode (ra_voice.hip) ----
+struct RaVoiceParams {
+  int sample_rate, P;
+  int envA, envR, xfade_len;       // setAHDSR(AHDSR{xfade_len, 0, 0, xfade_len, 1.}) and setEnvelopeCharacTime
+  double inc_low, inc_high;        // freq_to_angle_increment<float>(LOW_FREQ / HIGH_FREQ), widened
+  double n_frames, start_sample;   // the ramp spec's duration and start (phase_ratio1 * n_frames = 0 in SWEEP mode)
+  double base_volume;              // Element::baseVolume
+  float sine_gain, log_ratio, max_db, pan;
+  int random_pan;
+  uint64_t seed;
+  float loud_freqs[29], loud_elv[29]; // include/loudness.h:9-39 and the equal-loudness row of the configured level (:199-216)
+};
+struct RaVoiceEv { int64_t sample, noteid; int32_t type, pad; float freq, vel; };
+size_t ra_voice_state_bytes();
+void ra_voice_launch_init(void *state, int count, hipStream_t st);
+void ra_voice_launch(const RaVoiceParams &p, void *state, const RaVoiceEv *ev, const int32_t *ev_begin, int32_t *dropped, int n_streams, int64_t t0, int64_t n,
+                     float *d_out, hipStream_t st);
+
 // launchers (defined next to their kernels)
 void ra_launch_analysis(const RaParams &p, const RaBuffers &b, const float *d_voice, int64_t t0, int64_t n, int64_t f_lo, int64_t fb0, int64_t nfb_chunk,
                         int64_t nfb_total, hipStream_t st);

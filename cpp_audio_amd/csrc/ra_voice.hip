@@ -1,0 +1,251 @@
+// K9 — gen.voice, SWEEP mode (first slice): voice::Impl_<..., Mode::SWEEP, ...> (reference include/gen.voice.h:1087-1190)
+// = ImplCRTP::compute / onEvent (include/gen.crtp.h:350-622; SynchronizePhase::No, DefaultStartPhase::Zero) over
+// VolumeAdjusted<SoundEngine<SWEEP, 2, ...>> (include/soundengine.h:240-1127), its ramps being
+//   StereoPanned<VolumeAdjusted<Enveloped<FreqCtrl_<Mix<LoudnessVolumeAdjusted<SineOscillatorAlgo<double>>>, LogRamp<double>>, AHDSREnvelope>>>.
+//
+// The same skeleton as the other synth kernels: one workgroup per stream, lane = channel, samples in order in 16-sample tiles, the
+// channels summed in channel order.  What SWEEP reduces the sound engine to (the CPU restatement keeps the general shape):
+//   * the Markov chain of create_sweep (soundengine.h:697-720) is one certain transition whose LEAVE lambda builds the single ramp spec,
+//     and both mersenne<> draws on the way are inert (min_exp == max_exp): initialize_sweep is deterministic arithmetic, done at note-on;
+//   * of the engine's three ramps only one ever plays: get_ramps (:275-290) hands playNextSpec the LAST finished ramp, all three are
+//     finished when a note starts, and a SWEEP note has one spec — a lane carries that one ramp;
+//   * reference behaviour kept as it is: Mix::angleIncrements() never exceeds 0 (audioelement.h:1856-1865), so the volume filters see
+//     the control's `from`; a note-off silences the element at once and leaves its ramp unfinished (soundengine.h:345-353), which
+//     makes the channel unavailable for good (isEnvelopeFinished_internal, :457-467).
+// Per sample a ramp costs a sincos (the increment moves every sample), a float pow (the equal-loudness volume, include/loudness.h:246-274)
+// and three one-pole updates with re-derived coefficients: ~300 instructions on one wave per stream — correct first, not yet fast.
+#include "ra_chan.cuh"
+#include <algorithm>
+
+extern __shared__ __align__(16) unsigned char ra_smem_voice[];
+
+namespace {
+
+struct VoiceChan {
+  Chan c;   // the ramp: envelope, sine oscillator (cre, cim, mre, mim, alias, inc), its own volume filter (vol, target, finit, k, y, flags), gains
+  // LogRamp (audioelement.h:2464-2572)
+  double lr_from, lr_to, lr_cur, lr_dur, lr_C;
+  // the loudness adjustment's BaseVolumeAdjusted
+  double l_vol, l_target, l_finit, l_k, l_y;
+  // the outer VolumeAdjusted<SoundEngine>
+  double o_vol, o_target, o_finit, o_k, o_y;
+  // the single ramp spec (RampSpecs, soundengine.h:1046-1120)
+  double sp_from, sp_to, sp_dur, sp_cur, sp_C;
+  double start_angle;
+  int64_t noteid;
+  int oddOn, rt_active, spec_it, spec_end, remaining_silence, l_has, o_has, pad;
+};
+
+__device__ inline bool ramp_rt_active(const VoiceChan &v) { return rt_active(v.c); }
+__device__ inline bool engine_finished(const VoiceChan &v) { return !(v.oddOn & 1) && !ramp_rt_active(v); } // isEnvelopeFinished_internal
+__device__ inline bool elem_rt_active(const VoiceChan &v) { return v.rt_active && !engine_finished(v); }
+
+// loudness::equal_loudness_volume_from_freq, include/loudness.h:246-274 over :157-186 (float arithmetic)
+__device__ inline float loudness_volume(const RaVoiceParams &p, float freq) {
+  int min_ = 0, max_ = 28;
+  do {
+    const int center = (min_ + max_) / 2;
+    if (freq < p.loud_freqs[center]) max_ = center; else min_ = center;
+  } while (max_ - min_ >= 2);
+  int k; float ratio;
+  if (freq <= p.loud_freqs[min_]) { k = min_; ratio = 1.f; }
+  else if (freq >= p.loud_freqs[max_]) { k = max_; ratio = 1.f; }
+  else { k = max_; ratio = (freq - p.loud_freqs[min_]) / (p.loud_freqs[max_] - p.loud_freqs[min_]); }
+  const float db = (ratio == 1.f) ? p.loud_elv[k] : ratio * p.loud_elv[k] + (1.f - ratio) * p.loud_elv[k - 1];
+  if (db > p.max_db) return 1.f;
+  return powf(10.f, p.log_ratio * (db - p.max_db) / 20.f);
+}
+
+// FreqCtrl_::angleIncrements (audioelement.h:3117-3124) over Mix::angleIncrements (:1856-1865)
+__device__ inline double ramp_angle_increments(const RaVoiceParams &p, const VoiceChan &v) {
+  double minAngle = 0;
+  if (p.sine_gain != 0.f) minAngle = fmin(minAngle, v.c.inc);
+  if (minAngle != 0.) return minAngle;
+  return v.lr_from;
+}
+__device__ inline void one_pole_volume(int &has, double &vol, double target, double &finit, double &k, double &y, double inc_abs) { // BaseVolumeAdjusted::step :1195-1216
+  if (!has) {
+    finit = inc_abs;
+    const double a = M_PI * finit;
+    k = a / (1.0 + a);
+    y = target;
+    has = 1;
+  } else if (vol != target) {
+    if (finit != inc_abs) { finit = inc_abs; const double a = M_PI * finit; k = a / (1.0 + a); }
+  }
+  y = y + k * (target - y);
+  vol = y;
+}
+
+constexpr int VT = 16;
+
+__global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_voice_kernel(RaVoiceParams p, VoiceChan *__restrict__ state, const RaVoiceEv *__restrict__ ev,
+                                                                   const int32_t *__restrict__ ev_begin, int32_t *__restrict__ dropped_out, int64_t t0,
+                                                                   int64_t n, float *__restrict__ out) {
+  const int s = blockIdx.x, l = threadIdx.x, Ppad = blockDim.x, P = p.P;
+  double *tile = reinterpret_cast<double *>(ra_smem_voice);       // [Ppad][2 * VT + 1]
+  int *xi = reinterpret_cast<int *>(tile + (size_t)Ppad * (2 * VT + 1));
+  VoiceChan v = state[(size_t)s * Ppad + l];
+  const RaEnvParams ep = {p.envA, 0, 0, p.envR, 0.f}; // setAHDSR(AHDSR{xfade_len, LINEAR, 0, 0, LINEAR, xfade_len, LINEAR, 1.}), soundengine.h:790
+  int e = ev_begin[s];
+  const int e_end = ev_begin[s + 1];
+  int dropped = 0;
+  constexpr int64_t kNever = 0x7fffffffffffffffll;
+  int64_t next_ev = (e < e_end) ? ev[e].sample : kNever;
+  float *o = out + (size_t)s * n * 2;
+  int64_t t = t0;
+  const int64_t t_end = t0 + n;
+  while (t < t_end) {
+    if (next_ev <= t) { // Impl_::doProcessing (gen.voice.h:1159-1165): the events of this frame reach the synth before out.step
+      const RaVoiceEv q = ev[e];
+      ++e;
+      next_ev = (e < e_end) ? ev[e].sample : kNever;
+      if (l == 0) xi[0] = 0x7fffffff;
+      __syncthreads();
+      if (q.type == 0) { // onEvent(NoteOn), gen.crtp.h:389-449 + one-shot :455-527
+        if (l < P && engine_finished(v)) atomicMin(&xi[0], l); // SoundEngine::tryAcquire :291-308
+        __syncthreads();
+        const int sel = xi[0];
+        if (sel == 0x7fffffff) { if (l == 0) ++dropped; }
+        else if (l == sel) {
+          ++v.oddOn;
+          v.noteid = q.noteid;
+          v.remaining_silence = 0; v.start_angle = 0; v.o_has = 0;                 // forgetPastSignals: VolumeAdjusted + SoundEngine :314-317
+          v.o_target = p.base_volume * (double)q.vel;                               // Element::baseVolume * velocity, gen.crtp.h:425
+          // setupAudioElement (gen.voice.h:883-1003): parameters are uniform; the pan is per note
+          {
+            const float pan_f = p.random_pan ? hash_uniform_pm1(p.seed + (uint64_t)s, (uint64_t)q.noteid, 3) : p.pan;
+            double pan = (double)pan_f;
+            pan = fmin(pan, 1.); pan = fmax(pan, -1.);
+            const double ang = (0.25 * M_PI) * (pan + 1.);
+            v.c.gL = cos(ang); v.c.gR = sin(ang);                                   // stereo(), include/stereo.h:18-27
+          }
+          // engine.setAngleIncrements (soundengine.h:403-405) + initialize_sweep (:905-918) -> do_initialize (:1001-1044) -> node 0's LEAVE
+          // lambda (:700-713); base_freq > 0 and n_frames > 0 were checked on the host
+          v.spec_it = -1; v.spec_end = 1;
+          v.sp_from = p.inc_low; v.sp_to = p.inc_high; v.sp_dur = p.n_frames; v.sp_cur = p.start_sample;
+          v.sp_C = (v.sp_to == v.sp_from) ? (double)1.f : -log(v.sp_from / v.sp_to) / (v.sp_to - v.sp_from);
+          // the one-shot: setPhase = setStartAngle(0) (DefaultStartPhase::Zero), onKeyPressed (soundengine.h:333-337)
+          v.start_angle = 0;
+          v.rt_active = 1;
+        }
+      } else { // NoteOff one-shot, gen.crtp.h:541-588
+        if (l < P && v.noteid == q.noteid) atomicMin(&xi[0], l);
+        __syncthreads();
+        if (l == xi[0] && (v.oddOn & 1)) { // canHandleExplicitKeyReleaseNow = goOn(); onKeyReleased :345-353
+          v.rt_active = 0;
+          ++v.oddOn;                                         // stop(i)
+          env_on_key_released(v.c, 0);                       // every ramp's onKeyReleased: only a KeyPressed one reacts
+        }
+      }
+      __syncthreads();
+      continue;
+    }
+    const int64_t seg_end = min(t_end, next_ev);
+    if (!__syncthreads_or(l < P && elem_rt_active(v))) {
+      for (int64_t r = (t - t0) * 2 + l; r < (seg_end - t0) * 2; r += blockDim.x) o[r] = 0.f;
+      t = seg_end;
+      continue;
+    }
+    const int m = (int)min((int64_t)VT, seg_end - t);
+    double *mine = tile + (size_t)l * (2 * VT + 1);
+    for (int i = 0; i < m; ++i) {
+      double vL = 0.0, vR = 0.0;
+      if (l < P && elem_rt_active(v)) { // ImplCRTP::compute, gen.crtp.h:352-371
+        // ---- SoundEngine::step: orchestrate_algos (soundengine.h:741-773) ----
+        if (v.spec_it != v.spec_end) {
+          const bool has_cur = v.spec_it >= 0 && v.spec_it < v.spec_end; // (silenceAfter is true for a SWEEP spec)
+          bool play = true;
+          if (v.c.state == ENV_PRESSED) {
+            const int remaining = v.c.reldelay; // countStepsToRelease
+            if (remaining > 0) play = false;
+            else if (remaining == 0 && has_cur) v.remaining_silence = 0; // articulative_pause_length: never set in SWEEP mode, taken as 0
+          }
+          if (play && has_cur && v.remaining_silence > 0) { --v.remaining_silence; play = false; }
+          if (play && (v.oddOn & 1)) { // playNextSpec :775-801: a finished ramp exists (two of the three never play)
+            ++v.spec_it;
+            if (v.spec_it != v.spec_end) {
+              v.lr_from = v.sp_from; v.lr_to = v.sp_to; v.lr_dur = v.sp_dur; v.lr_cur = v.sp_cur; v.lr_C = v.sp_C;
+              chan_forget_past_signals(v.c); v.l_has = 0;     // new_ramp->forgetPastSignals()
+              { double sn, cs; sincos(M_PI * v.start_angle, &sn, &cs); v.c.cre = cs; v.c.cim = sn; } // setStartAngle
+              v.c.target = (double)1.f;                       // spec volume (setVolume never called in SWEEP: 1.f)
+              v.c.state = ENV_SOON;                           // tryAcquire
+              const int time_to_release = (int)(.5f + v.lr_dur) - p.xfade_len;
+              env_on_key_pressed(v.c, 0);
+              env_on_key_released(v.c, max(time_to_release, 0));
+            }
+          }
+        }
+        // ---- step_algos (:423-436): the ramp steps unless it is finished ----
+        if (v.c.state != ENV_DONE2) {
+          env_step(v.c, ep);
+          double inc;
+          { // LogRamp::do_step, audioelement.h:2522-2542
+            if (v.lr_cur + (double).5f > v.lr_dur) { v.lr_cur = 0; const double tmp = v.lr_from; v.lr_from = v.lr_to; v.lr_to = tmp; }
+            inc = v.lr_from + (v.lr_to - v.lr_from) * (v.lr_cur / v.lr_dur);
+            const double f = v.lr_from + (v.lr_to - v.lr_from) * (v.lr_cur + (double).5f) / v.lr_dur;
+            v.lr_cur += v.lr_C * f;
+          }
+          // Mix::setAngleIncrements -> LoudnessVolumeAdjusted::setAngleIncrements (:1291-1298) -> SineOscillatorAlgo::setAngleIncrements
+          v.l_target = (double)loudness_volume(p, (float)(inc * 0.5 * (double)p.sample_rate));
+          osc_set_inc(v.c, inc);
+          { // SineOscillatorAlgo::step
+            const double re = v.c.cre * v.c.mre - v.c.cim * v.c.mim, im = v.c.cre * v.c.mim + v.c.cim * v.c.mre;
+            const double g = 0.5 * (3.0 - (re * re + im * im));
+            v.c.cre = re * g; v.c.cim = im * g;
+          }
+          one_pole_volume(v.l_has, v.l_vol, v.l_target, v.l_finit, v.l_k, v.l_y, fabs(v.c.inc));
+          int has = (v.c.flags & FL_HAS_VOL) ? 1 : 0;
+          one_pole_volume(has, v.c.vol, v.c.target, v.c.finit, v.c.k, v.c.y, fabs(ramp_angle_increments(p, v)));
+          v.c.flags |= FL_HAS_VOL;
+        }
+        // ---- the outer BaseVolumeAdjusted::step: SoundEngine::angleIncrements (:407-421) is the sounding ramp's, else 0 ----
+        const bool sounding = v.c.state == ENV_RELEASED || v.c.state == ENV_PRESSED;
+        one_pole_volume(v.o_has, v.o_vol, v.o_target, v.o_finit, v.o_k, v.o_y, sounding ? fabs(ramp_angle_increments(p, v)) : 0.0);
+        if (elem_rt_active(v) && sounding) {
+          double sum = 0.f;                                             // Mix::imag :1867-1873
+          sum += (double)p.sine_gain * (v.l_vol * (v.c.alias * v.c.cim));
+          const double mono = v.c.vol * (sum * v.c.value);             // ramp: VolumeAdjusted over Enveloped
+          vL = v.o_vol * (0.0 + v.c.gL * mono);                        // SoundEngine::imag(i): v{} += r.imag(i); BaseVolumeAdjusted::imag(i)
+          vR = v.o_vol * (0.0 + v.c.gR * mono);
+        }
+      }
+      mine[i] = vL; mine[VT + i] = vR;
+    }
+    __syncthreads();
+    if (l < 2 * m) { // buffer[2 i + j] += c.elem.imag(j), channels in index order; then the float cast of SimpleAudioOutContext::step
+      const int fr = l >> 1, ch = l & 1;
+      double acc = 0.0;
+      for (int q = 0; q < P; ++q) acc += tile[(size_t)q * (2 * VT + 1) + ch * VT + fr];
+      o[(t - t0 + fr) * 2 + ch] = (float)acc;
+    }
+    __syncthreads();
+    t += m;
+  }
+  state[(size_t)s * Ppad + l] = v;
+  if (l == 0 && dropped) dropped_out[s] += dropped;
+}
+
+__global__ void ra_voice_init_kernel(VoiceChan *state, int count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  VoiceChan v;
+  memset(&v, 0, sizeof(v));
+  chan_init(v.c);
+  v.noteid = -1;
+  state[i] = v;
+}
+
+} // namespace
+
+size_t ra_voice_state_bytes() { return sizeof(VoiceChan); }
+void ra_voice_launch_init(void *state, int count, hipStream_t st) {
+  hipLaunchKernelGGL(ra_voice_init_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, static_cast<VoiceChan *>(state), count);
+}
+void ra_voice_launch(const RaVoiceParams &p, void *state, const RaVoiceEv *ev, const int32_t *ev_begin, int32_t *dropped, int n_streams, int64_t t0, int64_t n,
+                     float *d_out, hipStream_t st) {
+  if (n <= 0) return;
+  const int Ppad = ((p.P + 63) / 64) * 64;
+  const size_t lds = (size_t)Ppad * (2 * VT + 1) * sizeof(double) + 16;
+  hipLaunchKernelGGL(ra_voice_kernel, dim3((unsigned)n_streams), dim3((unsigned)Ppad), lds, st, p, static_cast<VoiceChan *>(state), ev, ev_begin, dropped, t0, n, d_out);
+}

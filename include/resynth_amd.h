@@ -310,6 +310,49 @@ int64_t ra_render_note(double angle_increment, double volume, const ra_ahdsr *en
 int ra_sqmag(const float *h_windows, int32_t n_windows, int32_t window_size, int32_t window_kind, int32_t device, double *h_sqmag,
              int32_t *fft_length);
 
+/*
+ * ---- gen.voice, first slice: the SWEEP voice -----------------------------------------------------------------
+ * voice::Impl_<..., Mode::SWEEP, ...> (include/gen.voice.h:1087-1190): the same ImplCRTP compute / onEvent boundary as the sine bank, the
+ * element being VolumeAdjusted<SoundEngine<SWEEP, 2, ...>> (include/soundengine.h:240-1127).  A context of its own: the voice is driven
+ * by note events, not by the analysis.  Parameters are the SWEEP program's, de-normalised (gen.voice.h:186-208,474-529,560-580).
+ * What SWEEP mode asks of the absent cpp.algorithms (a MarkovChain with one certain transition, two inert mersenne<> draws) is
+ * restated exactly; interpolation is itp::LINEAR only (the reference's SWEEP programs use nothing else); a random pan uses the declared
+ * counter hash.  BIRDS / ROBOTS / WIND (Markov chains with real draws, pink-noise buffers) are not built.
+ */
+typedef struct ra_voice_config {
+  int32_t sample_rate;
+  int32_t n_channels;            /* 2 * nVoices (gen.crtp.h:225), <= 256 */
+  float length_ms;               /* LENGTH (10 .. 500) */
+  float length_exponent;         /* LENGTH_EXPONENT (0 .. 7): the sweep lasts length_ms * 2^exponent */
+  float xfade_length_seconds;    /* XFADE_LENGTH (0.0023 .. 0.0454): attack and release of the ramp's envelope */
+  float low_freq, high_freq;     /* LOW_FREQ, HIGH_FREQ: the sweep's ends, Hz */
+  float sine_gain;               /* SINE_GAIN */
+  float loudness_level;          /* LOUDNESS_LEVEL, phons (20 .. 100) */
+  float loudness_compensation_amount; /* LOUDNESS_COMPENSATION_AMOUNT (log_ratio, 0 .. 1) */
+  int32_t loudness_ref_freq_index;    /* LOUDNESS_REF_FREQ_INDEX (0 .. 15) */
+  float pan;                     /* PAN (-1 .. 1) */
+  int32_t random_pan;            /* RANDOM_PAN as a boolean */
+  uint64_t seed;
+} ra_voice_config;
+typedef struct ra_voice_event {
+  int64_t sample;    /* frame of Impl_::doProcessing at which the event reaches onEvent (gen.voice.h:1159-1165) */
+  int32_t stream;
+  int32_t type;      /* 0 NoteOn, 1 NoteOff */
+  int64_t noteid;    /* unique per note (events.h:55-107); a note-off names its note-on's id */
+  float frequency;   /* > 0 (SoundEngine::do_initialize refuses base_freq <= 0, soundengine.h:1012-1015); SWEEP ignores its value */
+  float velocity;
+} ra_voice_event;
+typedef struct ra_voice ra_voice;
+int ra_voice_default_config(ra_voice_config *cfg); /* the "Sweep 1" program (gen.voice.h:752-754) with its sweep ends at 100 Hz / 20 kHz */
+int ra_voice_create(const ra_voice_config *cfg, int32_t n_streams, int32_t device, ra_voice **out);
+void ra_voice_destroy(ra_voice *v);
+/* queue events (HOST pointer; per stream in non-decreasing sample order, not before the frames already processed) */
+int ra_voice_events(ra_voice *v, const ra_voice_event *h_events, int64_t n_events);
+/* Impl_::doProcessing over n_frames for every stream: h_out [n_streams][n_frames][2] float32 (HOST pointer); consecutive calls continue */
+int ra_voice_process_host(ra_voice *v, int64_t n_frames, float *h_out);
+/* note-ons that found no channel (onDroppedNote), all streams; negative RA_E* on error */
+int64_t ra_voice_dropped_note_ons(ra_voice *v);
+
 #ifdef __cplusplus
 }
 #endif

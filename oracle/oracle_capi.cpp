@@ -3,6 +3,7 @@
  * Not part of the product; nothing under cpp_audio_amd/ or include/ links this.
  */
 #include "oracle_resynth.hpp"
+#include "oracle_voice.hpp"
 #include <cstring>
 #include <memory>
 #include <thread>
@@ -212,6 +213,30 @@ int64_t ora_resynth_notes(const int32_t *start, const int32_t *end, const double
   int64_t n = static_cast<int64_t>(o.size());
   for (int64_t i = 0; i < n && i < cap; ++i) out[i] = o[i];
   return n;
+}
+
+// gen.voice, SWEEP mode (oracle_voice.hpp): Impl_::doProcessing (gen.voice.h:1128-1187) over n_frames for one stream — events reach the
+// synth at their frame, then SimpleAudioOutContext::step renders.  ev: sample / type (0 on, 1 off) / noteid / frequency / velocity.
+// out [n_frames][2] float.  Returns the number of note-ons dropped.
+int32_t ora_voice_run(const ora_voice_params *p, const int64_t *ev_sample, const int32_t *ev_type, const int64_t *ev_noteid, const float *ev_freq,
+                      const float *ev_vel, int64_t n_ev, int64_t n_frames, float *out) {
+  Stepper stepper;
+  VoiceSynth synth(p->n_channels);
+  synth.phase_policy = 1; // DefaultStartPhase::Zero
+  VoiceInitializer init;
+  init.p = *p;
+  synth.initializer = init;
+  synth.initialize(stepper);
+  int32_t dropped = 0;
+  int64_t e = 0;
+  for (int64_t k = 0; k < n_frames; ++k) {
+    for (; e < n_ev && ev_sample[e] <= k; ++e) {
+      Event evt{ev_type[e] == 0 ? EventType::NoteOn : EventType::NoteOff, ev_noteid[e], ev_freq[e], ev_vel[e], 0};
+      if (synth.onEvent(p->sample_rate, evt, stepper) != onEventResult::OK) ++dropped;
+    }
+    stepper.step(out + 2 * k, 1);
+  }
+  return dropped;
 }
 
 // deduceNotesSlow as decided in oracle_resynth.hpp; returns the number of notes, stores the first cap

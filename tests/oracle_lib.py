@@ -269,6 +269,29 @@ def deduce_notes(x, sr, half_window_size, stride, window_kind=0, cap=1 << 20):
     return st[:n], en[:n], fr[:n], am[:n]
 
 
+class OraVoiceParams(C.Structure):
+    """Mirror of oracle/oracle_voice.hpp: ora_voice_params."""
+    _fields_ = [("sample_rate", C.c_int32), ("n_channels", C.c_int32), ("length_ms", C.c_float), ("length_exponent", C.c_float),
+                ("xfade_length_seconds", C.c_float), ("low_freq", C.c_float), ("high_freq", C.c_float), ("sine_gain", C.c_float),
+                ("loudness_level", C.c_float), ("loudness_compensation", C.c_float), ("loudness_ref_freq_index", C.c_int32),
+                ("pan", C.c_float), ("random_pan", C.c_int32), ("seed", C.c_uint64)]
+
+
+def voice_run(params, rows, n_frames):
+    """gen.voice SWEEP on the oracle, one stream.  rows: (sample, type, noteid, frequency, velocity).  Returns (out [n, 2] float32, dropped)."""
+    rows = sorted(rows, key=lambda r: r[0])
+    es = np.array([r[0] for r in rows], np.int64)
+    et = np.array([r[1] for r in rows], np.int32)
+    ei = np.array([r[2] for r in rows], np.int64)
+    ef = np.array([r[3] for r in rows], np.float32)
+    ev = np.array([r[4] for r in rows], np.float32)
+    out = np.zeros((n_frames, 2), np.float32)
+    L = lib()
+    L.ora_voice_run.restype = C.c_int32
+    d = L.ora_voice_run(C.byref(params), _p(es), _p(et), _p(ei), _p(ef), _p(ev), C.c_int64(len(rows)), C.c_int64(n_frames), _p(out))
+    return out, d
+
+
 def det_math(x, which):
     """oracle_math.hpp: which = 'log2' | 'log10' | 'exp10' | 'pitch_to_freq' (440 * det_pow(2^(1/12), x - 69)) over a float64 array."""
     x = np.ascontiguousarray(x, np.float64)

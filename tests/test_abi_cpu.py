@@ -34,7 +34,8 @@ def test_struct_mirrors_match_c_layout(api, tmp_path):
     fields = [f[0] for f in api.RaConfig._fields_]
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "resynth_amd.h"\nint main(){printf("%zu\\n",sizeof(ra_config));'
                    + "".join(f'printf("%zu\\n",offsetof(ra_config,{f}));' for f in fields)
-                   + 'printf("%zu %zu %zu\\n",sizeof(ra_event),sizeof(ra_stats),sizeof(ra_note));return 0;}\n')
+                   + 'printf("%zu %zu %zu\\n",sizeof(ra_event),sizeof(ra_stats),sizeof(ra_note));'
+                   + 'printf("%zu %zu %zu\\n",sizeof(ra_carrier_event),sizeof(ra_voice_config),sizeof(ra_voice_event));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     lines = subprocess.check_output([str(exe)]).decode().split("\n")
@@ -42,7 +43,10 @@ def test_struct_mirrors_match_c_layout(api, tmp_path):
     for i, f in enumerate(fields):
         assert int(lines[1 + i]) == getattr(api.RaConfig, f).offset, f
     ev, st, nt = map(int, lines[1 + len(fields)].split())
-    assert ev == api.EVENT_DTYPE.itemsize and st == C.sizeof(api.RaStats) and nt == C.sizeof(api.RaNote)
+    assert ev == api.EVENT_DTYPE.itemsize and st == C.sizeof(api.RaStats) and nt == C.sizeof(api.RaNote) and nt == api.NOTE_DTYPE.itemsize
+    ce, vc, ve = map(int, lines[2 + len(fields)].split())
+    assert ce == C.sizeof(api.RaCarrierEvent) == api.CARRIER_EVENT_DTYPE.itemsize
+    assert vc == C.sizeof(api.RaVoiceConfig) and ve == api.VOICE_EVENT_DTYPE.itemsize
 
 
 def test_defaults_match_reference(api):
