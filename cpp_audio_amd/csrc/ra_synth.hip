@@ -209,27 +209,32 @@ constexpr int TROW_MONO = TD + 1; // stereo_spread 0: every channel has the same
 #endif
 #define RA_PRAGMA(x) _Pragma(#x)
 #define RA_UNROLL(n) RA_PRAGMA(unroll n)
+// LEN = 0: the number of steps is the runtime argument n (the pieces of a tile cut at a transition), the loop stays rolled.
+// Rotation of `mult` while gliding: the first step turns by an arbitrary angle (cd0, sd0); each later one by the span's small mean angle,
+// applied as (1, tan) — two multiply-adds instead of four operations.  That turns by exactly the angle and stretches `mult` by 1 / cos,
+// i.e. by d^2 / 2 ~ 1e-10 .. 1e-8 per step: `mult` is renormalised at the end of the span like the phasor.
 template <int LEN, bool GLIDE, bool HI, bool KVAR, bool MONO>
-__device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, double cd0, double sd0, double cd, double sd, double al_da, double al_dda,
-                                  double *mine) {
+__device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, double cd0, double sd0, double tn, double al_da, double al_dda, double *mine,
+                                  int n) {
+  const int len = LEN ? LEN : n;
   double cur = c.cur, mre = c.mre, mim = c.mim, cre = c.cre, cim = c.cim, y = c.y, value = c.value, alias = c.alias, f = c.inc;
   double kk = c.k, fin = c.finit, rr = 0.0, a_used = c.alias;
   const double target = c.target;
   if (KVAR) rr = 1.0 / (1.0 + M_PI * c.finit);
-  double va = alias * value;
-  const double dva = alias * r.dv;
-  auto step = [&](double rc, double rs) -> double {
+  // w_i = (alias + i al_da) (value + (i + 1) dv), the product at step i; va holds w_{i-1} before step i
+  (void)al_dda; (void)a_used;
+  double va = alias * value - (HI ? al_da * value : 0.0); // = w_{-1} = (alias - al_da) * value
+  double d1 = HI ? fma(al_da, value, (alias - al_da) * r.dv) + al_da * r.dv : alias * r.dv; // w_0 - w_{-1}
+  const double d2 = HI ? 2.0 * (al_da * r.dv) : 0.0;
+  auto step = [&](auto first_tag) -> double {
+    constexpr bool FIRST = decltype(first_tag)::value;
     if (GLIDE) {
       f = fma(r.slope, cur, r.base);
       cur = fma(r.alpha, cur, r.beta);
-      const double mr = fma(mre, rc, -(mim * rs)), mi = fma(mre, rs, mim * rc);
+      double mr, mi;
+      if (FIRST) { mr = fma(mre, cd0, -(mim * sd0)); mi = fma(mre, sd0, mim * cd0); }
+      else { mr = fma(-tn, mim, mre); mi = fma(tn, mre, mim); }
       mre = mr; mim = mi;
-      if (HI) { // freqAliasingMultiplicator (audioelement.h:466-483) along the glide: second-order forward differences from the tile's first
-        // increment (set up by the caller; third-order remainder < 1e-10), zero differences for lanes whose gain does not move
-        a_used = alias;
-        alias += al_da;
-        al_da += al_dda;
-      }
       if (KVAR) { // BaseVolumeAdjusted::step, audioelement.h:1195-1216: k = a / (1 + a), a = pi min(max increment, |inc|); 1 / (1 + a) by Newton
         if (r.kvar && y != target) {
           const double w = fmin(max_filter_inc, fabs(f));
@@ -244,19 +249,27 @@ __device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, dou
     const double re = fma(cre, mre, -(cim * mim)), im = fma(cre, mim, cim * mre);
     cre = re; cim = im;
     y = fma(kk, target - y, y);
-    if (HI) { value += r.dv; return y * ((a_used * cim) * value); }
-    va += dva;
-    return y * (cim * va); // the anti-aliasing gain is constant here: folded into the envelope ramp
+    // anti-aliasing gain times envelope: both move linearly over the span (HI: the gain along the secant of freqAliasingMultiplicator,
+    // audioelement.h:466-483, between the span's first and last increment — set up by the caller; else it is constant), so their product
+    // is followed by its forward differences: va += d1 (; d1 += d2)
+    va += d1;
+    if (HI) d1 += d2;
+    return y * (cim * va);
   };
   auto put = [&](int i, double v) { if (MONO) mine[i] = v; else { mine[i] = c.gL * v; mine[TD + i] = c.gR * v; } };
-  put(0, step(cd0, sd0));
-  RA_UNROLL(RA_TILE_UNROLL)
-  for (int i = 1; i < LEN; ++i) put(i, step(cd, sd));
+  put(0, step(std::true_type{}));
+  if (LEN) {
+    RA_UNROLL(RA_TILE_UNROLL)
+    for (int i = 1; i < LEN; ++i) put(i, step(std::false_type{}));
+  } else {
+    for (int i = 1; i < len; ++i) put(i, step(std::false_type{}));
+  }
   const double g = 0.5 * (3.0 - fma(cre, cre, cim * cim));
   c.cre = cre * g; c.cim = cim * g;
-  c.y = y; c.vol = y; c.value = HI ? value : fma((double)LEN, r.dv, value);
+  c.y = y; c.vol = y; c.value = fma((double)len, r.dv, value);
   if (GLIDE) {
-    c.mre = mre; c.mim = mim; c.cur = cur; c.alias = HI ? a_used : alias;
+    const double gm = 0.5 * (3.0 - fma(mre, mre, mim * mim));
+    c.mre = mre * gm; c.mim = mim * gm; c.cur = cur; c.alias = HI ? fma((double)(len - 1), al_da, alias) : alias; // the gain the last step used
     if (r.gliding) { c.fres = f; c.inc = f; }
     if (KVAR) { c.k = kk; c.finit = fin; }
   }
@@ -322,10 +335,11 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
   };
   if (__any(r.active && r.irregular)) atomicOr(b_error_flags, RA_ERR_BOOKKEEPING); // see regime_setup
 
-  // LEN consecutive samples of the tile, written to row entries off .. off + LEN - 1.  If no lane has a transition inside them they take
-  // the straight-line code; otherwise (when allowed) every sample is a checked step.  Returns whether the samples were produced.
-  auto span = [&](auto len_tag, int off, bool allow_checked) -> bool {
-    constexpr int LEN = decltype(len_tag)::value;
+  // LEN (compile time; 0: n_rt) consecutive samples of the tile, written to row entries off .. off + LEN - 1, by the straight-line code —
+  // if no lane of the wave has a transition inside them; otherwise nothing is produced and the caller cuts the span shorter.
+  auto clean_span = [&](auto len_tag, int off, int n_rt) -> bool {
+    constexpr int LENC = decltype(len_tag)::value;
+    const int LEN = LENC ? LENC : n_rt;
     double *row = mine + off;
     // a span is clean for a lane if no transition can fall inside it: then the loop needs no per-sample checks
     double step0 = 0.0;
@@ -333,9 +347,11 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
     bool clean = !r.active || (!stepped0 && r.steps_left >= LEN &&
                                (!r.gliding || (fabs(r.alpha - 1.0) < 1e-2 && c.cur + (LEN - 1) * fabs(step0) * 1.1 <= lim)));
     // Anti-aliasing gain of a glide above fs/8, (1 / inc - 1) / 3 between inc = 1/4 and 1 (freqAliasingMultiplicator, audioelement.h:466-483):
-    // over a span it is followed by its value and first two forward differences at the span's first increment (1 / inc from the running
-    // reciprocal, two Newton steps).  A span in which the increment crosses 1/4 or 1 is not clean (the checked step evaluates the function).
-    double al0 = c.alias, al_da = 0.0, al_dda = 0.0;
+    // over a span it follows the secant between its values at the span's first and last increment (1 / inc from the running reciprocal,
+    // two Newton steps each; the function's curvature over a span leaves < 3e-7 of the gain).  A span in which the increment crosses 1/4
+    // or 1 is not clean (the checked step evaluates the function).
+    double al0 = c.alias, al_da = 0.0;
+    const double al_dda = 0.0;
     if (clean && r.active && r.gliding && r.hi) {
       const double f0 = fma(r.slope, c.cur, r.base), df = r.slope * step0, fl = fma((double)(LEN - 1), df, f0); // first and last increment
       const double flo = f0 < fl ? f0 : fl, fhi = f0 < fl ? fl : f0;
@@ -345,82 +361,87 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
       if (fhi <= 0.25) al0 = 1.0;
       else if (flo >= 1.0) al0 = 0.0;
       else if (flo >= 0.25 && fhi <= 1.0) {
-        const double r2 = rf * rf, q = (r2 * rf) * (1. / 3.) * (df * df); // half the second derivative times df^2
+        double rl = rf * fma(-fl, rf, 2.0);
+        rl = rl * fma(-fl, rl, 2.0);
         al0 = fma(rf, 1. / 3., -1. / 3.);
-        al_da = fma(-(r2 * (1. / 3.)), df, q);
-        al_dda = 2.0 * q;
+        const double inv = LENC == TD ? 1.0 / (TD - 1) : (LEN > 1 ? 1.0 / (double)(LEN - 1) : 0.0);
+        al_da = ((rl - rf) * (1. / 3.)) * inv;
       } else clean = false;
     }
-    if (__all(clean)) {
-      const bool any_glide = __any(r.active && r.gliding);
-      if (r.active) {
-        c.alias = al0; // (its own value for lanes whose gain does not move)
-        if (!any_glide) { clk.tally<0>(); clean_tile<LEN, false, false, false, MONO>(c, r, k.max_filter_inc, 1.0, 0.0, 1.0, 0.0, 0.0, 0.0, row); }
-        else {
-          // Rotation of `mult` per step while gliding: pi (inc_i - inc_{i-1}).  The span's first step turns by d0 = pi (inc_0 - inc),
-          // whatever the oscillator's increment currently is (0 right after a note change); the later steps turn by
-          // pi slope (cur_i - cur_{i-1}), a geometric sequence with ratio alpha (|alpha - 1| ~ 1e-5): their mean serves all of them.
-          double cd0 = 1.0, sd0 = 0.0, cd = 1.0, sd = 0.0;
-          if (r.gliding) {
-            const double d0 = M_PI * (fma(r.slope, c.cur, r.base) - c.inc);
-            const double dA = (M_PI * r.slope) * step0 * (1.0 + 0.5 * (LEN - 2) * (r.alpha - 1.0));
-            double d2 = d0 * d0;
-            sd0 = d0 * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
-            cd0 = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
-            d2 = dA * dA;
-            sd = dA * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
-            cd = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
-          }
-          if (__any(r.active && r.kvar)) clk.tally<3>(); else if (__any(r.active && r.gliding && r.hi)) clk.tally<2>(); else clk.tally<1>();
-          if (__any(r.active && r.kvar)) clean_tile<LEN, true, true, true, MONO>(c, r, k.max_filter_inc, cd0, sd0, cd, sd, al_da, al_dda, row);
-          else if (__any(r.active && r.gliding && r.hi)) clean_tile<LEN, true, true, false, MONO>(c, r, k.max_filter_inc, cd0, sd0, cd, sd, al_da, al_dda, row);
-          else clean_tile<LEN, true, false, false, MONO>(c, r, k.max_filter_inc, cd0, sd0, cd, sd, 0.0, 0.0, row);
-          // over the m' = LEN - 1 later steps the even spread runs ahead of the exact (linearly growing) rotation by b (j+1)(m'-1-j)/2
-          // at step j, b = pi slope step0 (alpha - 1); the oscillator has integrated that: take the sum b (m'-1) m' (m'+1) / 12 back out
-          const double dl = (M_PI * r.slope) * step0 * (r.alpha - 1.0) * ((LEN - 2) * (LEN - 1) * LEN * (1.0 / 12.0));
-          const double re = fma(c.cim, dl, c.cre), im = fma(-c.cre, dl, c.cim);
-          c.cre = re; c.cim = im;
+    if (!__all(clean)) return false;
+    const bool any_glide = __any(r.active && r.gliding);
+    if (r.active) {
+      c.alias = al0; // (its own value for lanes whose gain does not move)
+      if (!any_glide) { clk.tally<0>(); clean_tile<LENC, false, false, false, MONO>(c, r, k.max_filter_inc, 1.0, 0.0, 0.0, 0.0, 0.0, row, LEN); }
+      else {
+        // Rotation of `mult` per step while gliding: pi (inc_i - inc_{i-1}).  The span's first step turns by d0 = pi (inc_0 - inc),
+        // whatever the oscillator's increment currently is (0 right after a note change); the later steps turn by
+        // pi slope (cur_i - cur_{i-1}), a geometric sequence with ratio alpha (|alpha - 1| ~ 1e-5): their mean serves all of them,
+        // as its tangent (clean_tile).
+        double cd0 = 1.0, sd0 = 0.0, tn = 0.0;
+        if (r.gliding) {
+          const double d0 = M_PI * (fma(r.slope, c.cur, r.base) - c.inc);
+          const double dA = (M_PI * r.slope) * step0 * (1.0 + 0.5 * (LEN - 2) * (r.alpha - 1.0));
+          double d2 = d0 * d0;
+          sd0 = d0 * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
+          cd0 = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
+          d2 = dA * dA;
+          tn = dA * fma(d2, fma(d2, 2.0 / 15.0, 1.0 / 3.0), 1.0); // tan: |dA| ~ 1e-5, the series' remainder ~ dA^7
         }
-        r.pending += LEN; r.steps_left -= LEN;
-      } else {
-#pragma unroll
-        for (int i = 0; i < LEN; ++i) { row[i] = 0.0; if (!MONO) row[TD + i] = 0.0; }
+        if (__any(r.active && r.kvar)) clk.tally<3>(); else if (__any(r.active && r.gliding && r.hi)) clk.tally<2>(); else clk.tally<1>();
+        if (__any(r.active && r.kvar)) clean_tile<LENC, true, true, true, MONO>(c, r, k.max_filter_inc, cd0, sd0, tn, al_da, al_dda, row, LEN);
+        else if (__any(r.active && r.gliding && r.hi)) clean_tile<LENC, true, true, false, MONO>(c, r, k.max_filter_inc, cd0, sd0, tn, al_da, al_dda, row, LEN);
+        else clean_tile<LENC, true, false, false, MONO>(c, r, k.max_filter_inc, cd0, sd0, tn, 0.0, 0.0, row, LEN);
+        // over the m' = LEN - 1 later steps the even spread runs ahead of the exact (linearly growing) rotation by b (j+1)(m'-1-j)/2
+        // at step j, b = pi slope step0 (alpha - 1); the oscillator has integrated that: take the sum b (m'-1) m' (m'+1) / 12 back out
+        const double dl = (M_PI * r.slope) * step0 * (r.alpha - 1.0) * ((double)(LEN - 2) * (double)(LEN - 1) * (double)LEN * (1.0 / 12.0));
+        const double re = fma(c.cim, dl, c.cre), im = fma(-c.cre, dl, c.cim);
+        c.cre = re; c.cim = im;
       }
-      clk.lap<0>();
-      return true;
+      r.pending += LEN; r.steps_left -= LEN;
+    } else {
+      for (int i = 0; i < LEN; ++i) { row[i] = 0.0; if (!MONO) row[TD + i] = 0.0; }
     }
-    if (!allow_checked) return false;
-    for (int i = 0; i < LEN; ++i) {
+    clk.lap<0>();
+    return true;
+  };
+  // how many of the next `remaining` samples this lane can take before its next transition (an estimate that errs on the short side for
+  // the glide's end: the exact test is clean_span's)
+  auto safe_len = [&](int remaining) -> int {
+    if (!r.active) return remaining;
+    if (stepped0) return 0;
+    int n = min(remaining, r.steps_left);
+    if (r.gliding) {
+      if (!(fabs(r.alpha - 1.0) < 1e-2)) return 0;
+      const float step = (float)(fabs(fma(r.alpha - 1.0, c.cur, r.beta)) * 1.1), room = (float)(lim - c.cur);
+      if (!(room >= 0.f)) return 0;
+      if (step > 0.f) { const float q = 0.999f * room / step; n = q < 1.0e6f ? min(n, (int)q + 1) : n; }
+    }
+    return n;
+  };
+  auto wave_min = [&](int v) -> int {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+  };
+
+  while (t < seg_end) {
+    const int m = (int)min((int64_t)TD, seg_end - t);
+    // The whole tile in one unrolled go if no lane has a transition in it (~9 of 10 tiles).  Otherwise it is cut at the transitions: clean
+    // pieces of whatever length the wave allows (rolled loop), and at a sample where some lane changes regime one checked step for the
+    // wave — an envelope stage change, the end of a glide, a note's first sample (already taken by the propagate kernel).
+    int pos = (m == TD && clean_span(std::integral_constant<int, TD>{}, 0, TD)) ? TD : 0;
+    while (pos < m) {
+      const int nn = wave_min(safe_len(m - pos));
+      if (nn >= 1 && clean_span(std::integral_constant<int, 0>{}, pos, nn)) { pos += nn; continue; }
       double v = 0.0;
       if (r.active) {
         if (stepped0) v = c.vol * ((c.alias * c.cim) * c.value); // already stepped (propagate kernel): StereoPanned::imag of the state as loaded
         else v = checked_step();
       }
       stepped0 = false;
-      if (MONO) row[i] = v; else { row[i] = c.gL * v; row[TD + i] = c.gR * v; }
-    }
-    clk.lap<1>();
-    return true;
-  };
-
-  while (t < seg_end) {
-    const int m = (int)min((int64_t)TD, seg_end - t);
-    if (m == TD) {
-      // the whole tile in one go if it is clean; otherwise its two halves separately, so that one transition costs half a tile of checked steps
-      if (!span(std::integral_constant<int, TD>{}, 0, false)) {
-        span(std::integral_constant<int, TD / 2>{}, 0, true);
-        span(std::integral_constant<int, TD / 2>{}, TD / 2, true);
-      }
-    } else { // a partial tile at the end of a segment
-      for (int i = 0; i < m; ++i) {
-        double v = 0.0;
-        if (r.active) {
-          if (stepped0) v = c.vol * ((c.alias * c.cim) * c.value);
-          else v = checked_step();
-        }
-        stepped0 = false;
-        if (MONO) mine[i] = v; else { mine[i] = c.gL * v; mine[TD + i] = c.gR * v; }
-      }
+      if (MONO) mine[pos] = v; else { mine[pos] = c.gL * v; mine[TD + pos] = c.gR * v; }
+      ++pos;
       clk.lap<1>();
     }
     if (Ppad > 64) __syncthreads(); // one wave: its LDS operations execute in order, no barrier needed
