@@ -192,6 +192,11 @@ __device__ inline void regime_setup(Chan &c, const SynConst &k, double inv_dur, 
   }
 }
 
+// tuning aid: -DRA_ABL=1 leaves out the straight-line steps of a clean span (its set-up stays), 2 the channel sum and output, 4 the
+// checked steps (bit mask; instruction-count ablations with rocprofv3 --pmc SQ_INSTS_VALU, scripts/build_variants.sh); 0 = the product
+#ifndef RA_ABL
+#define RA_ABL 0
+#endif
 #ifndef RA_TILE_DEPTH
 #define RA_TILE_DEPTH 16 // samples per tile: 8 or 16 (the per-tile set-up and the channel sums are amortised over them)
 #endif
@@ -257,6 +262,7 @@ __device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, dou
     return y * (cim * va);
   };
   auto put = [&](int i, double v) { if (MONO) mine[i] = v; else { mine[i] = c.gL * v; mine[TD + i] = c.gR * v; } };
+  if (RA_ABL & 1) return;
   put(0, step(std::true_type{}));
   if (LEN) {
     RA_UNROLL(RA_TILE_UNROLL)
@@ -435,7 +441,7 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
       const int nn = wave_min(safe_len(m - pos));
       if (nn >= 1 && clean_span(std::integral_constant<int, 0>{}, pos, nn)) { pos += nn; continue; }
       double v = 0.0;
-      if (r.active) {
+      if (r.active && !(RA_ABL & 4)) {
         if (stepped0) v = c.vol * ((c.alias * c.cim) * c.value); // already stepped (propagate kernel): StereoPanned::imag of the state as loaded
         else v = checked_step();
       }
@@ -445,7 +451,7 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
       clk.lap<1>();
     }
     if (Ppad > 64) __syncthreads(); // one wave: its LDS operations execute in order, no barrier needed
-    if (l < 64) { // NOUT outputs x NPART channel groups
+    if (l < 64 && !(RA_ABL & 2)) { // NOUT outputs x NPART channel groups
       double acc = 0.0;
       if (fr < m) {
         const double *q = col;

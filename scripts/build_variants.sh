@@ -11,6 +11,6 @@ for spec in "$@"; do
   /opt/rocm/bin/hipcc $FLAGS $extra -c ra_synth.hip -o /tmp/ra_synth_$name.o &
   /opt/rocm/bin/hipcc $FLAGS $extra -c ra_analysis.hip -o /tmp/ra_analysis_$name.o
   wait
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../ab_libs/libresynth_$name.so ra_capi.o /tmp/ra_analysis_$name.o ra_track.o /tmp/ra_synth_$name.o ra_vocoder.o ra_notes.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../ab_libs/libresynth_$name.so ra_capi.o /tmp/ra_analysis_$name.o ra_track.o /tmp/ra_synth_$name.o ra_vocoder.o ra_carrier.o ra_post.o ra_voice.o ra_notes.o
   echo "built $name ($extra)"
 done
