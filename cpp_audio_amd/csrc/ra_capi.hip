@@ -185,7 +185,7 @@ int validate(const ra_config &c, int32_t n_streams) {
   if (c.min_volume < 0) return fail(RA_EINVAL, "min_volume is too small");
   if (c.nearby_distance_tones < 0) return fail(RA_EINVAL, "nearby_distance_tones is too small");
   if (c.max_track_pitches < 0) return fail(RA_EINVAL, "max_track_pitches is too small");
-  if (c.max_pitches_per_frame < 1 || c.max_pitches_per_frame > 4096) return fail(RA_EINVAL, "max_pitches_per_frame must be in 1..4096");
+  if (c.max_pitches_per_frame < 0 || c.max_pitches_per_frame > 4096) return fail(RA_EINVAL, "max_pitches_per_frame must be in 0..4096 (0 = sized for the worst case)");
   if (c.vocoder_count_bands < 1 || c.vocoder_count_bands > 50) return fail(RA_EINVAL, "vocoder_count_bands must be in 1..50");
   if (c.window_kind < 0 || c.window_kind > 2) return fail(RA_EINVAL, "unknown window_kind");
   if (c.autotune_factor < 0) return fail(RA_EINVAL, "autotune_factor must be >= 0");
@@ -331,6 +331,17 @@ int build_tables(ra_context *c) {
   p.P = cfg.n_channels;
   p.Ppad = ((p.P + 63) / 64) * 64;
   p.maxr = cfg.max_pitches_per_frame;
+  if (p.maxr == 0) {
+    // Sized like the reference's growing vectors (lib.cpp:1102-1112) would end up in the worst case: a spectrum of M bins has at most
+    // M / 2 local maxima, each at most one list entry (two with a harmonize step: the lists then hold twice maxr).  Bounded by the LDS
+    // the analysis (FFT buffer + two lists) and the tracking (40 bytes per entry) workgroups may hold; from FFT length 16384 on that
+    // bound is below M / 2 and RA_EOVERFLOW stays possible for noise-like spectra.
+    const bool harm = cfg.pitch_harmonize_pre_autotune != 0.f || cfg.pitch_harmonize_post_autotune != 0.f;
+    const size_t fft_bytes = (size_t)std::max(p.M, 16) * sizeof(double2), lim = RA_LDS_LIMIT_BYTES; // ra_zsize(M) slots
+    const size_t fit_a = fft_bytes + 4096 < lim ? (lim - fft_bytes - 4096) / (2 * sizeof(double2) * (harm ? 2 : 1)) : 1;
+    const size_t fit_t = ((size_t)lim - (size_t)p.P * 88 - 64) / 40;
+    p.maxr = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(fit_a, fit_t), std::min<size_t>(4096, std::max(16, p.M / 2))));
+  }
   p.min_volume = static_cast<double>(cfg.min_volume);
   p.nearby = static_cast<double>(cfg.nearby_distance_tones);
   p.max_track = static_cast<double>(cfg.max_track_pitches);
@@ -553,13 +564,13 @@ int ensure_scratch(ra_context *c, int64_t nfb, int64_t n, int n_chunks) {
   if (p.voc_enabled) {
     size_t S = p.n_streams;
     if (n > b.mix_cap) {
-      HIP_TRY(hipStreamSynchronize(c->stream));
+      HIP_TRY(hipDeviceSynchronize()); // an earlier block may still use the old buffer on the render stream
       dev_free(c, b.voc_mix);
       b.mix_cap = n;
       if ((r = dev_alloc(c, &b.voc_mix, S * n, false))) return r;
     }
     if (p.car_P > 0 && n > b.car_gen_cap) {
-      HIP_TRY(hipStreamSynchronize(c->stream));
+      HIP_TRY(hipDeviceSynchronize()); // an earlier block may still use the old buffer on the render stream
       dev_free(c, b.car_gen_d); dev_free(c, b.car_gen_f);
       b.car_gen_cap = n;
       if ((r = dev_alloc(c, &b.car_gen_d, S * n, false))) return r;
@@ -568,13 +579,13 @@ int ensure_scratch(ra_context *c, int64_t nfb, int64_t n, int n_chunks) {
     RaFrameRange mod = ra_frames_firing(p.voc_Wm, p.voc_S, c->t, n), car = ra_frames_firing(2 * p.voc_S, p.voc_S, c->t, n);
     if (p.voc_kind != RA_VOCODER_FFT) { mod.count = 0; car.count = 0; }
     if (mod.count > b.voc_mod_cap) {
-      HIP_TRY(hipStreamSynchronize(c->stream));
+      HIP_TRY(hipDeviceSynchronize()); // an earlier block may still use the old buffer on the render stream
       dev_free(c, b.voc_amp);
       b.voc_mod_cap = mod.count + 2;
       if ((r = dev_alloc(c, &b.voc_amp, S * b.voc_mod_cap * p.voc_bands, false))) return r;
     }
     if (car.count > b.voc_car_cap) {
-      HIP_TRY(hipStreamSynchronize(c->stream));
+      HIP_TRY(hipDeviceSynchronize()); // an earlier block may still use the old buffer on the render stream
       dev_free(c, b.voc_sig);
       b.voc_car_cap = car.count + 2;
       if ((r = dev_alloc(c, &b.voc_sig, S * b.voc_car_cap * 2 * p.voc_S, false))) return r;
@@ -691,12 +702,13 @@ int process_block_impl(ra_context *c, const float *d_voice, const float *d_carri
   if (c->cfg.reference_order != 1 && nfb >= 64) n_chunks = static_cast<int>(std::min<int64_t>(kMaxChunks, std::max<int64_t>(3, nfb / 64)));
   static const int forced_chunks = std::getenv("RA_PIPELINE_CHUNKS") ? std::atoi(std::getenv("RA_PIPELINE_CHUNKS")) : 0; // tuning aid
   if (forced_chunks > 0 && c->cfg.reference_order != 1 && nfb >= forced_chunks) n_chunks = std::min(forced_chunks, kMaxChunks);
-  // blocks that cannot overlap their predecessor: single-chunk / reference-order blocks (they run on the caller's stream) and the vocoder
-  // (its histories are rolled on the render stream): they first wait for whatever is still in flight
+  // blocks that cannot overlap their predecessor: single-chunk / reference-order / feedback blocks (they run on the caller's stream): they
+  // first wait for whatever is still in flight.  The vocoder can: all of its work (carrier synth, transforms or filter bank, mix, history
+  // roll) is queued on the render stream, in block order, and its single-buffered scratch and mix are only touched there
   int r;
   if (p.fb_gain != 0.f) n_chunks = static_cast<int>(std::min<int64_t>(nfb, nfb / ((int64_t)p.fb_sz / p.H + 1) + 1)) + 2; // pieces (only sizes the hop-state buffer)
   const bool caller_stream_only = n_chunks == 1 || p.fb_gain != 0.f;
-  if (caller_stream_only || p.voc_enabled) { if ((r = join_streams(c))) return r; async = false; }
+  if (caller_stream_only) { if ((r = join_streams(c))) return r; async = false; }
   c->parity ^= 1; // (ensure_scratch binds the set `parity` names; a failure there flips it back: nothing has been launched yet)
   if ((r = ensure_scratch(c, nfb, n, n_chunks))) { c->parity ^= 1; return r; }
   // the vocoder's carrier: the caller's buffer, or — when there is none and the context has a carrier synth — that synth's output

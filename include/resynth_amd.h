@@ -89,7 +89,8 @@ typedef struct ra_config {
 
   /* capacity of the per-frame pitch list handed from analysis to tracking (the reference's vectors grow
    * on demand, lib.cpp:1102-1112); exceeding it sets RA_EOVERFLOW instead of truncating silently. */
-  int32_t max_pitches_per_frame; /* default 512; 1..4096, further limited by the 160 KB of LDS a workgroup may hold: the analysis keeps
+  int32_t max_pitches_per_frame; /* default 512 (the fastest: the lists live in LDS beside the FFT buffer); 0 = sized for the worst case,
+                                    min(FFT length / 4, what fits) — no spectrum can overflow it up to FFT length 8192; 1..4096, further limited by the 160 KB of LDS a workgroup may hold: the analysis keeps
                                     two lists of this capacity (twice that with a harmonize step) beside its FFT buffer, the tracking
                                     40 bytes per entry — ra_create returns RA_EINVAL with the byte counts when they do not fit */
 

@@ -309,6 +309,46 @@ def test_vocoder_block_size_invariance(api, sig):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("kind,synth", [(0, False), (1, False), (1, True)])
+def test_vocoder_overlapped_blocks_equal_stream_ordered_blocks(api, sig, kind, synth):
+    # ra_process_device_async with a vocoder: block k + 1's analysis / tracking / propagation overlap block k's render, the vocoder's own
+    # work (carrier synth, transforms or filter bank, mix, history roll) stays in block order on the render stream -> bits equal
+    import torch
+    S, n, nb = 4, 160000, 3                      # 160 k frames -> the chunked pipeline is used
+    x = torch.from_numpy(sig.make_streams(S, n * nb, kind="speech", base_seed=17)).cuda()
+    car = torch.from_numpy(np.stack([sig.carrier_stream(n * nb, freq=90.0 + 20 * s) for s in range(S)])).cuda()
+    kw = dict(PARITY_KW, **VOC_KW)
+    kw.update(vocoder_kind=kind, vocoder_count_bands=32)
+    rows = []
+    if synth:
+        kw.update(carrier_n_channels=8, vocoder_carrier_square_volume=0.0, vocoder_carrier_sine_volume=0.5, vocoder_carrier_saw_volume=0.5)
+        for s in range(S):
+            for j in range(12):
+                rows += [(j * 37000 + 11 * s, s, 0, 50 + j % 7, 0, 0.0, 0.8), (j * 37000 + 30000, s, 1, 50 + j % 7, 0, 0.0, 0.0)]
+        rows.sort(key=lambda r: (r[1], r[0]))
+    cfg = api.default_config(**kw)
+    outs = []
+    for overlap in (False, True):
+        out = torch.zeros(nb, S, n, 2, dtype=torch.float32, device="cuda")
+        keep = []
+        with api.Context(cfg, S, 0) as ctx:
+            ctx.set_hip_stream(torch.cuda.current_stream().cuda_stream)
+            if synth:
+                ctx.carrier_events(rows)
+            for k in range(nb):
+                blk = x[:, k * n:(k + 1) * n].contiguous()
+                cblk = car[:, k * n:(k + 1) * n].contiguous()
+                keep += [blk, cblk]                # inputs must stay alive until the join
+                ctx.process_device(blk.data_ptr(), 0 if synth else cblk.data_ptr(), n, out[k].data_ptr(), overlap=overlap)
+            if overlap:
+                ctx.join()
+            ctx.synchronize()
+            assert ctx.stats().error_flags == 0
+        outs.append(out.cpu().numpy())
+    assert np.sqrt(np.mean(outs[0].astype(np.float64) ** 2)) > 1e-3
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_vocoder_many_streams_frames_per_workgroup(api, oracle, sig):
     # enough streams x frames that a modulator workgroup takes 8 consecutive frames (ra_launch_vocoder); two unequal blocks, so that a
     # workgroup's last frames fall off the end of a block
@@ -613,6 +653,29 @@ def test_against_the_libm_oracle(api, oracle, sig, shape):
     assert worst_p <= 16.0 and worst_v <= 64.0
     if shape == "configs1":
         assert compared == S, "without autotune no stream is expected to sit on a tie"
+
+
+def test_worst_case_list_capacity(api, oracle):
+    # white noise: a local maximum at every third bin or so, and with nearby_distance_tones = 0 each one stays a list entry of its own —
+    # the default capacity (512) overflows (RA_EOVERFLOW, nothing truncated silently), max_pitches_per_frame = 0 sizes the lists for the
+    # worst case like the reference's growing vectors (lib.cpp:1102-1112) and the result matches the restatement
+    rng = np.random.default_rng(9)
+    x = (0.1 * rng.standard_normal((1, 30000))).astype(np.float32)
+    kw = dict(nearby_distance_tones=0.0, min_volume=0.0, n_channels=32)
+    with api.Context(api.default_config(**dict(PARITY_KW, **kw)), 1, 0) as ctx:
+        with pytest.raises(api.RaError) as e:
+            ctx.process_host(x)
+        assert e.value.code == -4
+    gcfg, k = both_configs(api, oracle, max_pitches_per_frame=0, **kw)
+    with api.Context(gcfg, 1, 0) as ctx:
+        out = ctx.process_host(x)
+        assert ctx.stats().error_flags == 0
+        fire, offs, pitch, vol = ctx.frame_pitches(0)
+    assert np.max(np.diff(offs)) > 512
+    ofire, ooffs, opitch, ovol = oracle.run_frames(oracle.default_config(**k), x[0])
+    assert np.array_equal(offs, ooffs) and np.array_equal(pitch, opitch) and np.array_equal(vol, ovol)
+    ref, _, _ = oracle.run_offline(oracle.default_config(**k), x[0])
+    assert rms(out[0], ref) <= RMS_TOL
 
 
 def test_lds_limits_are_checked_at_create(api, oracle, sig):
