@@ -387,6 +387,10 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
         al0 = fma(rf, 1. / 3., -1. / 3.);
         const double inv = LENC ? 1.0 / (SPAN - 1) : (SPAN > 1 ? 1.0 / (double)(SPAN - 1) : 0.0);
         al_da = ((rl - rf) * (1. / 3.)) * inv;
+        // the secant of a convex function lies above it by f'' (fl - f0)^2 x (1 - x) / 2, mean f'' (fl - f0)^2 / 12 with f'' = 2 / (3 inc^3):
+        // the line is lowered by that mean (the error that is left averages to zero over the span)
+        const double dfl = fl - f0;
+        al0 = fma(-(rf * rf) * rf, (dfl * dfl) * (1. / 18.), al0);
       } else clean = false;
     }
     if (!__all(clean)) return false;
@@ -402,24 +406,32 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
         // whatever the oscillator's increment currently is (0 right after a note change); the later steps turn by
         // pi slope (cur_i - cur_{i-1}), a geometric sequence with ratio alpha (|alpha - 1| ~ 1e-5): their mean serves all of them,
         // as its tangent (clean_tile).
-        double cd0 = 1.0, sd0 = 0.0;
+        double cd0 = 1.0, sd0 = 0.0, tn2 = 0.0, dl2 = 0.0;
         if (r.gliding) {
           const double d0 = M_PI * (fma(r.slope, c.cur, r.base) - c.inc);
-          const double dA = (M_PI * r.slope) * step0 * (1.0 + 0.5 * (SPAN - 2) * (r.alpha - 1.0));
+          const double ps = (M_PI * r.slope) * step0, am1 = r.alpha - 1.0;
+          const double dA = ps * (1.0 + 0.5 * (LEN - 2) * am1);
           double d2 = d0 * d0;
           sd0 = d0 * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
           cd0 = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
           d2 = dA * dA;
           tn = dA * fma(d2, fma(d2, 2.0 / 15.0, 1.0 / 3.0), 1.0); // tan: |dA| ~ 1e-5, the series' remainder ~ dA^7
-          // over the m' = SPAN - 1 later steps the even spread runs ahead of the exact (linearly growing) rotation by b (j+1)(m'-1-j)/2
-          // at step j, b = pi slope step0 (alpha - 1); the oscillator integrates that: the sum b (m'-1) m' (m'+1) / 12 is taken back
-          // out at the end of the span (at most ~4e-8 rad in between)
-          dl = (M_PI * r.slope) * step0 * (r.alpha - 1.0) * ((double)(SPAN - 2) * (double)(SPAN - 1) * (double)SPAN * (1.0 / 12.0));
+          // over the tile's m' = LEN - 1 later steps the even spread runs ahead of the exact (linearly growing) rotation by
+          // b (j+1)(m'-1-j)/2 at step j, b = pi slope step0 (alpha - 1); the oscillator integrates that: the sum b (m'-1) m' (m'+1) / 12
+          // is taken back out at the end of the tile
+          dl = ps * am1 * ((double)(LEN - 2) * (double)(LEN - 1) * (double)LEN * (1.0 / 12.0));
+          if (PAIR) { // the second tile's LEN steps turn by pi slope step0 alpha^(LEN - 1 + k), k = 0 .. LEN - 1: their own mean and sum
+            const double dB = ps * (1.0 + 1.5 * (LEN - 1) * am1);
+            d2 = dB * dB;
+            tn2 = dB * fma(d2, fma(d2, 2.0 / 15.0, 1.0 / 3.0), 1.0);
+            dl2 = ps * am1 * ((double)(LEN - 1) * (double)LEN * (double)(LEN + 1) * (1.0 / 12.0));
+          }
         }
         if (kind == 3) { clk.tally<3>(); clean_tile<LENC, true, true, true, MONO>(c, r, k.max_filter_inc, cd0, sd0, tn, al_da, al_dda, row, LEN); }
         else if (kind == 2) { clk.tally<2>(); clean_tile<LENC, true, true, false, MONO>(c, r, k.max_filter_inc, cd0, sd0, tn, al_da, al_dda, row, LEN); }
         else { clk.tally<1>(); clean_tile<LENC, true, false, false, MONO>(c, r, k.max_filter_inc, cd0, sd0, tn, 0.0, 0.0, row, LEN); }
-        if (!PAIR) { const double re = fma(c.cim, dl, c.cre), im = fma(-c.cre, dl, c.cim); c.cre = re; c.cim = im; }
+        { const double re = fma(c.cim, dl, c.cre), im = fma(-c.cre, dl, c.cim); c.cre = re; c.cim = im; }
+        tn = tn2; dl = dl2; // (what a pair's second tile runs with)
       }
       r.pending += LEN; r.steps_left -= LEN;
     } else {

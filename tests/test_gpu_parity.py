@@ -656,13 +656,13 @@ def test_against_the_libm_oracle(api, oracle, sig, shape):
 
 
 def test_worst_case_list_capacity(api, oracle):
-    # white noise: a local maximum at every third bin or so, and with nearby_distance_tones = 0 each one stays a list entry of its own —
-    # the default capacity (512) overflows (RA_EOVERFLOW, nothing truncated silently), max_pitches_per_frame = 0 sizes the lists for the
-    # worst case like the reference's growing vectors (lib.cpp:1102-1112) and the result matches the restatement
+    # white noise: a local maximum every few bins, and with nearby_distance_tones = 0 each one stays a list entry of its own — a capacity
+    # below that overflows (RA_EOVERFLOW, nothing truncated silently), max_pitches_per_frame = 0 sizes the lists for the worst case
+    # like the reference's growing vectors (lib.cpp:1102-1112) and the result matches the restatement
     rng = np.random.default_rng(9)
     x = (0.1 * rng.standard_normal((1, 30000))).astype(np.float32)
     kw = dict(nearby_distance_tones=0.0, min_volume=0.0, n_channels=32)
-    with api.Context(api.default_config(**dict(PARITY_KW, **kw)), 1, 0) as ctx:
+    with api.Context(api.default_config(**dict(PARITY_KW, max_pitches_per_frame=128, **kw)), 1, 0) as ctx:
         with pytest.raises(api.RaError) as e:
             ctx.process_host(x)
         assert e.value.code == -4
@@ -671,7 +671,7 @@ def test_worst_case_list_capacity(api, oracle):
         out = ctx.process_host(x)
         assert ctx.stats().error_flags == 0
         fire, offs, pitch, vol = ctx.frame_pitches(0)
-    assert np.max(np.diff(offs)) > 512
+    assert np.max(np.diff(offs)) > 128
     ofire, ooffs, opitch, ovol = oracle.run_frames(oracle.default_config(**k), x[0])
     assert np.array_equal(offs, ooffs) and np.array_equal(pitch, opitch) and np.array_equal(vol, ovol)
     ref, _, _ = oracle.run_offline(oracle.default_config(**k), x[0])
