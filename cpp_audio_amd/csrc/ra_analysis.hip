@@ -141,7 +141,7 @@ __device__ inline void block_exclusive_scan(int *scan, int v, int tid) {
 
 template <int T>
 __global__ void __launch_bounds__(T, (T >= 512 ? 4 : 1)) // 512 / 1024 threads: 4 waves per SIMD (<= 128 VGPRs), so that two 512-thread groups share a CU
-ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int64_t t0, int64_t n, int64_t f_lo, int fb0, int nfb_total) {
+ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int64_t t0, int64_t n, int64_t f_lo, int fb0, int nfb_total, int nfb_launch) {
 #ifndef RA_ANALYSIS_PRIO
 #define RA_ANALYSIS_PRIO 0
 #endif
@@ -149,7 +149,14 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   // kernel is short of wave slots, not of issue cycles
   if (RA_ANALYSIS_PRIO) __builtin_amdgcn_s_setprio(RA_ANALYSIS_PRIO);
   const int tid = threadIdx.x;
-  const int fb = fb0 + blockIdx.x; // frame index inside the block [t0, t0 + n): this launch covers frames fb0 .. fb0 + gridDim.x - 1
+  // XCD-aware frame order.  Workgroups go to the 8 XCDs round robin by linear id (= blockIdx.x + gridDim.x * blockIdx.y, gridDim.x a multiple
+  // of 8), and each XCD has its own L2: with frame = blockIdx.x, the four frames that share a window's samples (75 % overlap) would land on
+  // four different XCDs and every window would come from HBM (measured in round 1: each input sample fetched ~4 times).  Instead XCD g takes
+  // the contiguous frames [g * per, (g + 1) * per) of the launch, in order: a window's samples are read from HBM once per XCD range.
+  const int per = gridDim.x >> 3;
+  const int fidx = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (fidx >= nfb_launch) return;
+  const int fb = fb0 + fidx; // frame index inside the block [t0, t0 + n): this launch covers frames fb0 .. fb0 + nfb_launch - 1
   const int s = blockIdx.y;
   const int64_t f = f_lo + fb;
   const int M = p.M, N = p.N;
@@ -633,7 +640,7 @@ size_t ra_analysis_lds_bytes(const RaParams &p) {
 void ra_launch_analysis(const RaParams &p, const RaBuffers &b, const float *d_voice, int64_t t0, int64_t n, int64_t f_lo, int64_t fb0, int64_t nfb_chunk,
                         int64_t nfb_total, hipStream_t st) {
   if (nfb_chunk <= 0) return;
-  dim3 grid((unsigned)nfb_chunk, (unsigned)p.n_streams);
+  dim3 grid((unsigned)(8 * ((nfb_chunk + 7) / 8)), (unsigned)p.n_streams); // a multiple of 8 per row: see the kernel's frame order
   size_t lds = ra_analysis_lds_bytes(p);
   static unsigned long long attr_done = 0;
   ra_once_per_device(attr_done, [] {
@@ -642,9 +649,9 @@ void ra_launch_analysis(const RaParams &p, const RaBuffers &b, const float *d_vo
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_analysis_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   switch (ra_analysis_threads(p)) {
-  case 1024: hipLaunchKernelGGL(ra_analysis_kernel<1024>, grid, dim3(1024), lds, st, p, b, d_voice, t0, n, f_lo, (int)fb0, (int)nfb_total); break;
-  case 512: hipLaunchKernelGGL(ra_analysis_kernel<512>, grid, dim3(512), lds, st, p, b, d_voice, t0, n, f_lo, (int)fb0, (int)nfb_total); break;
-  default: hipLaunchKernelGGL(ra_analysis_kernel<256>, grid, dim3(256), lds, st, p, b, d_voice, t0, n, f_lo, (int)fb0, (int)nfb_total); break;
+  case 1024: hipLaunchKernelGGL(ra_analysis_kernel<1024>, grid, dim3(1024), lds, st, p, b, d_voice, t0, n, f_lo, (int)fb0, (int)nfb_total, (int)nfb_chunk); break;
+  case 512: hipLaunchKernelGGL(ra_analysis_kernel<512>, grid, dim3(512), lds, st, p, b, d_voice, t0, n, f_lo, (int)fb0, (int)nfb_total, (int)nfb_chunk); break;
+  default: hipLaunchKernelGGL(ra_analysis_kernel<256>, grid, dim3(256), lds, st, p, b, d_voice, t0, n, f_lo, (int)fb0, (int)nfb_total, (int)nfb_chunk); break;
   }
 }
 

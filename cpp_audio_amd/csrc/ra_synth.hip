@@ -203,14 +203,7 @@ __device__ inline void regime_setup(Chan &c, const SynConst &k, double inv_dur, 
 constexpr int TD = RA_TILE_DEPTH; // tile depth of the regime renderer
 static_assert(TD == 8 || TD == 16, "tile depth");
 constexpr int TROW = 2 * TD + 1; // its LDS tile is lane-major: [Ppad][TROW] doubles, entry out * TD + frame (odd row length: conflict-free both ways)
-// stereo_spread 0: every channel has the same two gains, applied after the channel sum: one value per sample and lane, and room for
-// deeper tiles (the per-tile set-up and the sum's cross-lane part are paid once per tile)
-#ifndef RA_TILE_DEPTH_MONO
-#define RA_TILE_DEPTH_MONO 16
-#endif
-constexpr int TD_MONO = RA_TILE_DEPTH_MONO;
-static_assert(TD_MONO == 8 || TD_MONO == 16 || TD_MONO == 32, "mono tile depth");
-constexpr int TROW_MONO = TD_MONO + 1;
+constexpr int TROW_MONO = TD + 1; // stereo_spread 0: every channel has the same two gains, applied after the channel sum
 
 // LEN steps (a whole tile, or half of one) of a lane whose wave has no transition inside them: straight-line code, no state machine.
 // GLIDE: some lane of the wave glides (the others run the same code with the identity rotation, alpha = 1, beta = 0);
@@ -225,13 +218,11 @@ constexpr int TROW_MONO = TD_MONO + 1;
 // Rotation of `mult` while gliding: the first step turns by an arbitrary angle (cd0, sd0); each later one by the span's small mean angle,
 // applied as (1, tan) — two multiply-adds instead of four operations.  That turns by exactly the angle and stretches `mult` by 1 / cos,
 // i.e. by d^2 / 2 ~ 1e-10 .. 1e-8 per step: `mult` is renormalised at the end of the span like the phasor.
-// CONT: the second tile of a pair that shares one set-up (the span is two tiles long): its first step is a regular one, and the
-// anti-aliasing gain goes on from where the first tile left it.
-template <int LEN, bool GLIDE, bool HI, bool KVAR, bool MONO, bool CONT = false>
+template <int LEN, bool GLIDE, bool HI, bool KVAR, bool MONO>
 __device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, double cd0, double sd0, double tn, double al_da, double al_dda, double *mine,
                                   int n) {
   const int len = LEN ? LEN : n;
-  double cur = c.cur, mre = c.mre, mim = c.mim, cre = c.cre, cim = c.cim, y = c.y, value = c.value, alias = (HI && CONT) ? c.alias + al_da : c.alias, f = c.inc;
+  double cur = c.cur, mre = c.mre, mim = c.mim, cre = c.cre, cim = c.cim, y = c.y, value = c.value, alias = c.alias, f = c.inc;
   double kk = c.k, fin = c.finit, rr = 0.0, a_used = c.alias;
   const double target = c.target;
   if (KVAR) rr = 1.0 / (1.0 + M_PI * c.finit);
@@ -272,9 +263,9 @@ __device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, dou
   };
   auto put = [&](int i, double v) { if (MONO) mine[i] = v; else { mine[i] = c.gL * v; mine[TD + i] = c.gR * v; } };
   if (RA_ABL & 1) return;
-  put(0, step(std::integral_constant<bool, !CONT>{}));
+  put(0, step(std::true_type{}));
   if (LEN) {
-#pragma unroll
+    RA_UNROLL(RA_TILE_UNROLL)
     for (int i = 1; i < LEN; ++i) put(i, step(std::false_type{}));
   } else {
     for (int i = 1; i < len; ++i) put(i, step(std::false_type{}));
@@ -306,9 +297,8 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
   double *mine = tile + l * ROW;                                                // this lane's row
   // reduction role of lanes 0..63: frame fr of output ch over a quarter of the channels (MONO: frame fr over an eighth)
   // the 64 reducing lanes: output value o (frame fr of channel ch; entries of a row are laid out [ch][fr]) over one of NPART channel groups
-  constexpr int TDM = MONO ? TD_MONO : TD; // this kernel's tile depth
-  constexpr int NOUT = MONO ? TDM : 2 * TDM, NPART = 64 / NOUT;
-  const int o = l & (NOUT - 1), fr = o & (TDM - 1), ch = o / TDM, part = (l & 63) / NOUT;
+  constexpr int NOUT = MONO ? TD : 2 * TD, NPART = 64 / NOUT;
+  const int o = l & (NOUT - 1), fr = o & (TD - 1), ch = o / TD, part = (l & 63) / NOUT;
   const double *col = tile + (part * (Ppad / NPART)) * ROW + o;
   double gLm = 0.0, gRm = 0.0;
   if (MONO) { const double ang = (0.25 * M_PI) * (0.0 + 1.); gLm = cos(ang); gRm = sin(ang); } // stereo(0), stereo.h:18-27, as at note-on
@@ -351,30 +341,25 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
   };
   if (__any(r.active && r.irregular)) atomicOr(b_error_flags, RA_ERR_BOOKKEEPING); // see regime_setup
 
-  // The straight-line code over a span of SPAN samples that no lane's transition falls into: SPAN = one tile (LENC; 0: the runtime n_rt,
-  // a piece of a tile) or, PAIR, two whole tiles that share this set-up — the second one is run by clean_second after the first tile's
-  // channel sum.  Returns false (nothing done) if some lane is not clean over the span.
-  double pr_tn = 0.0, pr_da = 0.0, pr_dl = 0.0; // what the second tile of a pair needs from the set-up
-  int pr_kind = 0;                              // 0: no second tile pending; else 1 + the specialisation (0 steady, 1 glide, 2 hi, 3 kvar)
-  auto clean_span = [&](auto len_tag, auto pair_tag, int off, int n_rt) -> bool {
+  // LEN (compile time; 0: n_rt) consecutive samples of the tile, written to row entries off .. off + LEN - 1, by the straight-line code —
+  // if no lane of the wave has a transition inside them; otherwise nothing is produced and the caller cuts the span shorter.
+  auto clean_span = [&](auto len_tag, int off, int n_rt) -> bool {
     constexpr int LENC = decltype(len_tag)::value;
-    constexpr bool PAIR = decltype(pair_tag)::value;
-    const int LEN = LENC ? LENC : n_rt;          // samples produced now
-    const int SPAN = PAIR ? 2 * LEN : LEN;       // samples the set-up covers
+    const int LEN = LENC ? LENC : n_rt;
     double *row = mine + off;
     // a span is clean for a lane if no transition can fall inside it: then the loop needs no per-sample checks
     double step0 = 0.0;
     if (r.active && r.gliding) step0 = fma(r.alpha - 1.0, c.cur, r.beta); // cur increment of the span's first step
-    bool clean = !r.active || (!stepped0 && r.steps_left >= SPAN &&
-                               (!r.gliding || (fabs(r.alpha - 1.0) < 1e-2 && c.cur + (SPAN - 1) * fabs(step0) * 1.1 <= lim)));
+    bool clean = !r.active || (!stepped0 && r.steps_left >= LEN &&
+                               (!r.gliding || (fabs(r.alpha - 1.0) < 1e-2 && c.cur + (LEN - 1) * fabs(step0) * 1.1 <= lim)));
     // Anti-aliasing gain of a glide above fs/8, (1 / inc - 1) / 3 between inc = 1/4 and 1 (freqAliasingMultiplicator, audioelement.h:466-483):
     // over a span it follows the secant between its values at the span's first and last increment (1 / inc from the running reciprocal,
-    // two Newton steps each; the function's curvature over a span leaves < 1e-6 of the gain).  A span in which the increment crosses 1/4
+    // two Newton steps each; the function's curvature over a span leaves < 3e-7 of the gain).  A span in which the increment crosses 1/4
     // or 1 is not clean (the checked step evaluates the function).
     double al0 = c.alias, al_da = 0.0;
     const double al_dda = 0.0;
     if (clean && r.active && r.gliding && r.hi) {
-      const double f0 = fma(r.slope, c.cur, r.base), df = r.slope * step0, fl = fma((double)(SPAN - 1), df, f0); // first and last increment
+      const double f0 = fma(r.slope, c.cur, r.base), df = r.slope * step0, fl = fma((double)(LEN - 1), df, f0); // first and last increment
       const double flo = f0 < fl ? f0 : fl, fhi = f0 < fl ? fl : f0;
       double rf = r.rf * fma(-f0, r.rf, 2.0);
       rf = rf * fma(-f0, rf, 2.0);
@@ -385,81 +370,46 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
         double rl = rf * fma(-fl, rf, 2.0);
         rl = rl * fma(-fl, rl, 2.0);
         al0 = fma(rf, 1. / 3., -1. / 3.);
-        const double inv = LENC ? 1.0 / (SPAN - 1) : (SPAN > 1 ? 1.0 / (double)(SPAN - 1) : 0.0);
+        const double inv = LENC == TD ? 1.0 / (TD - 1) : (LEN > 1 ? 1.0 / (double)(LEN - 1) : 0.0);
         al_da = ((rl - rf) * (1. / 3.)) * inv;
-        // the secant of a convex function lies above it by f'' (fl - f0)^2 x (1 - x) / 2, mean f'' (fl - f0)^2 / 12 with f'' = 2 / (3 inc^3):
-        // the line is lowered by that mean (the error that is left averages to zero over the span)
-        const double dfl = fl - f0;
-        al0 = fma(-(rf * rf) * rf, (dfl * dfl) * (1. / 18.), al0);
       } else clean = false;
     }
     if (!__all(clean)) return false;
     const bool any_glide = __any(r.active && r.gliding);
-    int kind = 0;
-    if (any_glide) kind = __any(r.active && r.kvar) ? 3 : __any(r.active && r.gliding && r.hi) ? 2 : 1;
-    double tn = 0.0, dl = 0.0;
     if (r.active) {
       c.alias = al0; // (its own value for lanes whose gain does not move)
-      if (kind == 0) { clk.tally<0>(); clean_tile<LENC, false, false, false, MONO>(c, r, k.max_filter_inc, 1.0, 0.0, 0.0, 0.0, 0.0, row, LEN); }
+      if (!any_glide) { clk.tally<0>(); clean_tile<LENC, false, false, false, MONO>(c, r, k.max_filter_inc, 1.0, 0.0, 0.0, 0.0, 0.0, row, LEN); }
       else {
         // Rotation of `mult` per step while gliding: pi (inc_i - inc_{i-1}).  The span's first step turns by d0 = pi (inc_0 - inc),
         // whatever the oscillator's increment currently is (0 right after a note change); the later steps turn by
         // pi slope (cur_i - cur_{i-1}), a geometric sequence with ratio alpha (|alpha - 1| ~ 1e-5): their mean serves all of them,
         // as its tangent (clean_tile).
-        double cd0 = 1.0, sd0 = 0.0, tn2 = 0.0, dl2 = 0.0;
+        double cd0 = 1.0, sd0 = 0.0, tn = 0.0;
         if (r.gliding) {
           const double d0 = M_PI * (fma(r.slope, c.cur, r.base) - c.inc);
-          const double ps = (M_PI * r.slope) * step0, am1 = r.alpha - 1.0;
-          const double dA = ps * (1.0 + 0.5 * (LEN - 2) * am1);
+          const double dA = (M_PI * r.slope) * step0 * (1.0 + 0.5 * (LEN - 2) * (r.alpha - 1.0));
           double d2 = d0 * d0;
           sd0 = d0 * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
           cd0 = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
           d2 = dA * dA;
           tn = dA * fma(d2, fma(d2, 2.0 / 15.0, 1.0 / 3.0), 1.0); // tan: |dA| ~ 1e-5, the series' remainder ~ dA^7
-          // over the tile's m' = LEN - 1 later steps the even spread runs ahead of the exact (linearly growing) rotation by
-          // b (j+1)(m'-1-j)/2 at step j, b = pi slope step0 (alpha - 1); the oscillator integrates that: the sum b (m'-1) m' (m'+1) / 12
-          // is taken back out at the end of the tile
-          dl = ps * am1 * ((double)(LEN - 2) * (double)(LEN - 1) * (double)LEN * (1.0 / 12.0));
-          if (PAIR) { // the second tile's LEN steps turn by pi slope step0 alpha^(LEN - 1 + k), k = 0 .. LEN - 1: their own mean and sum
-            const double dB = ps * (1.0 + 1.5 * (LEN - 1) * am1);
-            d2 = dB * dB;
-            tn2 = dB * fma(d2, fma(d2, 2.0 / 15.0, 1.0 / 3.0), 1.0);
-            dl2 = ps * am1 * ((double)(LEN - 1) * (double)LEN * (double)(LEN + 1) * (1.0 / 12.0));
-          }
         }
-        if (kind == 3) { clk.tally<3>(); clean_tile<LENC, true, true, true, MONO>(c, r, k.max_filter_inc, cd0, sd0, tn, al_da, al_dda, row, LEN); }
-        else if (kind == 2) { clk.tally<2>(); clean_tile<LENC, true, true, false, MONO>(c, r, k.max_filter_inc, cd0, sd0, tn, al_da, al_dda, row, LEN); }
-        else { clk.tally<1>(); clean_tile<LENC, true, false, false, MONO>(c, r, k.max_filter_inc, cd0, sd0, tn, 0.0, 0.0, row, LEN); }
-        { const double re = fma(c.cim, dl, c.cre), im = fma(-c.cre, dl, c.cim); c.cre = re; c.cim = im; }
-        tn = tn2; dl = dl2; // (what a pair's second tile runs with)
+        if (__any(r.active && r.kvar)) clk.tally<3>(); else if (__any(r.active && r.gliding && r.hi)) clk.tally<2>(); else clk.tally<1>();
+        if (__any(r.active && r.kvar)) clean_tile<LENC, true, true, true, MONO>(c, r, k.max_filter_inc, cd0, sd0, tn, al_da, al_dda, row, LEN);
+        else if (__any(r.active && r.gliding && r.hi)) clean_tile<LENC, true, true, false, MONO>(c, r, k.max_filter_inc, cd0, sd0, tn, al_da, al_dda, row, LEN);
+        else clean_tile<LENC, true, false, false, MONO>(c, r, k.max_filter_inc, cd0, sd0, tn, 0.0, 0.0, row, LEN);
+        // over the m' = LEN - 1 later steps the even spread runs ahead of the exact (linearly growing) rotation by b (j+1)(m'-1-j)/2
+        // at step j, b = pi slope step0 (alpha - 1); the oscillator has integrated that: take the sum b (m'-1) m' (m'+1) / 12 back out
+        const double dl = (M_PI * r.slope) * step0 * (r.alpha - 1.0) * ((double)(LEN - 2) * (double)(LEN - 1) * (double)LEN * (1.0 / 12.0));
+        const double re = fma(c.cim, dl, c.cre), im = fma(-c.cre, dl, c.cim);
+        c.cre = re; c.cim = im;
       }
       r.pending += LEN; r.steps_left -= LEN;
     } else {
       for (int i = 0; i < LEN; ++i) { row[i] = 0.0; if (!MONO) row[TD + i] = 0.0; }
     }
-    if (PAIR) { pr_kind = 1 + kind; pr_tn = tn; pr_da = al_da; pr_dl = dl; }
     clk.lap<0>();
     return true;
-  };
-  // the second tile of a pair: no set-up, the first step is a regular one
-  auto clean_second = [&](auto len_tag) {
-    constexpr int LENC = decltype(len_tag)::value;
-    const int kind = pr_kind - 1;
-    pr_kind = 0;
-    if (r.active) {
-      if (kind == 0) clean_tile<LENC, false, false, false, MONO, true>(c, r, k.max_filter_inc, 1.0, 0.0, 0.0, 0.0, 0.0, mine, LENC);
-      else {
-        if (kind == 3) clean_tile<LENC, true, true, true, MONO, true>(c, r, k.max_filter_inc, 1.0, 0.0, pr_tn, pr_da, 0.0, mine, LENC);
-        else if (kind == 2) clean_tile<LENC, true, true, false, MONO, true>(c, r, k.max_filter_inc, 1.0, 0.0, pr_tn, pr_da, 0.0, mine, LENC);
-        else clean_tile<LENC, true, false, false, MONO, true>(c, r, k.max_filter_inc, 1.0, 0.0, pr_tn, 0.0, 0.0, mine, LENC);
-        const double re = fma(c.cim, pr_dl, c.cre), im = fma(-c.cre, pr_dl, c.cim);
-        c.cre = re; c.cim = im;
-      }
-      r.pending += LENC; r.steps_left -= LENC;
-    } else {
-      for (int i = 0; i < LENC; ++i) { mine[i] = 0.0; if (!MONO) mine[TD + i] = 0.0; }
-    }
-    clk.lap<0>();
   };
   // how many of the next `remaining` samples this lane can take before its next transition (an estimate that errs on the short side for
   // the glide's end: the exact test is clean_span's)
@@ -482,20 +432,14 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
   };
 
   while (t < seg_end) {
-    const int m = (int)min((int64_t)TDM, seg_end - t);
+    const int m = (int)min((int64_t)TD, seg_end - t);
     // The whole tile in one unrolled go if no lane has a transition in it (~9 of 10 tiles).  Otherwise it is cut at the transitions: clean
     // pieces of whatever length the wave allows (rolled loop), and at a sample where some lane changes regime one checked step for the
     // wave — an envelope stage change, the end of a glide, a note's first sample (already taken by the propagate kernel).
-    // Two whole tiles ahead with no transition in either: one set-up serves both (the second runs after this tile's channel sum).
-    int pos = 0;
-    if (pr_kind) { clean_second(std::integral_constant<int, TDM>{}); pos = TDM; }
-    else if (m == TDM) {
-      if (seg_end - t >= 2 * TDM && clean_span(std::integral_constant<int, TDM>{}, std::true_type{}, 0, TDM)) pos = TDM;
-      else if (clean_span(std::integral_constant<int, TDM>{}, std::false_type{}, 0, TDM)) pos = TDM;
-    }
+    int pos = (m == TD && clean_span(std::integral_constant<int, TD>{}, 0, TD)) ? TD : 0;
     while (pos < m) {
       const int nn = wave_min(safe_len(m - pos));
-      if (nn >= 1 && clean_span(std::integral_constant<int, 0>{}, std::false_type{}, pos, nn)) { pos += nn; continue; }
+      if (nn >= 1 && clean_span(std::integral_constant<int, 0>{}, pos, nn)) { pos += nn; continue; }
       double v = 0.0;
       if (r.active && !(RA_ABL & 4)) {
         if (stepped0) v = c.vol * ((c.alias * c.cim) * c.value); // already stepped (propagate kernel): StereoPanned::imag of the state as loaded
