@@ -23,6 +23,13 @@ extern __shared__ __align__(16) unsigned char ra_smem_trk[];
 
 namespace {
 
+__device__ inline double ra_readlane_f64(double v, int lane) { // lane is wave-uniform
+  const long long u = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u & 0xffffffffll), lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)u >> 32), lane);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // Enveloped::setAngleIncrements, audioelement.h:218-225 with sound.functions.h:69-76
 __device__ inline int min_change_for(float freq, int sample_rate) {
   float inc_f = 2 * (freq * 1.f) / sample_rate; // freq_to_angle_increment<float>, sound.functions.h:58-62
@@ -104,7 +111,25 @@ __global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, i
 
     clk.lap<0>(); sumA += A; sumPlayed += n_played;
     // ---- phase 1: track_pitches, algo.cpp:256-305 (sequential two-pointer scan) ----
-    if (lane == 0) {
+    if (A <= 64 && n_played <= 64) {
+      // The scan is a chain of comparisons; run by one lane out of LDS it costs two dependent LDS round trips per step (~200 cycles).
+      // Here lane i holds item i's pitch and played note i's pitch in registers, the scan's operands are read with v_readlane (the
+      // indices are wave-uniform) and its control flow is scalar: ~8 instructions per step.
+      const double my_pitch = lane < A ? pitch[lane] : 0.0, my_played = lane < n_played ? pl_pitch[lane] : 0.0;
+      int my_pc = -1, my_cont = 0;
+      int it = 0;
+      for (int idx = 0; idx < A; ++idx) {
+        const double np = ra_readlane_f64(my_pitch, idx);
+        for (; it != n_played; ++it) {
+          const double q = ra_readlane_f64(my_played, it);
+          if (q < np - p.max_track) continue;
+          if (q <= np + p.max_track) { if (lane == idx) my_pc = it; if (lane == it) my_cont = 1; ++it; }
+          break;
+        }
+      }
+      if (lane < A) pc[lane] = my_pc;
+      if (lane < n_played) cont[lane] = my_cont;
+    } else if (lane == 0) {
       int it = 0;
       for (int idx = 0; idx < A; ++idx) {
         double np = pitch[idx];
