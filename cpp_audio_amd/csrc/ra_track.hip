@@ -112,23 +112,27 @@ __global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, i
     clk.lap<0>(); sumA += A; sumPlayed += n_played;
     // ---- phase 1: track_pitches, algo.cpp:256-305 (sequential two-pointer scan) ----
     if (A <= 64 && n_played <= 64) {
-      // The scan is a chain of comparisons; run by one lane out of LDS it costs two dependent LDS round trips per step (~200 cycles).
-      // Here lane i holds item i's pitch and played note i's pitch in registers, the scan's operands are read with v_readlane (the
-      // indices are wave-uniform) and its control flow is scalar: ~8 instructions per step.
+      // The scan is a chain of comparisons; run by one lane out of LDS it costs two dependent LDS round trips per step (~200 cycles per
+      // step of either pointer).  Here lane j holds played note j's pitch: for item idx (its pitch broadcast with v_readlane) one vector
+      // comparison gives the mask of notes not below the window, the scan's pointer `it` masks off the notes already passed, the first
+      // bit left is where the reference's inner loop stops, and a second comparison says whether that note lies inside the window —
+      // one short scalar step per item, no inner loop.  (Played pitches ascend: sort_by_current_pitch, algo.cpp:434-439.)
       const double my_pitch = lane < A ? pitch[lane] : 0.0, my_played = lane < n_played ? pl_pitch[lane] : 0.0;
-      int my_pc = -1, my_cont = 0;
+      const unsigned long long valid = n_played == 64 ? ~0ull : ((1ull << n_played) - 1ull);
+      int my_pc = -1;
+      unsigned long long cont_mask = 0ull;
       int it = 0;
-      for (int idx = 0; idx < A; ++idx) {
+      for (int idx = 0; idx < A && it < n_played; ++idx) {
         const double np = ra_readlane_f64(my_pitch, idx);
-        for (; it != n_played; ++it) {
-          const double q = ra_readlane_f64(my_played, it);
-          if (q < np - p.max_track) continue;
-          if (q <= np + p.max_track) { if (lane == idx) my_pc = it; if (lane == it) my_cont = 1; ++it; }
-          break;
-        }
+        const unsigned long long not_below = __ballot(!(my_played < np - p.max_track)) & valid & (~0ull << it);
+        if (!not_below) { it = n_played; break; }      // every remaining note lies below this (and every later) window
+        const int j = __ffsll((long long)not_below) - 1;
+        const unsigned long long inside = __ballot(my_played <= np + p.max_track);
+        if ((inside >> j) & 1ull) { if (lane == idx) my_pc = j; cont_mask |= 1ull << j; it = j + 1; }
+        else it = j;
       }
       if (lane < A) pc[lane] = my_pc;
-      if (lane < n_played) cont[lane] = my_cont;
+      if (lane < n_played) cont[lane] = (int)((cont_mask >> lane) & 1ull);
     } else if (lane == 0) {
       int it = 0;
       for (int idx = 0; idx < A; ++idx) {
