@@ -370,7 +370,8 @@ int build_tables(ra_context *c) {
   p.vol_mod = cfg.voice_volume;
   p.vol_car = cfg.carrier_volume;
   p.vol_voc = cfg.vocoder_volume;
-  p.render_mode = cfg.reference_order >= 2 ? cfg.reference_order : 0;
+  p.render_mode = (cfg.reference_order == 2 || cfg.reference_order == 3) ? cfg.reference_order : 0;
+  p.render_pack = cfg.reference_order != 4;
   p.fb_gain = cfg.analysis_output_feedback_gain;
   p.fb_sz = std::max(0, static_cast<int>(0.5f + cfg.output_delay_seconds * cfg.sample_rate)); // lib.cpp:1638-1639
   p.voc_enabled = (cfg.voice_volume != 0.f || cfg.carrier_volume != 0.f || cfg.vocoder_volume != 0.f) ? 1 : 0;
@@ -861,11 +862,17 @@ int process_block_impl(ra_context *c, const float *d_voice, const float *d_carri
     static const int order = std::getenv("RA_PIPELINE_ORDER") ? std::atoi(std::getenv("RA_PIPELINE_ORDER")) : 0;
     static const int lead = std::getenv("RA_PIPELINE_LEAD") ? std::max(1, std::atoi(std::getenv("RA_PIPELINE_LEAD"))) : 2;
     if (order == 1 && !one_queue) sA = sR;
+    static const int agroup = std::getenv("RA_PIPELINE_AGROUP") ? std::max(1, std::atoi(std::getenv("RA_PIPELINE_AGROUP"))) : 1; // tuning aid
     auto front = [&](int i) -> int { // analysis of chunk i, and the two chains that hang off it
       const RaSpan sp = span_of(i);
-      RA_TRY(timed_launch(c, ST_ANALYSIS, sA, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, sp.fb0, sp.nfb, nfb, sA); }));
-      HIP_TRY(hipEventRecord(c->ev_chunk[0][i], sA));
-      HIP_TRY(hipStreamWaitEvent(sT, c->ev_chunk[0][i], 0));
+      // one analysis launch may cover several chunks (from the second chunk on: the short first one gets the chain going)
+      const int a_first = (i == 0) ? 0 : 1 + ((i - 1) / agroup) * agroup, a_last = (i == 0) ? 0 : std::min(n_chunks - 1, a_first + agroup - 1);
+      if (i == a_first) {
+        const int64_t fb0 = cut(a_first), fb1 = (a_last == n_chunks - 1) ? nfb : cut(a_last + 1);
+        RA_TRY(timed_launch(c, ST_ANALYSIS, sA, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, fb0, fb1 - fb0, nfb, sA); }));
+        HIP_TRY(hipEventRecord(c->ev_chunk[0][a_first], sA));
+      }
+      HIP_TRY(hipStreamWaitEvent(sT, c->ev_chunk[0][a_first], 0));
       RA_TRY(timed_launch(c, ST_TRACK, sT, [&] { ra_launch_track(p, b, f_lo, sp.fb0, sp.nfb, sT); }));
       HIP_TRY(hipEventRecord(c->ev_chunk[1][i], sT));
       HIP_TRY(hipStreamWaitEvent(sP, c->ev_chunk[1][i], 0));
@@ -1013,7 +1020,7 @@ int ra_create(const ra_config *cfg, int32_t n_streams, int32_t device, ra_contex
   if (!r) r = alloc_state(c);
   if (!r) r = init_state(c);
   if (!r && std::getenv("RA_PHASE_CLOCKS")) {
-    r = dev_alloc(c, &c->dbg_clk, 64, true);
+    r = dev_alloc(c, &c->dbg_clk, 128, true);
   }
   if (r) { std::string keep = g_last_error; ra_destroy(c); g_last_error = keep; return r; }
   *out = c;
@@ -1025,10 +1032,10 @@ void ra_destroy(ra_context *c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize(); // asynchronous blocks may still be running on the internal streams
   if (c->dbg_clk) { // tuning aid: ticks of the 100 MHz s_memtime counter per kernel phase, summed over workgroups
-    unsigned long long h[64];
+    unsigned long long h[128];
     if (hipMemcpy(h, c->dbg_clk, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
       std::fprintf(stderr, "[resynth_amd] phase clocks:");
-      for (int i = 0; i < 64; ++i) if (h[i]) std::fprintf(stderr, " [%d]=%llu", i, h[i]);
+      for (int i = 0; i < 128; ++i) if (h[i]) std::fprintf(stderr, " [%d]=%llu", i, h[i]);
       std::fprintf(stderr, "\n");
     }
   }

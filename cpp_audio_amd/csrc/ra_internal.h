@@ -44,6 +44,7 @@ struct RaParams {
   float fb_gain;   // output -> analysis feedback (lib.cpp:1626-1652): gain, and the delay in frames
   int fb_sz;
   int render_mode; // diagnostics: 0 regime renderer, 2 hop-parallel with the reference-order step, 3 with the cheap generic step
+  int render_pack; // 1: two hops with at most 32 sounding channels each share a wave (ra_synth.hip: render_pair); 0 (reference_order 4): never
 };
 
 // ---- analysis -> tracking hand-off: one list per (stream, frame) ----------------------------------
@@ -125,7 +126,7 @@ struct RaBuffers {
   float *fb_block;          // [n_streams][n] mono output of the current block, written by the render as it goes
   int64_t fb_hist_len, fb_block_cap;
   double *dbg_sqmag;        // optional [frames][M] tap of |X|^2 (ra_sqmag), normally null
-  unsigned long long *dbg_clk; // optional [64] in-kernel phase clocks (env RA_PHASE_CLOCKS=1, printed by ra_destroy), normally null
+  unsigned long long *dbg_clk; // optional [128] in-kernel phase clocks (env RA_PHASE_CLOCKS=1, printed by ra_destroy), normally null
   // ---- post: "limit" ----
   double *post_d;           // [n_streams][n][2] the double mix of the block, read by the limiter kernel
   int64_t post_cap;

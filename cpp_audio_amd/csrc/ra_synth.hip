@@ -281,11 +281,13 @@ __device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, dou
   }
 }
 
-template <bool MONO>
+template <bool MONO, bool PACKED>
 __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &k, const RaParams &p, int s, int l, int64_t t, int64_t seg_end,
                                          int64_t t0, int64_t n, const double *__restrict__ mix, float *__restrict__ out, double *__restrict__ out_d,
-                                         int32_t *b_error_flags, float *__restrict__ fb_mono, RaPhaseClock &clk) {
-  const int Ppad = p.Ppad;
+                                         int32_t *b_error_flags, float *__restrict__ fb_mono, RaPhaseClock &clk, const int Ppad, const int64_t dB) {
+  constexpr bool packed = PACKED;
+  // packed (Ppad = 64, one wave): lanes 0..31 carry the sounding channels of the hop that starts at t, lanes 32..63 those of the hop that
+  // starts at t + dB and has the same length; the channel sums then stop at 32 lanes and each half writes its own frames.
   const double inv_dur = 1.0 / k.dur;
   const double lim = k.dur - 0.5; // a glide step that finds cur > lim clamps (InterpolatedFreq::step, audioelement.h:2768-2770)
   bool stepped0 = (c.flags & FL_STEPPED0) != 0; // this hop's first step was taken by the propagate kernel: sample 0 only reads the state
@@ -461,12 +463,14 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
           for (int j = 0; j < NJ; ++j) acc += q[j * ROW];
         }
       }
-      acc += lane_xor32_low(acc);
+      if (!packed) acc += lane_xor32_low(acc);
       if (NPART >= 4) acc += lane_xor16_even(acc);
       if (NPART >= 8) acc += lane_ror8(acc);
+      const int lo_lane = packed ? (l & 31) : l; // packed: lanes 32.. hold the second hop's frames (even rows of 16: where the swaps are valid)
+      const int64_t t_mine = (packed && l >= 32) ? t + dB : t;
       if (MONO) {
-        if (l < NOUT && fr < m) {
-          const int64_t rel = (t - t0) + fr;
+        if (lo_lane < NOUT && fr < m) {
+          const int64_t rel = (t_mine - t0) + fr;
           double oL = gLm * acc, oR = gRm * acc;
           if (mix) { oL += mix[rel]; oR += mix[rel]; }
           if (out) { // one 8-byte store per frame when the caller's buffer allows it (two 4-byte stores make partial-line writes)
@@ -478,8 +482,8 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
           if (fb_mono) fb_mono[rel] = (float)(oL + oR); // what the post processor publishes to the analysis (lib.cpp:1262-1272, pubsub.cpp:92)
         }
       } else {
-        const bool w = l < NOUT && fr < m;
-        const int64_t rel = (t - t0) + fr;
+        const bool w = lo_lane < NOUT && fr < m;
+        const int64_t rel = (t_mine - t0) + fr;
         if (w && mix) acc += mix[rel];
         const double other = (TD == 8) ? lane_ror8(acc) : lane_xor16_even(acc); // the other output channel of the same frame (lane +- TD)
         if (w) {
@@ -638,34 +642,100 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) RA_PROP_OCC ra_synth_propagat
 }
 
 // ---- K3b: render one segment ----------------------------------------------------------------------------------------
-template <bool DIAG, bool MONO>
-__device__ inline void render_segment(const RaParams &p, const RaBuffers &b, const RaSpan &sp, float *__restrict__ out, double *__restrict__ out_d) {
-  // blockDim.y > 1 (RA_RENDER_GROUP, single-wave streams only): wave y of the workgroup renders its own hop, nothing is shared between the
-  // waves.  Grouping four hops into a workgroup makes the renderer release wave slots on all four SIMDs of a CU at once, which lets the
-  // 4-wave analysis workgroups queued beside it be placed (their launches shrink from 18 to 13 ms per step), but the renderer then loses
-  // more than the chain gains: 24.6 ms per step against 22.7 ms with one hop per workgroup (the default).
-  const int wy = __builtin_amdgcn_readfirstlane((int)threadIdx.y); // wave-uniform (blockDim.x is a multiple of 64): keeps the hop's loops scalar
-  const int i = blockIdx.x * blockDim.y + wy, s = blockIdx.y, l = threadIdx.x, Ppad = p.Ppad;
+template <bool MONO>
+__device__ inline void render_diag_segment(const RaParams &p, const RaBuffers &b, const RaSpan &sp, float *__restrict__ out, double *__restrict__ out_d) {
+  const int i = blockIdx.x, s = blockIdx.y, l = threadIdx.x, Ppad = p.Ppad;
   if (i > sp.nfb) return;
   const int64_t seg_begin = (i == 0) ? sp.ct0 : ra_fire_sample(p.N, p.H, sp.f_lo + sp.fb0 + i - 1);
   const int64_t seg_end = (i < sp.nfb) ? ra_fire_sample(p.N, p.H, sp.f_lo + sp.fb0 + i) : sp.ct1;
   if (seg_end <= seg_begin) return;
   const size_t seg = (size_t)s * b.seg_cap + sp.seg0 + i;
-  RaPhaseClock clk(b.dbg_clk, l == 0);
-  const unsigned long long wg_t0 = clk.t;
   Chan c;
   load_chan(c, b.seg_sd + seg * SD_COUNT * Ppad, b.seg_si + seg * SI_COUNT * Ppad, Ppad, l);
   chan_from_phase(c);
-  clk.mark(20);
   const SynConst k = syn_const(p, s);
   const double *mix = (p.voc_enabled && b.voc_mix) ? b.voc_mix + (size_t)s * sp.n : nullptr;
-  if (DIAG) {
-    SynLds L = carve(ra_smem_syn, Ppad);
-    if (p.render_mode == 2) render_range<false>(c, L, k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
-    else render_range<true>(c, L, k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
-  } else render_range_fast<MONO>(c, reinterpret_cast<double *>(ra_smem_syn) + (size_t)wy * Ppad * (MONO ? TROW_MONO : TROW), k, p, s, l, seg_begin, seg_end,
-                                 sp.t0, sp.n, mix, out, out_d, b.error_flags,
-                                 (b.fb_block && !p.post_limit) ? b.fb_block + (size_t)s * sp.n : nullptr, clk); // with post "limit" the limiter publishes
+  SynLds L = carve(ra_smem_syn, Ppad);
+  if (p.render_mode == 2) render_range<false>(c, L, k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
+  else render_range<true>(c, L, k, p, s, l, seg_begin, seg_end, sp.t0, sp.n, mix, out, out_d);
+}
+
+// A workgroup renders two consecutive hops.  Channels are handed out first-free, so a stream that plays ~30 partials leaves half of a
+// 64-lane wave (and every further wave of a workgroup) idle: measured on the BASELINE shapes, 54 % of the hops of configs[1] and 97 % of
+// those of configs[3] (128 channels) have at most 32 sounding channels.  When both hops of the pair do and have the same length, their
+// sounding channels are compacted into the two halves of ONE wave (the workgroup's other waves leave) and the pair costs what one hop
+// did; otherwise the hops are rendered one after the other by the whole workgroup as before.
+template <bool MONO>
+__device__ inline void render_pair(const RaParams &p, const RaBuffers &b, const RaSpan &sp, float *__restrict__ out, double *__restrict__ out_d) {
+  // blockDim.y > 1 (RA_RENDER_GROUP, single-wave streams only): wave y of the workgroup renders its own pair, nothing is shared between the
+  // waves (a tuning aid: grouping makes the renderer release wave slots on all SIMDs of a CU at once; measured slower, not the default).
+  const int wy = __builtin_amdgcn_readfirstlane((int)threadIdx.y); // wave-uniform (blockDim.x is a multiple of 64): keeps the hop's loops scalar
+  // One workgroup per hop, as before.  Hop 0 of a span is a partial one (it starts where the span does) and goes alone; the pairs are hops
+  // (1, 2), (3, 4), ...: the workgroup of the first hop of a pair renders both if they can be packed and the workgroup of the second one,
+  // which takes the same decision from the same data, leaves; otherwise each renders its own hop.
+  const int ih = blockIdx.x * blockDim.y + wy, s = blockIdx.y, l = threadIdx.x, Ppad = p.Ppad;
+  if (ih > sp.nfb) return;
+  const bool second = ih > 0 && !(ih & 1);            // the second hop of a pair
+  const int i0 = second ? ih - 1 : ih;                // the pair's first hop (or the lone hop)
+  const bool two = i0 > 0 && i0 + 1 <= sp.nfb;
+  auto hop_begin = [&](int i) -> int64_t { return (i == 0) ? sp.ct0 : ra_fire_sample(p.N, p.H, sp.f_lo + sp.fb0 + i - 1); };
+  auto hop_end = [&](int i) -> int64_t { return (i < sp.nfb) ? ra_fire_sample(p.N, p.H, sp.f_lo + sp.fb0 + i) : sp.ct1; };
+  const int64_t beg0 = hop_begin(i0), end0 = hop_end(i0), beg1 = two ? hop_begin(i0 + 1) : 0, end1 = two ? hop_end(i0 + 1) : 0;
+  const size_t seg0 = (size_t)s * b.seg_cap + sp.seg0 + i0;
+  RaPhaseClock clk(b.dbg_clk, l == 0);
+  const unsigned long long wg_t0 = clk.t;
+  const SynConst k = syn_const(p, s);
+  const double *mix = (p.voc_enabled && b.voc_mix) ? b.voc_mix + (size_t)s * sp.n : nullptr;
+  double *tile = reinterpret_cast<double *>(ra_smem_syn) + (size_t)wy * Ppad * (MONO ? TROW_MONO : TROW);
+  float *fb_mono = (b.fb_block && !p.post_limit) ? b.fb_block + (size_t)s * sp.n : nullptr; // with post "limit" the limiter publishes
+
+  // sounding channels of both hops: every wave looks at all of them (Ppad / 64 state words per lane and hop), so the decision needs no barrier
+  bool pack = end0 > beg0 && end1 > beg1 && (end0 - beg0) == (end1 - beg1) && p.render_pack && !(RA_ABL & 8);
+  int src = -1; // packed: the channel this lane renders (lanes 0..31: first hop, 32..63: second), -1: none
+  if (pack) {
+    const int lw = l & 63;
+    int cnt[2] = {0, 0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int32_t *st = b.seg_si + (seg0 + h) * SI_COUNT * Ppad + SI_ENV_STATE * Ppad;
+      for (int blk = 0; blk < (Ppad >> 6); ++blk) {
+        const int stv = st[blk * 64 + lw];
+        const bool act = stv != ENV_SOON && stv != ENV_DONE2; // rt_active
+        const unsigned long long m = __ballot(act);
+        const int rank = cnt[h] + __popcll(m & ((1ull << lw) - 1ull));
+        // the lane that will render this channel is (h * 32 + rank): hand the channel index over through the wave's own tile
+        if (act && rank < 32 && l < 64) reinterpret_cast<int *>(tile)[h * 32 + rank] = blk * 64 + lw;
+        cnt[h] += __popcll(m);
+      }
+    }
+    pack = cnt[0] <= 32 && cnt[1] <= 32;
+    if (pack) {
+      if (l >= 64) return; // the other waves of the workgroup have nothing to do (no barrier follows on this path)
+      const int h = l >> 5;
+      if ((l & 31) < cnt[h]) src = reinterpret_cast<int *>(tile)[l]; // (one wave: its LDS operations execute in order)
+    }
+  }
+  if (pack && second) return; // rendered by the workgroup of the pair's first hop
+  if (clk.dst) atomicAdd(clk.dst + 64 + (pack ? 1 : 0), 1ull); // hops rendered alone / pairs rendered packed
+  Chan c;
+  if (pack) {
+    chan_init(c);
+    if (src >= 0) {
+      const size_t seg = seg0 + (l >> 5);
+      load_chan(c, b.seg_sd + seg * SD_COUNT * Ppad, b.seg_si + seg * SI_COUNT * Ppad, Ppad, src);
+      chan_from_phase(c);
+    }
+    clk.mark(20);
+    render_range_fast<MONO, true>(c, tile, k, p, s, l, beg0, end0, sp.t0, sp.n, mix, out, out_d, b.error_flags, fb_mono, clk, 64, beg1 - beg0);
+  } else {
+    const int64_t bh = second ? beg1 : beg0, eh = second ? end1 : end0;
+    if (eh <= bh) return;
+    const size_t seg = seg0 + (second ? 1 : 0);
+    load_chan(c, b.seg_sd + seg * SD_COUNT * Ppad, b.seg_si + seg * SI_COUNT * Ppad, Ppad, l);
+    chan_from_phase(c);
+    clk.mark(20);
+    render_range_fast<MONO, false>(c, tile, k, p, s, l, bh, eh, sp.t0, sp.n, mix, out, out_d, b.error_flags, fb_mono, clk, Ppad, 0);
+  }
   if (clk.dst) { // workgroup lifetime: maximum and a histogram in steps of 200 k ticks
     const unsigned long long d = __builtin_readcyclecounter() - wg_t0;
     atomicMax(clk.dst + 39, d);
@@ -673,15 +743,15 @@ __device__ inline void render_segment(const RaParams &p, const RaBuffers &b, con
   }
 }
 __global__ void __launch_bounds__(RA_MAX_CHANNELS) RA_REND_OCC ra_synth_render_kernel(RaParams p, RaBuffers b, RaSpan sp, float *__restrict__ out, double *__restrict__ out_d) {
-  render_segment<false, false>(p, b, sp, out, out_d);
+  render_pair<false>(p, b, sp, out, out_d);
 }
 // stereo_spread 0 (every channel panned to the centre): the two equal-for-all gains are applied after the channel sum
 __global__ void __launch_bounds__(RA_MAX_CHANNELS) RA_REND_OCC ra_synth_render_mono_kernel(RaParams p, RaBuffers b, RaSpan sp, float *__restrict__ out, double *__restrict__ out_d) {
-  render_segment<false, true>(p, b, sp, out, out_d);
+  render_pair<true>(p, b, sp, out, out_d);
 }
 // tuning aid (ra_config.reference_order 2 / 3): hop-parallel like the product kernel, but every sample takes the general step
 __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_synth_render_diag_kernel(RaParams p, RaBuffers b, RaSpan sp, float *__restrict__ out, double *__restrict__ out_d) {
-  render_segment<true, false>(p, b, sp, out, out_d);
+  render_diag_segment<false>(p, b, sp, out, out_d);
 }
 
 } // namespace
@@ -701,7 +771,10 @@ void ra_launch_synth_render(const RaParams &p, const RaBuffers &b, const RaSpan 
     hipLaunchKernelGGL(ra_synth_render_diag_kernel, grid, block, syn_lds_bytes(p.Ppad), st, p, b, sp, d_out, d_out_d);
     return;
   }
-  static const int group_env = std::getenv("RA_RENDER_GROUP") ? std::atoi(std::getenv("RA_RENDER_GROUP")) : 1; // tuning aid, see below
+  // hops per workgroup (single-wave streams).  The chip starts ~16 M workgroups per second: with packed pairs half of the one-wave workgroups
+  // leave at once and the 17 k workgroups of a chunk took longer to start than to run.  Two hops per workgroup, measured on configs[1] with
+  // packing: render alone 9.2 -> 8.3 ms, step 14.9 -> 13.7 ms; four: 16.3 ms (a four-wave workgroup wants a slot on every SIMD at once).
+  static const int group_env = std::getenv("RA_RENDER_GROUP") ? std::atoi(std::getenv("RA_RENDER_GROUP")) : 2;
   const unsigned group = (p.Ppad == 64) ? (unsigned)std::min(std::max(group_env, 1), RA_MAX_CHANNELS / 64) : 1u; // hops per workgroup
   const dim3 grid((unsigned)((sp.nfb + 1 + group - 1) / group), (unsigned)p.n_streams), block((unsigned)p.Ppad, group);
   const size_t lds = (size_t)group * p.Ppad * (p.stereo_spread == 0.f ? TROW_MONO : TROW) * sizeof(double); // the 8-frame tiles only

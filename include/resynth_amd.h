@@ -96,7 +96,9 @@ typedef struct ra_config {
 
   /* 0 (default): synthesis runs hop-parallel — per-hop channel states come from closed-form jumps, differing from
    * sample-by-sample stepping at rounding level (~1e-13).  1: one sample-serial launch per stream that follows the
-   * reference's operation order exactly (slow; for bit-level comparisons). */
+   * reference's operation order exactly (slow; for bit-level comparisons).  2 / 3 / 4 are tuning aids: hop-parallel with the general step
+   * on every sample (2: reference-order step, 3: the cheap generic step), and 4: the product renderer without the packing of two hops
+   * into one wavefront (which changes the order of the channel sum, i.e. the last bits). */
   int32_t reference_order;
 
   /* Feedback of the output into the analysis input (analyze_until_input_starvation, lib.cpp:1626-1652): analysis input k =

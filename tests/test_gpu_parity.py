@@ -116,6 +116,33 @@ def test_hop_parallel_vs_reference_order(api, sig):
     assert rms(outs[0], outs[1]) < 1e-8
 
 
+@pytest.mark.parametrize("kw", [
+    dict(stereo_spread=0.0),                                                                   # mono sum, 64 channels: one wave per hop
+    dict(stereo_spread=1.0),                                                                   # two sums per frame
+    dict(stereo_spread=1.0, window_size=8192, stride=2048, n_channels=128, use_autotune=1),    # two waves per hop: the second leaves when packed
+    dict(stereo_spread=0.0, n_channels=16, min_volume=0.002),                                  # few channels: every pair packs
+])
+def test_packed_hop_pairs_equal_unpacked(api, sig, kw):
+    # ra_synth.hip: render_pair renders two hops with <= 32 sounding channels each in the two halves of one wave; reference_order 4 turns
+    # that off.  Only the association of the channel sum changes: the doubles agree to rounding, the events are the same events.
+    x = np.concatenate([sig.make_streams(3, 96000, base_seed=5), sig.make_streams(2, 96000, kind="speech")])
+    res = []
+    for ro in (0, 4):
+        cfg = api.default_config(reference_order=ro, **dict(PARITY_KW, **kw))
+        with api.Context(cfg, 5, 0) as ctx:
+            out = ctx.process_host(x[:, :50000])                # two blocks
+            ev = [ctx.events(s) for s in range(5)]
+            out = np.concatenate([out, ctx.process_host(x[:, 50000:])], axis=1)
+            ev += [ctx.events(s) for s in range(5)]
+            assert ctx.stats().error_flags == 0
+            res.append((out.astype(np.float64), ev))
+    assert np.sqrt(np.mean(res[0][0] ** 2)) > 1e-3
+    assert np.max(np.abs(res[0][0] - res[1][0])) < 2e-7         # float32 outputs: an ulp of a sample near 1
+    assert rms(res[0][0], res[1][0]) < 1e-9
+    for a, b in zip(res[0][1], res[1][1]):
+        assert np.array_equal(a, b)
+
+
 def test_speech_like(api, oracle, sig):
     x = sig.make_streams(3, 72000, kind="speech")
     check_streams(api, oracle, x)
