@@ -71,6 +71,7 @@ struct ra_context {
   std::vector<int64_t> car_last_sample;
   std::vector<RaCarEv> car_upload[2];   // host images of the blocks' event lists (kept until the set is reused)
   std::vector<int32_t> car_upload_begin[2];
+  int64_t car_total_segs = 0;           // slots of the block's segment table (stage_carrier_events)
   bool pipeline_serial = false;         // measurement aid (ra_set_pipeline_serial): same chunks and launches, all on the caller's stream
   bool last_car_gen = false;            // the last block's carrier came from the synth (ra_get_carrier)
   // a block failed after it had started to change stream state (launches issued, histories rolled): the streams are then neither at the
@@ -379,6 +380,9 @@ int build_tables(ra_context *c) {
   p.voc_kind = cfg.vocoder_kind;
   p.car_P = p.voc_enabled ? cfg.carrier_n_channels : 0; // nothing hears the carrier synth while every vocoder volume is 0
   p.car_Ppad = ((p.car_P + 63) / 64) * 64;
+  p.car_CH = 4;
+  while (p.car_CH < p.car_P) p.car_CH *= 2;
+  p.car_serial = cfg.reference_order == 1;
   p.car_vol[0] = cfg.vocoder_carrier_noise_volume; p.car_vol[1] = cfg.vocoder_carrier_saw_volume; p.car_vol[2] = cfg.vocoder_carrier_triangle_volume;
   p.car_vol[3] = cfg.vocoder_carrier_square_volume; p.car_vol[4] = cfg.vocoder_carrier_sine_volume; p.car_vol[5] = cfg.vocoder_carrier_pulse_volume;
   p.car_pulse_width = cfg.vocoder_carrier_pulse_width;
@@ -673,6 +677,17 @@ int stage_carrier_events(ra_context *c, int64_t t0, int64_t n) {
     int r = dev_alloc(c, &b.car_ev, (size_t)b.car_ev_cap, false);
     if (r) { b.car_ev_cap = 0; return r; }
   }
+  // the segment table of the time-parallel synth (ra_carrier.hip): per stream one slot per 256 samples, one for the ragged end, one per event
+  c->car_total_segs = p.car_serial ? 0 : (int64_t)S * ((n + 255) / 256 + 1) + (int64_t)total;
+  if (c->car_total_segs > b.car_seg_cap) {
+    HIP_TRY(hipDeviceSynchronize());
+    dev_free(c, b.car_seg_info); dev_free(c, b.car_seg_d); dev_free(c, b.car_seg_i);
+    b.car_seg_cap = c->car_total_segs + c->car_total_segs / 8;
+    int r = dev_alloc(c, &b.car_seg_info, (size_t)b.car_seg_cap, false);
+    if (!r) r = dev_alloc(c, &b.car_seg_d, (size_t)b.car_seg_cap * ra_carrier_seg_doubles() * p.car_CH, false);
+    if (!r) r = dev_alloc(c, &b.car_seg_i, (size_t)b.car_seg_cap * SI_COUNT * p.car_CH, false);
+    if (r) { b.car_seg_cap = 0; return r; }
+  }
   std::vector<RaCarEv> &flat = c->car_upload[c->parity];
   std::vector<int32_t> &begin = c->car_upload_begin[c->parity];
   flat.clear();
@@ -734,7 +749,7 @@ int process_block_impl(ra_context *c, const float *d_voice, const float *d_carri
       const std::vector<int32_t> &begin = c->car_upload_begin[c->parity];
       if (!flat.empty()) (void)hipMemcpyAsync(b.car_ev, flat.data(), flat.size() * sizeof(RaCarEv), hipMemcpyHostToDevice, st);
       (void)hipMemcpyAsync(b.car_ev_begin, begin.data(), begin.size() * sizeof(int32_t), hipMemcpyHostToDevice, st);
-      ra_launch_carrier_synth(p, b, t0, n, st);
+      ra_launch_carrier_synth(p, b, t0, n, c->car_total_segs, st);
     }
     ra_launch_vocoder(p, b, d_voice, car_f, car_d, t0, n, st);
   };

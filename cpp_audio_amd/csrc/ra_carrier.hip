@@ -51,7 +51,7 @@ __device__ inline double car_angle_increments(const Chan &c, const CarX &x) {
 
 constexpr int CT = 16; // samples per tile
 
-__global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_synth_kernel(RaParams p, RaBuffers b, int64_t t0, int64_t n) {
+__global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_synth_serial_kernel(RaParams p, RaBuffers b, int64_t t0, int64_t n) {
   const int s = blockIdx.x, l = threadIdx.x, Ppad = p.car_Ppad, P = p.car_P;
   double *tile = reinterpret_cast<double *>(ra_smem_car);            // [Ppad][CT + 1]
   double *xch = tile + (size_t)Ppad * (CT + 1);                      // [4] broadcast slots
@@ -254,6 +254,346 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_synth_kernel(RaPar
   if (l == 0 && dropped) b.car_dropped[s] += dropped;
 }
 
+
+// ---- K6, time-parallel form (the default) ------------------------------------------------------------------------------
+// The serial kernel above runs 480 k dependent samples per stream on one wave: ~130 ms per 10 s block of 256 streams, whatever the chip.
+// Of everything a channel carries only ONE recurrence has no closed form that keeps its bits: the shared angle of the phase-controlled
+// oscillators.  The envelope's value is a function of its integer counters (env_jump), the control and the volume are constant after a
+// note's first step, the sine's phasor is a phase (theta += inc).  So:
+//   walk   (one workgroup per stream, lane = channel, samples in order): runs the events' one-shots, cuts the block into segments at
+//          the events and every CAR_G samples, stores every channel's state at the start of each segment, and moves on to the next
+//          segment by env_jump + `angle += inc; if (angle > 2) angle -= 2` (the exact sequence, four instructions per sample) + a phase
+//          addition.  Steps that are not regular (a note's first step, envelope stage changes) are taken one at a time.
+//   render (one wave per 64 / CH segments, lane = (segment, channel)): steps every segment from its stored state with the same code as the
+//          serial kernel, mixes the voices and sums the channels in channel order.
+// The angle, the envelope and the channel sum are the same operation sequences as in the serial kernel: the phase-controlled voices are
+// bit-identical to it (and to the CPU restatement); the sine voice restarts every segment from sincospi(theta) instead of carrying the
+// renormalised phasor product, a 1e-13 difference.
+constexpr int CAR_G = 256; // samples per segment (segments are also cut at events)
+enum { CS_VALUE, CS_TOP, CS_FROM, CS_TO, CS_CUR, CS_C, CS_FRES, CS_INC, CS_ALIAS, CS_VOL, CS_TARGET, CS_FINIT, CS_K, CS_Y, CS_THETA, CS_PH_ANGLE, CS_PH_INC,
+       CS_PH_ALIAS, CS_COUNT };
+
+__device__ inline void car_store_seg(const Chan &c, const CarX &x, double *d, int *i, int CH, int ch) {
+  d[CS_VALUE * CH + ch] = c.value; d[CS_TOP * CH + ch] = c.top; d[CS_FROM * CH + ch] = c.from; d[CS_TO * CH + ch] = c.to; d[CS_CUR * CH + ch] = c.cur;
+  d[CS_C * CH + ch] = c.C; d[CS_FRES * CH + ch] = c.fres; d[CS_INC * CH + ch] = c.inc; d[CS_ALIAS * CH + ch] = c.alias; d[CS_VOL * CH + ch] = c.vol;
+  d[CS_TARGET * CH + ch] = c.target; d[CS_FINIT * CH + ch] = c.finit; d[CS_K * CH + ch] = c.k; d[CS_Y * CH + ch] = c.y; d[CS_THETA * CH + ch] = c.theta;
+  d[CS_PH_ANGLE * CH + ch] = x.ph_angle; d[CS_PH_INC * CH + ch] = x.ph_inc; d[CS_PH_ALIAS * CH + ch] = x.ph_alias;
+  i[SI_ENV_STATE * CH + ch] = c.state; i[SI_ENV_COUNTER * CH + ch] = c.counter; i[SI_ENV_RELDELAY * CH + ch] = c.reldelay;
+  i[SI_ENV_AHDSTATE * CH + ch] = c.ahdstate; i[SI_ENV_AHDCOUNTER * CH + ch] = c.ahdcounter; i[SI_ENV_MINCH * CH + ch] = c.minch;
+  i[SI_ENV_NEXTMINCH * CH + ch] = c.nextminch; i[SI_FLAGS * CH + ch] = c.flags;
+}
+__device__ inline void car_load_seg(Chan &c, CarX &x, const double *d, const int *i, int CH, int ch) {
+  c.value = d[CS_VALUE * CH + ch]; c.top = d[CS_TOP * CH + ch]; c.from = d[CS_FROM * CH + ch]; c.to = d[CS_TO * CH + ch]; c.cur = d[CS_CUR * CH + ch];
+  c.C = d[CS_C * CH + ch]; c.fres = d[CS_FRES * CH + ch]; c.inc = d[CS_INC * CH + ch]; c.alias = d[CS_ALIAS * CH + ch]; c.vol = d[CS_VOL * CH + ch];
+  c.target = d[CS_TARGET * CH + ch]; c.finit = d[CS_FINIT * CH + ch]; c.k = d[CS_K * CH + ch]; c.y = d[CS_Y * CH + ch]; c.theta = d[CS_THETA * CH + ch];
+  x.ph_angle = d[CS_PH_ANGLE * CH + ch]; x.ph_inc = d[CS_PH_INC * CH + ch]; x.ph_alias = d[CS_PH_ALIAS * CH + ch];
+  c.state = i[SI_ENV_STATE * CH + ch]; c.counter = i[SI_ENV_COUNTER * CH + ch]; c.reldelay = i[SI_ENV_RELDELAY * CH + ch];
+  c.ahdstate = i[SI_ENV_AHDSTATE * CH + ch]; c.ahdcounter = i[SI_ENV_AHDCOUNTER * CH + ch]; c.minch = i[SI_ENV_MINCH * CH + ch];
+  c.nextminch = i[SI_ENV_NEXTMINCH * CH + ch]; c.flags = i[SI_FLAGS * CH + ch];
+}
+
+// everything a step does to a channel except the two oscillator recurrences and the mix (the walk counts the steps and applies the
+// recurrences afterwards: the increments a step uses are those it has just set)
+__device__ inline void car_step_state(Chan &c, CarX &x, const RaEnvParams &ep) {
+  if (c.state == ENV_PRESSED && c.ahdstate < 0 && c.reldelay < 0 && c.counter >= 1) ++c.counter;
+  else env_step(c, ep);
+  const double f = ctrl_step(c, 100.0);
+  if (c.inc != f) {
+    x.ph_inc = phase_to_normal_form(f); x.ph_alias = alias_mult(f);
+    c.inc = f; c.alias = alias_mult(f); // osc_set_inc without the rotation (the render derives it from the increment)
+  }
+  if (!(c.flags & FL_HAS_VOL)) {
+    const double inc = fabs(car_angle_increments(c, x)), a = M_PI * inc;
+    c.finit = inc; c.k = a / (1.0 + a);
+    c.y = c.target + c.k * (c.target - c.target);
+    c.vol = c.y;
+    c.flags |= FL_HAS_VOL;
+  } else if (c.vol != c.target) {
+    const double inc = fabs(car_angle_increments(c, x));
+    if (c.finit != inc) { c.finit = inc; const double a = M_PI * inc; c.k = a / (1.0 + a); }
+    c.y = c.y + c.k * (c.target - c.y);
+    c.vol = c.y;
+  }
+}
+
+__global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_walk_kernel(RaParams p, RaBuffers b, int64_t t0, int64_t n) {
+  const int s = blockIdx.x, l = threadIdx.x, Ppad = p.car_Ppad, P = p.car_P, CH = p.car_CH;
+  double *xch = reinterpret_cast<double *>(ra_smem_car); // [4] broadcast slots
+  int *xi = reinterpret_cast<int *>(xch + 4);             // [4]
+  Chan c;
+  CarX x;
+  double *sd = b.car_sd + (size_t)s * SD_COUNT * Ppad;
+  int *si = b.car_si + (size_t)s * SI_COUNT * Ppad;
+  double *ext = b.car_ext + (size_t)s * CX_COUNT * Ppad;
+  load_chan(c, sd, si, Ppad, l);
+  x.ph_angle = ext[CX_PH_ANGLE * Ppad + l]; x.ph_inc = ext[CX_PH_INC * Ppad + l]; x.ph_alias = ext[CX_PH_ALIAS * Ppad + l];
+  int64_t noteid = b.car_noteid[(size_t)s * Ppad + l];
+  int dropped = 0;
+  const RaEnvParams ep = {p.envA, p.envH, p.envD, p.envR, p.SMinusOne};
+  const uint64_t seed = p.seed + (uint64_t)s;
+  const RaCarEv *ev = b.car_ev;
+  int e = b.car_ev_begin[s];
+  const int e_end = b.car_ev_begin[s + 1];
+  // this stream's slots of the segment table: one per CAR_G samples, one more for the block's ragged end, one per event
+  const int64_t per_stream = (n + CAR_G - 1) / CAR_G + 1;
+  int64_t seg = (int64_t)s * per_stream + b.car_ev_begin[s];
+  const int64_t seg_stop = (int64_t)(s + 1) * per_stream + e_end;
+  RaPhaseClock clk(b.dbg_clk, l == 0);
+  int64_t t = t0;
+  const int64_t t_end = t0 + n;
+  constexpr int64_t kNever = 0x7fffffffffffffffll;
+  int64_t next_ev = (e < e_end) ? ev[e].sample : kNever;
+  while (t < t_end) {
+    if (next_ev <= t) { // the one-shots queued for this frame run before its step (simple_audio_context.h:74-76)
+      const RaCarEv q = ev[e];
+      ++e;
+      next_ev = (e < e_end) ? ev[e].sample : kNever;
+      if (l == 0) { xi[0] = 0x7fffffff; xi[1] = 0x7fffffff; }
+      __syncthreads();
+      if (q.type == 0) { // ---- onEvent(NoteOn), gen.crtp.h:389-449, and its one-shot :455-527 (as in the serial kernel) ----
+        if (l < P && c.state == ENV_DONE2) atomicMin(&xi[0], l);
+        __syncthreads();
+        const int sel = xi[0];
+        if (sel == 0x7fffffff) { if (l == 0) ++dropped; }
+        else {
+          if (l == sel) {
+            c.state = ENV_SOON;
+            noteid = q.noteid;
+            chan_forget_past_signals(c);
+            c.target = 1.0 * (double)q.vel; c.flags |= FL_HAS_TARGET;
+            c.cur = 0;
+            const float inc_f = 2 * (q.freq * 1.f) / p.sample_rate;
+            chan_set_angle_increments(c, (double)inc_f, 0);
+            xch[0] = car_angle_increments(c, x);
+          }
+          __syncthreads();
+          if (l != sel && l < P && rt_active(c) && car_angle_increments(c, x) == xch[0]) atomicMin(&xi[1], l);
+          __syncthreads();
+          const int src = xi[1];
+          if (src != 0x7fffffff && l == src) { xch[1] = x.ph_angle; xch[2] = c.theta; }
+          __syncthreads();
+          if (l == sel) {
+            if (src != 0x7fffffff) {
+              x.ph_angle = phase_to_normal_form(xch[1]);
+              c.theta = xch[2];                          // SineOscillatorAlgo::synchronizeAngles :2397-2399, in the phase domain
+            } else {
+              const float a = (p.phase_policy == RA_PHASE_HASH) ? hash_uniform_pm1(seed, (uint64_t)q.noteid, 2) : 0.f;
+              x.ph_angle = phase_to_normal_form((double)a);
+              c.theta = (double)a;                       // setStartAngle :2401-2403
+            }
+            env_on_key_pressed(c, q.delay);
+          }
+        }
+      } else { // ---- NoteOff one-shot, gen.crtp.h:541-588 ----
+        if (l < P && noteid == q.noteid) atomicMin(&xi[0], l);
+        __syncthreads();
+        if (l == xi[0] && env_can_release_now(c, q.delay)) env_on_key_released(c, q.delay);
+      }
+      __syncthreads();
+      continue;
+    }
+    const int64_t grid_end = t0 + ((t - t0) / CAR_G + 1) * CAR_G;
+    const int64_t seg_end = min(min(t_end, next_ev), grid_end);
+    const int len = (int)(seg_end - t);
+    const bool act = l < P && rt_active(c);
+    const int any = __syncthreads_or(act);
+    if (seg < seg_stop) { // (always: the table has a slot for every cut)
+      if (l == 0) b.car_seg_info[seg] = make_int4(s, (int)(t - t0), len, any);
+      if (any && l < CH) car_store_seg(c, x, b.car_seg_d + (size_t)seg * CS_COUNT * CH, b.car_seg_i + (size_t)seg * SI_COUNT * CH, CH, l);
+    }
+    ++seg;
+    if (any) {
+      // the channel's steps of this segment: `na` of them, all with the increments the first one leaves behind
+      int na = 0;
+      {
+        int left = len;
+        while (left > 0 && rt_active(c) && l < P) {
+          int j = env_regular_steps(c, ep);
+          const bool regular = j > 0 && (c.flags & FL_HAS_VOL) && (c.flags & FL_HAS_FRES) && c.fres == c.to && c.inc == c.to && c.vol == c.target;
+          if (!regular) {
+            const double inc_before = x.ph_inc;
+            car_step_state(c, x, ep);
+            if (na > 0 && x.ph_inc != inc_before) atomicOr(b.error_flags, RA_ERR_BOOKKEEPING); // increments only move on a note's first step
+            ++na; --left;
+            continue;
+          }
+          j = min(j, left);
+          env_jump(c, ep, j);
+          na += j; left -= j;
+        }
+      }
+      // Phased::step (audioelement.h:1452-1470), `na` times: the one recurrence that has to be run
+      {
+        double ang = x.ph_angle;
+        const double inc = x.ph_inc;
+        auto one = [&](int i) {
+          const double t1 = ang + (i < na ? inc : 0.0); // (an angle that is not stepped stays <= 2)
+          const double t2 = t1 - 2.0;
+          ang = t1 > 2.0 ? t2 : t1;
+        };
+        int i = 0;
+        for (; i + 8 <= len; i += 8) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) one(i + u);
+        }
+        for (; i < len; ++i) one(i);
+        x.ph_angle = ang;
+      }
+      // SineOscillatorAlgo::step, `na` times, as a phase
+      if (na > 0) {
+        double th = fma((double)na, c.inc, c.theta);
+        th -= 2.0 * floor(0.5 * th);
+        c.theta = th;
+      }
+    }
+    t = seg_end;
+  }
+  // unused slots of this stream's part of the table
+  for (int64_t q = seg + l; q < seg_stop; q += blockDim.x) b.car_seg_info[q] = make_int4(s, 0, 0, 0);
+  store_chan(c, sd, si, Ppad, l);
+  ext[CX_PH_ANGLE * Ppad + l] = x.ph_angle; ext[CX_PH_INC * Ppad + l] = x.ph_inc; ext[CX_PH_ALIAS * Ppad + l] = x.ph_alias;
+  b.car_noteid[(size_t)s * Ppad + l] = noteid;
+  if (l == 0 && dropped) b.car_dropped[s] += dropped;
+}
+
+__global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_render_kernel(RaParams p, RaBuffers b, int64_t n, int64_t total_segs) {
+  const int l = threadIdx.x, nth = blockDim.x, P = p.car_P, CH = p.car_CH;
+  const int SUB = nth / CH;                       // segments per workgroup (CH >= 64: one)
+  const int g = l / CH, ch = l - g * CH;
+  double *tile = reinterpret_cast<double *>(ra_smem_car);          // [nth][CT + 1]
+  int4 *infos = reinterpret_cast<int4 *>(tile + (size_t)nth * (CT + 1)); // [SUB]
+  int *smax = reinterpret_cast<int *>(infos + SUB);
+  const int64_t seg = (int64_t)blockIdx.x * SUB + g;
+  int4 info = make_int4(0, 0, 0, 0);
+  if (seg < total_segs) info = b.car_seg_info[seg];
+  if (l == 0) *smax = 0;
+  __syncthreads();
+  double *out_d = b.car_gen_d + (size_t)info.x * n + info.y;
+  float *out_f = b.car_gen_f + (size_t)info.x * n + info.y;
+  if (info.z > 0 && !info.w) { // nothing sounds in this segment
+    for (int r = ch; r < info.z; r += CH) { out_d[r] = 0.0; out_f[r] = 0.f; }
+    info.z = 0;
+  }
+  if (ch == 0) { infos[g] = info; if (info.z > 0) atomicMax(smax, info.z); }
+  __syncthreads();
+  const int maxlen = *smax;
+  if (maxlen == 0) return;
+  Chan c;
+  CarX x;
+  chan_init(c);
+  x.ph_angle = 0; x.ph_inc = 0; x.ph_alias = 1;
+  const int len = info.z;
+  if (len > 0 && ch < P) {
+    car_load_seg(c, x, b.car_seg_d + (size_t)seg * CS_COUNT * CH, b.car_seg_i + (size_t)seg * SI_COUNT * CH, CH, ch);
+    double sn, cs;
+    sincospi(c.theta, &sn, &cs);
+    c.cre = cs; c.cim = sn;
+    sincos(M_PI * c.inc, &sn, &cs); // osc_set_inc's rotation
+    c.mre = cs; c.mim = sn;
+  }
+  const RaEnvParams ep = {p.envA, p.envH, p.envD, p.envR, p.SMinusOne};
+  const double v_saw = (double)p.car_vol[1], v_tri = (double)p.car_vol[2], v_sq = (double)p.car_vol[3],
+               v_sine = (double)p.car_vol[4], v_pulse = (double)p.car_vol[5];
+  double pw = (double)p.car_pulse_width;
+  pw = fmax(0., pw); pw = fmin(2., pw);
+  const double p_high = 0.5 * (2. - pw), p_low = p_high - 1.;
+  double *mine = tile + (size_t)l * (CT + 1);
+  for (int tp = 0; tp < maxlen; tp += CT) {
+    const int m = max(0, min(CT, len - tp));
+    const bool act = m > 0 && ch < P && rt_active(c);
+    const bool holds = c.state == ENV_PRESSED && c.ahdstate < 0 && c.counter >= 1 && (c.reldelay < 0 || c.reldelay >= m) && (c.flags & FL_HAS_FRES) &&
+                       c.fres == c.to && c.inc == c.to && (c.flags & FL_HAS_VOL) && c.vol == c.target;
+    if (__all(!act || holds)) { // every sounding channel of the wave just holds its note: oscillators and mix only
+      double ang = x.ph_angle, cre = c.cre, cim = c.cim;
+      const double inc = x.ph_inc, al = x.ph_alias, mre = c.mre, mim = c.mim, sal = c.alias, vol = c.vol, val = c.value;
+      auto one = [&](int i) {
+        ang += inc;                                                // Phased::step :1452-1470
+        if (ang > 2.0) ang -= 2.0;
+        const double re = cre * mre - cim * mim, im = cre * mim + cim * mre; // SineOscillatorAlgo::step
+        const double gn = 0.5 * (3.0 - (re * re + im * im));
+        cre = re * gn; cim = im * gn;
+        double sum = 0.f;                                          // UnityGainMix::imag
+        if (v_saw != 0.) sum += v_saw * (al * wave_saw(ang));
+        if (v_tri != 0.) sum += v_tri * (al * wave_triangle(ang));
+        if (v_sq != 0.) sum += v_sq * (al * wave_square(ang));
+        if (v_sine != 0.) sum += v_sine * (sal * cim);
+        if (v_pulse != 0.) sum += v_pulse * (al * wave_pulse(ang, pw, p_high, p_low));
+        mine[i] = vol * (sum * val);
+      };
+      if (act) {
+        if (m == CT) {
+#pragma unroll
+          for (int i = 0; i < CT; ++i) one(i);
+        } else {
+          for (int i = 0; i < m; ++i) one(i);
+        }
+        x.ph_angle = ang; c.cre = cre; c.cim = cim;
+        c.counter += m;
+        if (c.reldelay >= 0) c.reldelay -= m;
+      } else {
+        for (int i = 0; i < m; ++i) mine[i] = 0.0;
+      }
+    } else {
+      for (int i = 0; i < m; ++i) {
+        double v = 0.0;
+        if (ch < P && rt_active(c)) { // ImplCRTP::compute, gen.crtp.h:352-371 (the serial kernel's general step)
+          if (c.state == ENV_PRESSED && c.ahdstate < 0 && c.reldelay < 0 && c.counter >= 1) ++c.counter;
+          else env_step(c, ep);
+          const double f = ctrl_step(c, 100.0);
+          if (c.inc != f) {
+            x.ph_inc = phase_to_normal_form(f); x.ph_alias = alias_mult(f);
+            osc_set_inc(c, f);
+          }
+          x.ph_angle += x.ph_inc;
+          if (x.ph_angle > 2.0) x.ph_angle -= 2.0;
+          {
+            const double re = c.cre * c.mre - c.cim * c.mim, im = c.cre * c.mim + c.cim * c.mre;
+            const double gn = 0.5 * (3.0 - (re * re + im * im));
+            c.cre = re * gn; c.cim = im * gn;
+          }
+          if (!(c.flags & FL_HAS_VOL)) {
+            const double inc = fabs(car_angle_increments(c, x)), a = M_PI * inc;
+            c.finit = inc; c.k = a / (1.0 + a);
+            c.y = c.target + c.k * (c.target - c.target);
+            c.vol = c.y;
+            c.flags |= FL_HAS_VOL;
+          } else if (c.vol != c.target) {
+            const double inc = fabs(car_angle_increments(c, x));
+            if (c.finit != inc) { c.finit = inc; const double a = M_PI * inc; c.k = a / (1.0 + a); }
+            c.y = c.y + c.k * (c.target - c.y);
+            c.vol = c.y;
+          }
+          if (rt_active(c)) {
+            double sum = 0.f;
+            if (v_saw != 0.) sum += v_saw * (x.ph_alias * wave_saw(x.ph_angle));
+            if (v_tri != 0.) sum += v_tri * (x.ph_alias * wave_triangle(x.ph_angle));
+            if (v_sq != 0.) sum += v_sq * (x.ph_alias * wave_square(x.ph_angle));
+            if (v_sine != 0.) sum += v_sine * (c.alias * c.cim);
+            if (v_pulse != 0.) sum += v_pulse * (x.ph_alias * wave_pulse(x.ph_angle, pw, p_high, p_low));
+            v = c.vol * (sum * c.value);
+          }
+        }
+        mine[i] = v;
+      }
+    }
+    __syncthreads();
+    // `buffer[i] += c.elem.imag()` over the channels in index order (silent channels add 0), for every segment of the workgroup
+    for (int o = l; o < SUB * CT; o += nth) {
+      const int og = o / CT, i = o - og * CT;
+      const int4 gi = infos[og];
+      if (i < gi.z - tp) {
+        double acc = 0.0;
+        const double *col = tile + (size_t)og * CH * (CT + 1) + i;
+        for (int k = 0; k < P; ++k) acc += col[(size_t)k * (CT + 1)];
+        const size_t at = (size_t)gi.x * n + gi.y + tp + i;
+        b.car_gen_d[at] = acc;
+        b.car_gen_f[at] = (float)acc;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---- K7 -------------------------------------------------------------------------------------------------------------------
 constexpr int BT = 64; // samples per tile = lanes
 __device__ inline double readlane_f64(double v, int lane) { // lane is wave-uniform
@@ -321,10 +661,19 @@ __global__ void __launch_bounds__(64) ra_voc_bank_kernel(RaParams p, RaBuffers b
 
 } // namespace
 
-void ra_launch_carrier_synth(const RaParams &p, const RaBuffers &b, int64_t t0, int64_t n, hipStream_t st) {
+int ra_carrier_seg_doubles() { return CS_COUNT; }
+
+void ra_launch_carrier_synth(const RaParams &p, const RaBuffers &b, int64_t t0, int64_t n, int64_t total_segs, hipStream_t st) {
   if (n <= 0 || p.car_P <= 0) return;
-  const size_t lds = (size_t)p.car_Ppad * (CT + 1) * sizeof(double) + 4 * sizeof(double) + 4 * sizeof(int);
-  hipLaunchKernelGGL(ra_carrier_synth_kernel, dim3((unsigned)p.n_streams), dim3((unsigned)p.car_Ppad), lds, st, p, b, t0, n);
+  if (p.car_serial) { // reference_order 1: one sample-serial launch
+    const size_t lds = (size_t)p.car_Ppad * (CT + 1) * sizeof(double) + 4 * sizeof(double) + 4 * sizeof(int);
+    hipLaunchKernelGGL(ra_carrier_synth_serial_kernel, dim3((unsigned)p.n_streams), dim3((unsigned)p.car_Ppad), lds, st, p, b, t0, n);
+    return;
+  }
+  hipLaunchKernelGGL(ra_carrier_walk_kernel, dim3((unsigned)p.n_streams), dim3((unsigned)p.car_Ppad), 4 * sizeof(double) + 4 * sizeof(int), st, p, b, t0, n);
+  const int nth = std::max(64, p.car_CH), sub = nth / p.car_CH;
+  const size_t lds = (size_t)nth * (CT + 1) * sizeof(double) + (size_t)sub * sizeof(int4) + 16;
+  hipLaunchKernelGGL(ra_carrier_render_kernel, dim3((unsigned)((total_segs + sub - 1) / sub)), dim3((unsigned)nth), lds, st, p, b, n, total_segs);
 }
 
 void ra_launch_voc_bank(const RaParams &p, const RaBuffers &b, const float *d_voice, const float *d_carrier, const double *carrier_d, int64_t t0, int64_t n,

@@ -38,6 +38,8 @@ struct RaParams {
   // the band-pass bank variant of the vocoder and the vocoder carrier synth
   int voc_kind;            // RA_VOCODER_FFT / RA_VOCODER_BANDPASS
   int car_P, car_Ppad;     // channels of the carrier synth (0 = none), padded to a multiple of 64
+  int car_CH;              // channel slots per segment of the time-parallel synth: the power of two >= car_P (>= 4)
+  int car_serial;          // 1 (reference_order 1): the sample-serial carrier synth kernel
   float car_vol[6];        // noise, saw, triangle, square, sine, pulse volume targets (lib.cpp:978-983)
   float car_pulse_width;   // lib.cpp:984
   int post_limit;          // post: "limit" (lib.cpp:1247-1258): the double mix goes through the limiter kernel before the float cast
@@ -143,6 +145,11 @@ struct RaBuffers {
   double *car_gen_d;        // [n_streams][n] the generated carrier as the double the vocoder compute receives ...
   float *car_gen_f;         // ... and as the float PeriodicFFT::feed stores (periodicfft.cpp:55-61)
   int64_t car_gen_cap;
+  // the time-parallel carrier synth (ra_carrier.hip): the block cut into segments at the events and every 256 samples
+  int4 *car_seg_info;       // [segments] stream, first sample (block-relative), length (0: unused slot), does anything sound
+  double *car_seg_d;        // [segments][CS_COUNT][car_CH] channel state at the start of the segment
+  int32_t *car_seg_i;       // [segments][SI_COUNT][car_CH]
+  int64_t car_seg_cap;
   // ---- band-pass bank (vocoder_kind = RA_VOCODER_BANDPASS) ----
   double *bank_k;           // [3][64] one-pole coefficients per band: high-pass (band's lower edge), low-pass (upper edge), envelope follower
   double *bank_state;       // [n_streams][5][64] filter states: modulator hp / lp, envelope follower, carrier hp / lp
@@ -243,7 +250,8 @@ struct RaCarEv {
 };
 enum { CX_PH_ANGLE, CX_PH_INC, CX_PH_ALIAS, CX_COUNT };
 void ra_launch_limiter(const RaParams &p, const RaBuffers &b, int64_t r0, int64_t r1, int64_t n, float *d_out, hipStream_t st);
-void ra_launch_carrier_synth(const RaParams &p, const RaBuffers &b, int64_t t0, int64_t n, hipStream_t st);
+void ra_launch_carrier_synth(const RaParams &p, const RaBuffers &b, int64_t t0, int64_t n, int64_t total_segs, hipStream_t st);
+int ra_carrier_seg_doubles(); // doubles of channel state per (segment, channel slot) in car_seg_d
 void ra_launch_voc_bank(const RaParams &p, const RaBuffers &b, const float *d_voice, const float *d_carrier, const double *carrier_d, int64_t t0, int64_t n,
                         hipStream_t st);
 

@@ -774,8 +774,10 @@ void ra_launch_synth_render(const RaParams &p, const RaBuffers &b, const RaSpan 
   // hops per workgroup (single-wave streams).  The chip starts ~16 M workgroups per second: with packed pairs half of the one-wave workgroups
   // leave at once and the 17 k workgroups of a chunk took longer to start than to run.  Two hops per workgroup, measured on configs[1] with
   // packing: render alone 9.2 -> 8.3 ms, step 14.9 -> 13.7 ms; four: 16.3 ms (a four-wave workgroup wants a slot on every SIMD at once).
-  static const int group_env = std::getenv("RA_RENDER_GROUP") ? std::atoi(std::getenv("RA_RENDER_GROUP")) : 2;
-  const unsigned group = (p.Ppad == 64) ? (unsigned)std::min(std::max(group_env, 1), RA_MAX_CHANNELS / 64) : 1u; // hops per workgroup
+  // The stereo kernel's tile is twice the size: two of them per workgroup leave room for 8 waves per CU only (19.0 -> 20.2 ms): one hop there.
+  static const int group_env = std::getenv("RA_RENDER_GROUP") ? std::atoi(std::getenv("RA_RENDER_GROUP")) : 0;
+  const int group_want = group_env > 0 ? group_env : (p.stereo_spread == 0.f ? 2 : 1);
+  const unsigned group = (p.Ppad == 64) ? (unsigned)std::min(std::max(group_want, 1), RA_MAX_CHANNELS / 64) : 1u; // hops per workgroup
   const dim3 grid((unsigned)((sp.nfb + 1 + group - 1) / group), (unsigned)p.n_streams), block((unsigned)p.Ppad, group);
   const size_t lds = (size_t)group * p.Ppad * (p.stereo_spread == 0.f ? TROW_MONO : TROW) * sizeof(double); // the 8-frame tiles only
   if (p.stereo_spread == 0.f) hipLaunchKernelGGL(ra_synth_render_mono_kernel, grid, block, lds, st, p, b, sp, d_out, d_out_d);

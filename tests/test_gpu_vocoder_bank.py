@@ -136,6 +136,38 @@ def test_carrier_synth_matches_oracle(api, oracle, case):
         assert dropped > 0, "the case is meant to exhaust the channels"
 
 
+@pytest.mark.parametrize("sine", [0.0, 0.5])
+def test_carrier_synth_time_parallel_equals_sample_serial(api, sine):
+    # the default carrier synth walks the events, stores the channels' states every 256 samples and at every event, and renders the
+    # segments in parallel; reference_order 1 runs the one sample-serial kernel.  The phase-controlled voices are the same operation
+    # sequences in both (equal bit for bit); the sine restarts each segment from sincospi(theta).
+    n, S = 50000, 4
+    kw = dict(BASE, carrier_n_channels=6, carrier_volume=1.0, voice_volume=0.0, vocoder_volume=0.0, **dict(VOICES, vocoder_carrier_sine_volume=sine),
+              env_attack_seconds=0.01, env_hold_seconds=0.002, env_decay_seconds=0.03, env_release_seconds=0.05, env_sustain_level=0.5)
+    rng = np.random.default_rng(8)
+    rows = []
+    for s in range(S):
+        rows += chord_events(n, s, rng, n_notes=25, max_delay=40)   # more notes than channels: some are dropped
+    rows.sort(key=lambda r: (r[1], r[0]))
+    got = []
+    for ro in (0, 1):
+        with api.Context(api.default_config(reference_order=ro, **kw), S, 0) as ctx:
+            ctx.carrier_events(rows)
+            parts = []
+            for m in (20000, 30000):                                 # two blocks: the carried state is the same state
+                ctx.process_host(None, None, n_frames=m)
+                parts.append(np.stack([ctx.carrier(m, s) for s in range(S)]))
+            st = ctx.stats()
+            assert st.error_flags == 0
+            got.append((np.concatenate(parts, axis=1), st.carrier_dropped_note_on))
+    assert np.sqrt(np.mean(got[1][0] ** 2)) > 1e-2
+    assert got[0][1] == got[1][1]
+    if sine == 0.0:
+        assert np.array_equal(got[0][0], got[1][0]), f"max diff {np.max(np.abs(got[0][0] - got[1][0])):.3g}"
+    else:
+        assert np.max(np.abs(got[0][0] - got[1][0])) < 1e-11
+
+
 @pytest.mark.parametrize("kind", [0, 1])
 def test_carrier_synth_feeds_the_vocoder(api, oracle, sig, kind):
     # BASELINE configs[2] wording: 32 bands, carrier from the synth ("gen.sine") — FFT vocoder (kind 0) and band-pass bank (kind 1)
