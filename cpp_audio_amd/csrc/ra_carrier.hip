@@ -21,6 +21,7 @@
 //    Same operations in the same order as the CPU restatement (no contraction): the vocoded signal is equal bit for bit.
 #include "ra_chan.cuh"
 #include <algorithm>
+#include <cstdlib>
 
 extern __shared__ __align__(16) unsigned char ra_smem_car[];
 
@@ -659,6 +660,137 @@ __global__ void __launch_bounds__(64) ra_voc_bank_kernel(RaParams p, RaBuffers b
   st[l] = yA; st[64 + l] = yB; st[128 + l] = yE; st[192 + l] = yC; st[256 + l] = yD;
 }
 
+
+// K7 as a pipeline of wavefronts.  The kernel above runs the five recurrences of a stream on one wave: ~23 dependent-ish fp64 instructions
+// per sample at the rate a lone wave issues them (one per ~10 cycles): 38 ms per 10 s block, whatever the chip.  The recurrences form a
+// chain of stages (modulator low-pass of the high-pass -> band low-pass -> follower; carrier the same without the follower), each a
+// one-pole whose input is the previous stage's output of the SAME sample: six waves of one workgroup take one stage each and hand
+// 16-sample tiles to each other through LDS, one barrier per tile, the consumer one tile behind its producer (double-buffered edges).
+// Every stage evaluates the same expressions in the same order as the single-wave kernel: the results are bit-identical.
+constexpr int PT = 16;                  // samples per pipeline tile
+constexpr int PROW = 65;                // doubles per sample row ([sample][band], odd: the summing lanes walk rows)
+constexpr int PEDGE = PT * PROW;        // one buffer of an edge
+__global__ void __launch_bounds__(384) ra_voc_bank_pipe_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, const float *__restrict__ carrier_f,
+                                                             const double *__restrict__ carrier_d, int64_t n, int perm) {
+  const int s = blockIdx.x, l = threadIdx.x & 63, B = p.voc_bands;
+  // the stage this wave runs.  A workgroup's waves go to the CU's four SIMDs round robin: waves 0 / 4 and 1 / 5 share one.  The two input
+  // stages issue the most instructions per sample and get a SIMD of their own (RA_BANK_PERM: tuning aid, six digits = stage of wave 0..5)
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int w = (perm >> (4 * wid)) & 15;
+  double *lds = reinterpret_cast<double *>(ra_smem_car);
+  // edges: 0 hp of the modulator (stage 0 -> 1), 1 |band-passed modulator| (1 -> 2), 2 envelope (2 -> 4), 3 hp of the carrier (3 -> 4), 4 products (4 -> 5)
+  auto edge = [&](int e, int64_t tile) -> double * { return lds + ((size_t)e * 2 + (size_t)(tile & 1)) * PEDGE; };
+  const bool band = l < B;
+  const double kA = b.bank_k[l], kB = b.bank_k[64 + l], kE = b.bank_k[128 + l];
+  double *st = b.bank_state + (size_t)s * 5 * 64;
+  const int delay = (w == 0) ? 0 : (w == 1) ? 1 : (w == 2 || w == 3) ? 2 : (w == 4) ? 3 : 4;
+  double y = 0.0; // this stage's filter state
+  if (w < 5) y = st[w * 64 + l];
+  const float *vs = voice ? voice + (size_t)s * n : nullptr;
+  const float *cf = carrier_f ? carrier_f + (size_t)s * n : nullptr;
+  const double *cd = carrier_d ? carrier_d + (size_t)s * n : nullptr;
+  double *mix = b.voc_mix + (size_t)s * n;
+  const int64_t ntiles = (n + PT - 1) / PT;
+  auto fetch_m = [&](int64_t tile) -> double { const int64_t at = tile * PT + l; return (vs && tile >= 0 && tile < ntiles && l < PT && at < n) ? (double)vs[at] : 0.0; };
+  auto fetch_c = [&](int64_t tile) -> double {
+    const int64_t at = tile * PT + l;
+    if (!(tile >= 0 && tile < ntiles && l < PT && at < n)) return 0.0;
+    return cd ? cd[at] : cf ? (double)cf[at] : 0.0;
+  };
+  // the input tile of the stages that read global memory, requested one step ahead
+  double in_next = (w == 0 || w == 5) ? fetch_m(0) : (w == 3) ? fetch_c(0) : 0.0;
+  double in2_next = (w == 5) ? fetch_c(0) : 0.0; // the summing stage mixes the dry inputs in: both requested a step ahead, like the stages' inputs
+  unsigned long long clk_work = 0, clk_wait = 0, clk_t = b.dbg_clk ? __builtin_readcyclecounter() : 0; // tuning aid (RA_PHASE_CLOCKS): per stage, work / barrier
+  for (int64_t step = 0; step < ntiles + 4; ++step) {
+    const int64_t tile = step - delay;
+    if (tile >= 0 && tile < ntiles) {
+      const int cnt = (int)min((int64_t)PT, n - tile * PT);
+      const bool full = cnt == PT; // (all but the block's last tile: straight-line code, the compiler interleaves the samples)
+      if (w == 0 || w == 3) { // low-pass at the band's lower edge; out: input - low-pass (the high-pass)
+        const double in = in_next;
+        in_next = (w == 0) ? fetch_m(tile + 1) : fetch_c(tile + 1);
+        double *out = edge(w == 0 ? 0 : 3, tile) + l;
+        if (full) {
+#pragma unroll
+          for (int i = 0; i < PT; ++i) {
+            const double x = readlane_f64(in, i);
+            y = y + kA * (x - y);
+            out[i * PROW] = x - y;
+          }
+        } else {
+          for (int i = 0; i < cnt; ++i) {
+            const double x = readlane_f64(in, i);
+            y = y + kA * (x - y);
+            out[i * PROW] = x - y;
+          }
+        }
+      } else if (w == 1 || w == 2) { // 1: band low-pass of the modulator, out: its magnitude; 2: envelope follower
+        const double *in = edge(w - 1, tile) + l;
+        double *out = edge(w, tile) + l;
+        const double k = (w == 1) ? kB : kE;
+        if (full) {
+          double v[PT];
+#pragma unroll
+          for (int i = 0; i < PT; ++i) v[i] = in[i * PROW];
+#pragma unroll
+          for (int i = 0; i < PT; ++i) {
+            y = y + k * (v[i] - y);
+            out[i * PROW] = (w == 1) ? fabs(y) : y;
+          }
+        } else {
+          for (int i = 0; i < cnt; ++i) {
+            y = y + k * (in[i * PROW] - y);
+            out[i * PROW] = (w == 1) ? fabs(y) : y;
+          }
+        }
+      } else if (w == 4) { // band low-pass of the carrier, times the envelope: ponderation[i] * filtered
+        const double *in = edge(3, tile) + l, *env = edge(2, tile) + l;
+        double *out = edge(4, tile) + l;
+        if (full) {
+          double v[PT], g[PT];
+#pragma unroll
+          for (int i = 0; i < PT; ++i) { v[i] = in[i * PROW]; g[i] = env[i * PROW]; }
+#pragma unroll
+          for (int i = 0; i < PT; ++i) {
+            y = y + kB * (v[i] - y);
+            out[i * PROW] = band ? g[i] * y : 0.0;
+          }
+        } else {
+          for (int i = 0; i < cnt; ++i) {
+            y = y + kB * (in[i * PROW] - y);
+            out[i * PROW] = band ? env[i * PROW] * y : 0.0;
+          }
+        }
+      } else { // w == 5: `res += ponderation[i] * filtered` in band order, and the mix (vocoder.cpp:799-803)
+        const double mv = in_next, cv = in2_next;
+        in_next = fetch_m(tile + 1); in2_next = fetch_c(tile + 1);
+        if (l < cnt) {
+          const int64_t at = tile * PT + l;
+          const double *row = edge(4, tile) + l * PROW;
+          double acc = 0.0;
+          if ((B & 15) == 0) {
+            for (int q0 = 0; q0 < B; q0 += 16) { // sixteen reads in flight, then their adds in band order
+              double r[16];
+#pragma unroll
+              for (int j = 0; j < 16; ++j) r[j] = row[q0 + j];
+#pragma unroll
+              for (int j = 0; j < 16; ++j) acc += r[j];
+            }
+          } else {
+            for (int q = 0; q < B; ++q) acc += row[q];
+          }
+          mix[at] = (double)p.vol_mod * mv + (double)p.vol_car * cv + (double)p.vol_voc * acc;
+        }
+      }
+    }
+    if (b.dbg_clk) { const unsigned long long now = __builtin_readcyclecounter(); clk_work += now - clk_t; clk_t = now; }
+    __syncthreads();
+    if (b.dbg_clk) { const unsigned long long now = __builtin_readcyclecounter(); clk_wait += now - clk_t; clk_t = now; }
+  }
+  if (b.dbg_clk && l == 0) { atomicAdd(b.dbg_clk + 96 + 2 * w, clk_work); atomicAdd(b.dbg_clk + 97 + 2 * w, clk_wait); }
+  if (w < 5) st[w * 64 + l] = y;
+}
+
 } // namespace
 
 int ra_carrier_seg_doubles() { return CS_COUNT; }
@@ -680,5 +812,20 @@ void ra_launch_voc_bank(const RaParams &p, const RaBuffers &b, const float *d_vo
                         hipStream_t st) {
   if (n <= 0) return;
   (void)t0;
-  hipLaunchKernelGGL(ra_voc_bank_kernel, dim3((unsigned)p.n_streams), dim3(64), (size_t)BT * 65 * sizeof(double), st, p, b, d_voice, d_carrier, carrier_d, n);
+  static const bool single_wave = std::getenv("RA_BANK_SINGLE_WAVE") != nullptr; // tuning aid: the one-wave kernel (same bits, ~3x the time)
+  if (single_wave) {
+    hipLaunchKernelGGL(ra_voc_bank_kernel, dim3((unsigned)p.n_streams), dim3(64), (size_t)BT * 65 * sizeof(double), st, p, b, d_voice, d_carrier, carrier_d, n);
+    return;
+  }
+  static const int perm = [] {
+    int v = 0x132540; // waves 0..5 run stages 0, 4, 5, 2, 3, 1 (measured on configs[2]: 47.2 ms per step; in stage order 51.7; in-kernel clocks:
+                      // every stage then works ~1500 cycles per 16-sample tile, the floor of three dependent fp64 operations per sample is ~1100)
+    if (const char *e = std::getenv("RA_BANK_PERM")) { v = 0; for (int i = 0; i < 6 && e[i]; ++i) v |= (e[i] - '0') << (4 * i); }
+    return v;
+  }();
+  static unsigned long long attr_done = 0; // 81 KB of dynamic LDS: above the 64 KB default
+  ra_once_per_device(attr_done, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_bank_pipe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RA_LDS_LIMIT_BYTES);
+  });
+  hipLaunchKernelGGL(ra_voc_bank_pipe_kernel, dim3((unsigned)p.n_streams), dim3(384), (size_t)5 * 2 * PEDGE * sizeof(double), st, p, b, d_voice, d_carrier, carrier_d, n, perm);
 }
