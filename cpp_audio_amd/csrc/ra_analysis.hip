@@ -625,7 +625,7 @@ void ra_launch_roll_feedback(const RaParams &p, const RaBuffers &b, int64_t n, h
 // one wave per SIMD issues fp64 at half the rate two reach, scripts/ubench/fp64_rate.hip).  RA_ANALYSIS_T overrides (tuning aid).
 int ra_analysis_threads(const RaParams &p) {
   static const int forced = [] { const char *e = getenv("RA_ANALYSIS_T"); return e ? atoi(e) : 0; }();
-  if (forced == 256 || forced == 512 || forced == 1024) return forced;
+  if (forced == 128 || forced == 256 || forced == 512 || forced == 1024) return forced;
   return p.M >= 4096 ? 512 : 256;
 }
 
@@ -644,12 +644,14 @@ void ra_launch_analysis(const RaParams &p, const RaBuffers &b, const float *d_vo
   size_t lds = ra_analysis_lds_bytes(p);
   static unsigned long long attr_done = 0;
   ra_once_per_device(attr_done, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_analysis_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_analysis_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_analysis_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_analysis_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   switch (ra_analysis_threads(p)) {
   case 1024: hipLaunchKernelGGL(ra_analysis_kernel<1024>, grid, dim3(1024), lds, st, p, b, d_voice, t0, n, f_lo, (int)fb0, (int)nfb_total, (int)nfb_chunk); break;
+  case 128: hipLaunchKernelGGL(ra_analysis_kernel<128>, grid, dim3(128), lds, st, p, b, d_voice, t0, n, f_lo, (int)fb0, (int)nfb_total, (int)nfb_chunk); break;
   case 512: hipLaunchKernelGGL(ra_analysis_kernel<512>, grid, dim3(512), lds, st, p, b, d_voice, t0, n, f_lo, (int)fb0, (int)nfb_total, (int)nfb_chunk); break;
   default: hipLaunchKernelGGL(ra_analysis_kernel<256>, grid, dim3(256), lds, st, p, b, d_voice, t0, n, f_lo, (int)fb0, (int)nfb_total, (int)nfb_chunk); break;
   }
