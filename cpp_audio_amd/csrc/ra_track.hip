@@ -91,15 +91,36 @@ __global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, i
   RaPhaseClock clk(b.dbg_clk, lane == 0);
   unsigned long long sumA = 0, sumPlayed = 0;
 
+  // The head of the next frame's list (one item per lane) and its length are requested a frame ahead: a frame's work is a chain of ~20 k
+  // cycles that would otherwise start with a global round trip.
+  auto fetch_head = [&](int64_t fbn, double &pt, double &v, float &k, int &cnt) {
+    pt = 0.0; v = 0.0; k = 0.f; cnt = 0;
+    if (fbn < fb0 + n_frames_blk) {
+      const size_t lb = ((size_t)s * b.frames_cap + fbn) * maxr;
+      cnt = b.pl_count[(size_t)s * b.frames_cap + fbn];
+      if (lane < maxr) { pt = b.pl_pitch[lb + lane]; v = b.pl_vol[lb + lane]; k = b.pl_key[lb + lane]; }
+    }
+  };
+  double nx_pitch, nx_vol;
+  float nx_key;
+  int nx_count;
+  fetch_head(fb0, nx_pitch, nx_vol, nx_key, nx_count);
+
   for (int64_t fb = fb0; fb < fb0 + n_frames_blk; ++fb) { // frames fb0 .. of the block; scratch is indexed by fb
     const int64_t k_f = ra_fire_sample(p.N, p.H, f_lo + fb);
     const size_t lbase = ((size_t)s * b.frames_cap + fb) * maxr;
-    const int A = b.pl_count[(size_t)s * b.frames_cap + fb];
+    const int A = nx_count;
+    const double head_pitch = nx_pitch, head_vol = nx_vol;
+    const float head_key = nx_key;
+    fetch_head(fb + 1, nx_pitch, nx_vol, nx_key, nx_count);
 
-    // ---- phase 0: load the frame's list; per item the event payload (lib.cpp:319-324, midi.h:254-264) ----
+    // ---- phase 0: the frame's list; per item the event payload (lib.cpp:319-324, midi.h:254-264) ----
     for (int i = lane; i < A; i += 64) {
-      double pt = b.pl_pitch[lbase + i], v = b.pl_vol[lbase + i];
-      pitch[i] = pt; vol[i] = v; key[i] = b.pl_key[lbase + i];
+      double pt, v;
+      float ky;
+      if (i < 64) { pt = head_pitch; v = head_vol; ky = head_key; }
+      else { pt = b.pl_pitch[lbase + i]; v = b.pl_vol[lbase + i]; ky = b.pl_key[lbase + i]; }
+      pitch[i] = pt; vol[i] = v; key[i] = ky;
       float f = (float)((double)440.f * ra_pow(p.half_tone_ratio, pt - 69.0)); // midi.h:258-264; the power as in oracle_math.hpp (events are compared bit for bit)
       nf[i] = f;
       nv[i] = (float)((double)p.analysis_volume * v / (double)0.1f);
@@ -146,6 +167,15 @@ __global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, i
     }
     clk.lap<1>();
     // ---- phase 2: loudness order = stable rank sort by key, descending ----
+    if (A <= 64) { // the keys are in registers (one per lane): the other items' keys come by v_readlane instead of LDS round trips
+      int r = 0;
+      const int kbits = __float_as_int(head_key);
+      for (int j = 0; j < A; ++j) {
+        const float kj = __int_as_float(__builtin_amdgcn_readlane(kbits, j));
+        r += (kj > head_key || (kj == head_key && j < lane)) ? 1 : 0;
+      }
+      if (lane < A) ord[r] = lane;
+    } else
     for (int i = lane; i < A; i += 64) {
       float k = key[i];
       int r = 0;
@@ -223,6 +253,19 @@ __global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, i
 
     // ---- phase 6: remove_dead_notes + sort_by_current_pitch (both stable), algo.cpp:415-440 ----
     int kept = 0;
+    if (n_new <= 64) { // one note per lane: ranks among the kept notes from v_readlane broadcasts, walking the set bits of the kept mask
+      const bool is = lane < n_new && cont[lane];
+      const double pj = lane < n_new ? pl_pitch[lane] : 0.0;
+      const unsigned long long km = __ballot(is);
+      int r = 0;
+      for (unsigned long long m = km; m; m &= m - 1) {
+        const int i = __ffsll((long long)m) - 1;
+        const double pi = ra_readlane_f64(pj, i);
+        r += (pi < pj || (pi == pj && i < lane)) ? 1 : 0;
+      }
+      if (is) { tmp_pitch[r] = pj; tmp_noteid[r] = pl_noteid[lane]; tmp_chan[r] = pl_chan[lane]; }
+      kept = __popcll(km);
+    } else
     for (int j0 = 0; j0 < n_new; j0 += 64) {
       int j = j0 + lane;
       bool is = j < n_new && cont[j];
