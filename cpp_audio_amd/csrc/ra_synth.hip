@@ -623,7 +623,10 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) RA_PROP_OCC ra_synth_propagat
       c.flags |= FL_STEPPED0;
       --len;
     }
-    store_chan(c, b.seg_sd + seg * SD_COUNT * Ppad, b.seg_si + seg * SI_COUNT * Ppad, Ppad, l);
+    // the hop's start state for the render kernel: a channel that does not sound hands over its envelope state word only (the render
+    // never looks at the rest: half of the 12.8 KB per hop and stream on the BASELINE shapes)
+    if (rt_active(c)) store_chan(c, b.seg_sd + seg * SD_COUNT * Ppad, b.seg_si + seg * SI_COUNT * Ppad, Ppad, l);
+    else (b.seg_si + seg * SI_COUNT * Ppad)[SI_ENV_STATE * Ppad + l] = c.state;
     c.flags &= ~FL_STEPPED0;
     clk.lap<0>();
     chan_jump_phase(c, k.ep, k.dur, k.max_filter_inc, len);
@@ -651,8 +654,11 @@ __device__ inline void render_diag_segment(const RaParams &p, const RaBuffers &b
   if (seg_end <= seg_begin) return;
   const size_t seg = (size_t)s * b.seg_cap + sp.seg0 + i;
   Chan c;
-  load_chan(c, b.seg_sd + seg * SD_COUNT * Ppad, b.seg_si + seg * SI_COUNT * Ppad, Ppad, l);
-  chan_from_phase(c);
+  {
+    const int stv = (b.seg_si + seg * SI_COUNT * Ppad)[SI_ENV_STATE * Ppad + l];
+    if (stv != ENV_SOON && stv != ENV_DONE2) { load_chan(c, b.seg_sd + seg * SD_COUNT * Ppad, b.seg_si + seg * SI_COUNT * Ppad, Ppad, l); chan_from_phase(c); }
+    else { chan_init(c); c.state = stv; }
+  }
   const SynConst k = syn_const(p, s);
   const double *mix = (p.voc_enabled && b.voc_mix) ? b.voc_mix + (size_t)s * sp.n : nullptr;
   SynLds L = carve(ra_smem_syn, Ppad);
@@ -731,8 +737,11 @@ __device__ inline void render_pair(const RaParams &p, const RaBuffers &b, const 
     const int64_t bh = second ? beg1 : beg0, eh = second ? end1 : end0;
     if (eh <= bh) return;
     const size_t seg = seg0 + (second ? 1 : 0);
-    load_chan(c, b.seg_sd + seg * SD_COUNT * Ppad, b.seg_si + seg * SI_COUNT * Ppad, Ppad, l);
-    chan_from_phase(c);
+    { // (a silent channel's hop state is its envelope state word, see the propagate kernel)
+      const int stv = (b.seg_si + seg * SI_COUNT * Ppad)[SI_ENV_STATE * Ppad + l];
+      if (stv != ENV_SOON && stv != ENV_DONE2) { load_chan(c, b.seg_sd + seg * SD_COUNT * Ppad, b.seg_si + seg * SI_COUNT * Ppad, Ppad, l); chan_from_phase(c); }
+      else { chan_init(c); c.state = stv; }
+    }
     clk.mark(20);
     render_range_fast<MONO, false>(c, tile, k, p, s, l, bh, eh, sp.t0, sp.n, mix, out, out_d, b.error_flags, fb_mono, clk, Ppad, 0);
   }
