@@ -49,8 +49,8 @@ struct ra_context {
   int64_t kernel_launches[6] = {0, 0, 0, 0, 0, 0};
   // chunk pipeline: analysis / tracking / propagation / render streams and the events chaining them
   bool pipe_ready = false;
-  hipStream_t pipe_stream[4] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_voc = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t pipe_stream[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // analysis, tracking, propagation, render, vocoder
+  hipEvent_t ev_fork = nullptr, ev_voc = nullptr, ev_join[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_chunk[3][12] = {};
   // Per-block scratch (pitch lists, commands, hop states) exists twice: block k + 1 may run its analysis / tracking / propagation while
   // block k is still rendering (ra_process_device_async).  A set is reused two blocks later; the events say when its last readers are done.
@@ -59,6 +59,7 @@ struct ra_context {
     double *pl_pitch = nullptr, *pl_vol = nullptr; float *pl_key = nullptr; int32_t *pl_count = nullptr;
     RaCmd *cmd = nullptr; int32_t *cmd_non = nullptr;
     double *seg_sd = nullptr; int32_t *seg_si = nullptr;
+    double *voc_mix = nullptr; int64_t mix_cap = 0; // [n_streams][n] the vocoder's mix of the block (added by the render)
     hipEvent_t ev_track_done = nullptr, ev_prop_done = nullptr, ev_render_done = nullptr;
     bool used = false;
   } scr[2];
@@ -568,12 +569,15 @@ int ensure_scratch(ra_context *c, int64_t nfb, int64_t n, int n_chunks) {
   }
   if (p.voc_enabled) {
     size_t S = p.n_streams;
-    if (n > b.mix_cap) {
-      HIP_TRY(hipDeviceSynchronize()); // an earlier block may still use the old buffer on the render stream
-      dev_free(c, b.voc_mix);
-      b.mix_cap = n;
-      if ((r = dev_alloc(c, &b.voc_mix, S * n, false))) return r;
+    for (ra_context::Scratch &sc2 : c->scr) {
+      if (n > sc2.mix_cap) {
+        HIP_TRY(hipDeviceSynchronize()); // an earlier block may still use the old buffer
+        dev_free(c, sc2.voc_mix);
+        sc2.mix_cap = n;
+        if ((r = dev_alloc(c, &sc2.voc_mix, S * n, false))) return r;
+      }
     }
+    b.voc_mix = c->scr[c->parity].voc_mix; b.mix_cap = c->scr[c->parity].mix_cap;
     if (p.car_P > 0 && n > b.car_gen_cap) {
       HIP_TRY(hipDeviceSynchronize()); // an earlier block may still use the old buffer on the render stream
       dev_free(c, b.car_gen_d); dev_free(c, b.car_gen_f);
@@ -653,7 +657,7 @@ int timed_launch(ra_context *c, int stage, hipStream_t st, F &&launch) {
 // makes the caller's stream wait for everything the internal streams still hold (asynchronous blocks); no host synchronisation
 int join_streams(ra_context *c) {
   if (!c->pending_join || !c->pipe_ready) { c->pending_join = false; return RA_OK; }
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 5; ++i) {
     HIP_TRY(hipEventRecord(c->ev_join[i], c->pipe_stream[i]));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join[i], 0));
   }
@@ -802,30 +806,30 @@ int process_block_impl(ra_context *c, const float *d_voice, const float *d_carri
       // fills whatever the chain leaves free: the chain's queues get dispatch priority over the render queue.
       int prio_least = 0, prio_greatest = 0;
       HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-      for (int i = 0; i < 4; ++i) {
-        // RA_PIPELINE_PRIO (tuning aid): 0 = flat, 1 = chain high / render low, 2 = tracking and propagation high, analysis and render normal
-        const int prio = prio_mode == 0 ? 0 : prio_mode == 2 ? ((i == 1 || i == 2) ? prio_greatest : 0) : (i == 3 ? prio_least : prio_greatest);
+      for (int i = 0; i < 5; ++i) {
+        // RA_PIPELINE_PRIO (tuning aid): 0 = flat, 1 = chain high / render and vocoder low, 2 = tracking and propagation high, the others normal
+        const int prio = prio_mode == 0 ? 0 : prio_mode == 2 ? ((i == 1 || i == 2) ? prio_greatest : 0) : (i >= 3 ? prio_least : prio_greatest);
         HIP_TRY(hipStreamCreateWithPriority(&c->pipe_stream[i], hipStreamNonBlocking, prio));
       }
       HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&c->ev_voc, hipEventDisableTiming));
-      for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+      for (int i = 0; i < 5; ++i) HIP_TRY(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
       for (int i = 0; i < kMaxChunks; ++i)
         for (int k = 0; k < 3; ++k) HIP_TRY(hipEventCreateWithFlags(&c->ev_chunk[k][i], hipEventDisableTiming));
       c->pipe_ready = true;
     }
     // every stage has a queue of its own (on a shared queue propagate(i+1) would wait for render(i)); the caller's stream only
     // forks into them and joins them at the end of the block
-    hipStream_t sA = c->pipe_stream[0], sT = c->pipe_stream[1], sP = c->pipe_stream[2], sR = c->pipe_stream[3];
+    hipStream_t sA = c->pipe_stream[0], sT = c->pipe_stream[1], sP = c->pipe_stream[2], sR = c->pipe_stream[3], sV = c->pipe_stream[4];
     // streams of one priority share ROCm's 4 hardware queues; with flat priorities the analysis rides on the caller's stream instead so that
     // no two stages end up behind each other on one queue
     if (prio_mode == 0) sA = user;
     static const bool one_queue_env = std::getenv("RA_PIPELINE_SERIAL") != nullptr; // tuning aid: same chunks, no overlap
     const bool one_queue = one_queue_env || c->pipeline_serial;
-    if (one_queue) sA = sT = sP = sR = user;
+    if (one_queue) sA = sT = sP = sR = sV = user;
     if (sA == user) { if ((r = join_streams(c))) return r; async = false; } // tuning modes that use the caller's stream cannot overlap blocks
     HIP_TRY(hipEventRecord(c->ev_fork, user));
-    for (int i = 0; i < 4; ++i) HIP_TRY(hipStreamWaitEvent(c->pipe_stream[i], c->ev_fork, 0));
+    for (int i = 0; i < 5; ++i) HIP_TRY(hipStreamWaitEvent(c->pipe_stream[i], c->ev_fork, 0));
     // this scratch set was last used two blocks ago: its writers here wait for its readers there (normally long done)
     if (!sc.ev_track_done) {
       HIP_TRY(hipEventCreateWithFlags(&sc.ev_track_done, hipEventDisableTiming));
@@ -836,9 +840,13 @@ int process_block_impl(ra_context *c, const float *d_voice, const float *d_carri
       HIP_TRY(hipStreamWaitEvent(sA, sc.ev_track_done, 0));  // analysis rewrites the pitch lists tracking read
       HIP_TRY(hipStreamWaitEvent(sT, sc.ev_prop_done, 0));   // tracking rewrites the commands propagation read
       HIP_TRY(hipStreamWaitEvent(sP, sc.ev_render_done, 0)); // propagation rewrites the hop states the render read
+      if (p.voc_enabled) HIP_TRY(hipStreamWaitEvent(sV, sc.ev_render_done, 0)); // the vocoder rewrites this set's mix, which that render added
     }
-    if (p.voc_enabled) { // independent of the analysis chain: runs beside it, only the render waits for the mix
-      RA_TRY(timed_launch(c, ST_VOCODER, sR, [&] { launch_vocoder(sR); }));
+    if (p.voc_enabled) { // independent of the analysis chain, on a queue of its own: block k + 1's vocoder runs while block k renders (the
+      // mix exists per scratch set; the vocoder's own scratch and the generated carrier are only touched on this queue, in block order)
+      RA_TRY(timed_launch(c, ST_VOCODER, sV, [&] { launch_vocoder(sV); }));
+      HIP_TRY(hipEventRecord(c->ev_voc, sV));
+      if (sR != sV) HIP_TRY(hipStreamWaitEvent(sR, c->ev_voc, 0));
     }
     // Chunk boundaries (in frames).  The first chunk is short — nothing overlaps its analysis -> tracking -> propagation, so the render
     // stream starts that much sooner — and so are the last two: when the analysis of the block is over, only the chain and the render of
@@ -1060,7 +1068,7 @@ void ra_destroy(ra_context *c) {
   for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->pipe_ready) {
-    for (int i = 0; i < 4; ++i) { (void)hipStreamSynchronize(c->pipe_stream[i]); (void)hipStreamDestroy(c->pipe_stream[i]); }
+    for (int i = 0; i < 5; ++i) { (void)hipStreamSynchronize(c->pipe_stream[i]); (void)hipStreamDestroy(c->pipe_stream[i]); }
     (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_voc);
     for (auto e : c->ev_join) (void)hipEventDestroy(e);
     for (auto &row : c->ev_chunk) for (auto e : row) if (e) (void)hipEventDestroy(e);
