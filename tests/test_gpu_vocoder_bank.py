@@ -136,13 +136,14 @@ def test_carrier_synth_matches_oracle(api, oracle, case):
         assert dropped > 0, "the case is meant to exhaust the channels"
 
 
-@pytest.mark.parametrize("sine", [0.0, 0.5])
-def test_carrier_synth_time_parallel_equals_sample_serial(api, sine):
+@pytest.mark.parametrize("sine,channels", [(0.0, 6), (0.5, 6), (0.0, 1), (0.0, 100), (0.4, 256)])
+def test_carrier_synth_time_parallel_equals_sample_serial(api, sine, channels):
     # the default carrier synth walks the events, stores the channels' states every 256 samples and at every event, and renders the
     # segments in parallel; reference_order 1 runs the one sample-serial kernel.  The phase-controlled voices are the same operation
     # sequences in both (equal bit for bit); the sine restarts each segment from sincospi(theta).
     n, S = 50000, 4
-    kw = dict(BASE, carrier_n_channels=6, carrier_volume=1.0, voice_volume=0.0, vocoder_volume=0.0, **dict(VOICES, vocoder_carrier_sine_volume=sine),
+    # (1 channel: 64 segments share a wave of the render; 100 / 256: two / four waves per segment)
+    kw = dict(BASE, carrier_n_channels=channels, carrier_volume=1.0, voice_volume=0.0, vocoder_volume=0.0, **dict(VOICES, vocoder_carrier_sine_volume=sine),
               env_attack_seconds=0.01, env_hold_seconds=0.002, env_decay_seconds=0.03, env_release_seconds=0.05, env_sustain_level=0.5)
     rng = np.random.default_rng(8)
     rows = []
