@@ -210,6 +210,34 @@ class Runner:
         self.torch.cuda.empty_cache()
 
 
+def time_voice(api, torch, dev, S, seconds, steps):
+    """SURVEY.md section 8 (f4), first slice: gen.voice in SWEEP mode, S synths of 16 channels, a sweep note every 50 ms per synth, output in HBM."""
+    n = int(round(seconds * SR))
+    cfg = api.voice_default_config(seed=99, random_pan=1, length_exponent=2.0)
+    out = torch.empty(S, n, 2, dtype=torch.float32, device=dev)
+    rows = []
+    for s in range(S):
+        per = []
+        for k in range(int((steps + 1) * seconds * 20)):
+            on = k * (SR // 20) + 7 * (s % 64)
+            per.append((on, s, 0, k, 440.0, 0.5))
+            per.append((on + (SR * 4) // 10, s, 1, k, 0.0, 0.0))   # released after the 292 ms sweep has ended: the channel is free again
+        rows += sorted(per, key=lambda r: r[0])
+    with api.Voice(cfg, S, 0) as v:
+        v.events(rows)
+        v.process_device(n, out.data_ptr())   # warm-up block
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            v.process_device(n, out.data_ptr())
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        dropped = v.dropped_note_ons()
+    return {"config": f"gen.voice SWEEP (section 8 f4, first slice): {S} synths x 16 channels, a 292 ms sweep note every 50 ms, {seconds:g} s per step, output resident",
+            "streams": S, "seconds_per_step": seconds, "steps": steps, "ms_per_step": dt * 1e3, "frames_per_s": S * n / dt,
+            "dropped_note_on": int(dropped), "out_rms": float(out.double().pow(2).mean().sqrt().item())}
+
+
 def time_config(api, torch, dev, name, cfg_kw, S, seconds, steps, carrier=None):
     """An `other_configs` entry: full-size timing of another BASELINE config (same issue mode and clock as the headline)."""
     n = int(round(seconds * SR))
@@ -440,6 +468,7 @@ def main():
             others.append(time_config(api, torch, dev, "configs[3]: 1000 stereo = 2000 mono streams, N = 8192, H = 2048, P = 128, autotune major / C",
                                       dict(parity, window_size=8192, stride=2048, n_channels=128, use_autotune=1, autotune_type=0, autotune_scale_mode=0,
                                            autotune_root_note=0), 2000, 10.0, 2))
+            others.append(time_voice(api, torch, dev, 256, 10.0, 2))
         except Exception as e:  # a failure here must not cost the headline line
             others.append({"error": repr(e)})
         result["other_configs"] = others

@@ -81,7 +81,7 @@ EXPORTED_SYMBOLS = [
     "ra_feed", "ra_compute", "ra_get_stats", "ra_get_events", "ra_get_frame_pitches", "ra_resynth_notes", "ra_sqmag",
     "ra_set_profiling", "ra_get_kernel_ms", "ra_get_kernel_launches", "ra_render_note",
     "ra_carrier_events", "ra_get_carrier", "ra_set_pipeline_serial", "ra_deduce_notes",
-    "ra_voice_default_config", "ra_voice_create", "ra_voice_destroy", "ra_voice_events", "ra_voice_process_host", "ra_voice_dropped_note_ons",
+    "ra_voice_default_config", "ra_voice_create", "ra_voice_destroy", "ra_voice_events", "ra_voice_process_host", "ra_voice_process_device", "ra_voice_dropped_note_ons",
 ]
 
 _lib = None
@@ -340,6 +340,7 @@ class Voice:
         L.ra_voice_destroy.restype = None
         L.ra_voice_events.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.ra_voice_process_host.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        L.ra_voice_process_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         L.ra_voice_dropped_note_ons.argtypes = [C.c_void_p]
         L.ra_voice_dropped_note_ons.restype = C.c_int64
         _check(L.ra_voice_create(C.byref(cfg), self.n_streams, int(device), C.byref(self._h)))
@@ -372,6 +373,10 @@ class Voice:
         out = np.empty((self.n_streams, int(n_frames), 2), np.float32)
         _check(lib().ra_voice_process_host(self._h, int(n_frames), _p(out)))
         return out
+
+    def process_device(self, n_frames, d_out_ptr):
+        """d_out_ptr: device pointer to [n_streams][n_frames][2] float32 (e.g. a torch tensor's data_ptr())."""
+        _check(lib().ra_voice_process_device(self._h, int(n_frames), C.c_void_p(int(d_out_ptr))))
 
     def dropped_note_ons(self):
         return _check(lib().ra_voice_dropped_note_ons(self._h))

@@ -1710,10 +1710,7 @@ int ra_voice_events(ra_voice *v, const ra_voice_event *ev, int64_t n) {
   return RA_OK;
 }
 
-int ra_voice_process_host(ra_voice *v, int64_t n, float *h_out) {
-  if (!v) return fail(RA_EINVAL, "null context");
-  if (n < 0 || (n > 0 && !h_out)) return fail(RA_EINVAL, "bad output");
-  if (n == 0) return RA_OK;
+static int voice_block(ra_voice *v, int64_t n, float *d_out) { // stages the block's events and runs it into d_out (device)
   HIP_TRY(hipSetDevice(v->device));
   const int S = v->n_streams;
   std::vector<RaVoiceEv> flat;
@@ -1730,18 +1727,36 @@ int ra_voice_process_host(ra_voice *v, int64_t n, float *h_out) {
     v->ev_cap = std::max<int64_t>(256, 2 * static_cast<int64_t>(flat.size()));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&v->ev), sizeof(RaVoiceEv) * v->ev_cap));
   }
+  if (!flat.empty()) HIP_TRY(hipMemcpy(v->ev, flat.data(), sizeof(RaVoiceEv) * flat.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(v->ev_begin, begin.data(), sizeof(int32_t) * begin.size(), hipMemcpyHostToDevice));
+  ra_voice_launch(v->p, v->state, v->ev, v->ev_begin, v->dropped, S, v->t, n, d_out, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  v->t += n;
+  return RA_OK;
+}
+
+int ra_voice_process_device(ra_voice *v, int64_t n, float *d_out) {
+  if (!v) return fail(RA_EINVAL, "null context");
+  if (n < 0 || (n > 0 && !d_out)) return fail(RA_EINVAL, "bad output");
+  if (n == 0) return RA_OK;
+  return voice_block(v, n, d_out);
+}
+
+int ra_voice_process_host(ra_voice *v, int64_t n, float *h_out) {
+  if (!v) return fail(RA_EINVAL, "null context");
+  if (n < 0 || (n > 0 && !h_out)) return fail(RA_EINVAL, "bad output");
+  if (n == 0) return RA_OK;
+  HIP_TRY(hipSetDevice(v->device));
+  const int S = v->n_streams;
   if (n > v->out_cap) {
     (void)hipFree(v->out);
     v->out = nullptr;
     v->out_cap = n;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&v->out), sizeof(float) * 2 * static_cast<size_t>(S) * n));
   }
-  if (!flat.empty()) HIP_TRY(hipMemcpy(v->ev, flat.data(), sizeof(RaVoiceEv) * flat.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(v->ev_begin, begin.data(), sizeof(int32_t) * begin.size(), hipMemcpyHostToDevice));
-  ra_voice_launch(v->p, v->state, v->ev, v->ev_begin, v->dropped, S, v->t, n, v->out, nullptr);
-  HIP_TRY(hipGetLastError());
+  if (int r = voice_block(v, n, v->out)) return r;
   HIP_TRY(hipMemcpy(h_out, v->out, sizeof(float) * 2 * static_cast<size_t>(S) * n, hipMemcpyDeviceToHost));
-  v->t += n;
   return RA_OK;
 }
 

@@ -353,6 +353,8 @@ void ra_voice_destroy(ra_voice *v);
 int ra_voice_events(ra_voice *v, const ra_voice_event *h_events, int64_t n_events);
 /* Impl_::doProcessing over n_frames for every stream: h_out [n_streams][n_frames][2] float32 (HOST pointer); consecutive calls continue */
 int ra_voice_process_host(ra_voice *v, int64_t n_frames, float *h_out);
+/* the same with the output resident in HBM: d_out [n_streams][n_frames][2] float32 (DEVICE pointer); synchronous on the null stream */
+int ra_voice_process_device(ra_voice *v, int64_t n_frames, float *d_out);
 /* note-ons that found no channel (onDroppedNote), all streams; negative RA_E* on error */
 int64_t ra_voice_dropped_note_ons(ra_voice *v);
 

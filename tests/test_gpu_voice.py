@@ -71,6 +71,21 @@ def test_sweep_voice_is_a_sweep(api):
     assert np.allclose(out[m, 1] / out[m, 0], g[1] / g[0], rtol=1e-4)
 
 
+def test_voice_output_resident_in_hbm_equals_host_output(api):
+    import torch
+    rows = [(100 * k + 37 * s, s, 0, 10 * s + k, 200.0 + 50 * k, 0.8) for s in range(3) for k in range(5)]
+    rows.sort(key=lambda r: (r[1], r[0]))
+    cfg = api.voice_default_config(seed=5, random_pan=1)
+    with api.Voice(cfg, 3, 0) as v:
+        v.events(rows)
+        host = v.process(30000)
+    with api.Voice(cfg, 3, 0) as v:
+        v.events(rows)
+        out = torch.empty(3, 30000, 2, dtype=torch.float32, device="cuda:0")
+        v.process_device(30000, out.data_ptr())
+    assert np.any(host != 0) and np.array_equal(out.cpu().numpy(), host)
+
+
 def test_voice_argument_errors(api):
     for kw in (dict(n_channels=0), dict(low_freq=0.0), dict(length_ms=0.0), dict(loudness_ref_freq_index=16), dict(length_ms=10.0, length_exponent=0.0, xfade_length_seconds=0.04)):
         with pytest.raises(api.RaError) as e:
