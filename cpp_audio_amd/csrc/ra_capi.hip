@@ -271,8 +271,10 @@ int build_vocoder_tables(ra_context *c) {
   p.voc_Mc = p.voc_Lc / 2;
   p.voc_bands = cfg.vocoder_count_bands;
   if (cfg.vocoder_kind == RA_VOCODER_FFT) {
-    if (p.voc_Lm > RA_MAX_FFT) return fail(RA_EINVAL, "vocoder modulator window is too large (FFT length > 16384)");
-    if (p.voc_Lc > 4096) return fail(RA_EINVAL, "vocoder stride is too large (carrier FFT length > 4096)");
+    // the reference's own limits (vocoder.cpp:94-96): modulator FFT <= 2^16 (the window is clamped to it above, :111-115), stride <= 2^16,
+    // carrier FFT <= 2^17.  Transforms that do not fit the 160 KB of LDS run on buffers in HBM (ra_vocoder.hip: BIG).
+    if (S > (1 << 16)) return fail(RA_EINVAL, "vocoder stride is too large (max_stride_size = 65536 frames, vocoder.cpp:96)");
+    if (p.voc_Lm > (1 << 16) || p.voc_Lc > (1 << 17)) return fail(RA_EINVAL, "vocoder FFT length above the reference's maximum (65536 / 131072)");
   }
   if (!(cfg.vocoder_min_freq > 0.f) || !(cfg.vocoder_max_freq > cfg.vocoder_min_freq)) return fail(RA_EINVAL, "vocoder band limits must satisfy 0 < min < max");
   // SetupParams::fill_freqs, vocoder.cpp:15-27 (float logs, double exp)
@@ -434,6 +436,20 @@ int alloc_state(ra_context *c) {
     if ((r = dev_alloc(c, &b.voc_car_hist, S * 2 * p.voc_S))) return r;
     if ((r = dev_alloc(c, &b.voc_amp_prev, S * p.voc_bands))) return r;
     if ((r = dev_alloc(c, &b.voc_sig_prev, S * 4 * p.voc_S))) return r;
+    // transforms and history rolls that do not fit LDS work on buffers in HBM (ra_vocoder.hip)
+    const size_t mod_slots = (size_t)std::max(p.voc_Mm, 16), car_slots = (size_t)std::max(p.voc_Mc, 16) + std::max(p.voc_Mc, 1);
+    size_t big = 0;
+    if (mod_slots * sizeof(double2) > (size_t)RA_LDS_LIMIT_BYTES) big = std::max(big, mod_slots);
+    if (car_slots * sizeof(double2) > (size_t)RA_LDS_LIMIT_BYTES) big = std::max(big, car_slots);
+    if (big) {
+      b.voc_big_slot = (int64_t)big;
+      if ((r = dev_alloc(c, &b.voc_big, ((size_t)RA_VOC_BIG_WORKGROUPS + S) * big, false))) return r;
+    }
+    const size_t roll_bytes = std::max((size_t)4 * p.voc_S * sizeof(double), (size_t)p.voc_Wm * sizeof(float));
+    if (roll_bytes > (size_t)RA_LDS_LIMIT_BYTES) {
+      b.voc_roll_slot = (int64_t)((roll_bytes + sizeof(double) - 1) / sizeof(double));
+      if ((r = dev_alloc(c, &b.voc_roll_tmp, S * (size_t)b.voc_roll_slot, false))) return r;
+    }
   }
   if (p.voc_enabled && p.voc_kind == RA_VOCODER_BANDPASS && (r = dev_alloc(c, &b.bank_state, S * 5 * 64))) return r;
   if (p.post_limit && (r = dev_alloc(c, &b.lim_state, S * 2))) return r;

@@ -92,6 +92,8 @@ enum { ENV_SOON = 0, ENV_PRESSED = 1, ENV_RELEASED = 2, ENV_DONE1 = 3, ENV_DONE2
 enum { RA_ERR_OVERFLOW = 1, RA_ERR_BOOKKEEPING = 2 };
 
 // device buffers of one context
+constexpr int RA_VOC_BIG_WORKGROUPS = 1024; // workgroups of a vocoder launch whose transform buffers live in HBM (ra_vocoder.hip)
+
 struct RaBuffers {
   // constant tables
   double *half_window;      // [N/2]
@@ -154,6 +156,10 @@ struct RaBuffers {
   double *bank_k;           // [3][64] one-pole coefficients per band: high-pass (band's lower edge), low-pass (upper edge), envelope follower
   double *bank_state;       // [n_streams][5][64] filter states: modulator hp / lp, envelope follower, carrier hp / lp
   // ---- vocoder (only allocated when a vocoder volume is non-zero) ----
+  double2 *voc_big;         // transform buffers in HBM for frames that do not fit LDS: [RA_VOC_BIG_WORKGROUPS + n_streams][voc_big_slot], else null
+  int64_t voc_big_slot;
+  double *voc_roll_tmp;     // [n_streams][voc_roll_slot] staging of the history roll when it does not fit LDS, else null
+  int64_t voc_roll_slot;
   double *voc_half_window;  // [Wm/2] Gaussian 4 sigma
   double2 *vm_tw_half, *vm_tw_full; int *vm_bitrev;   // modulator FFT, length Lm
   double2 *vc_tw_half, *vc_tw_full; int *vc_bitrev;   // carrier FFT, length Lc

@@ -25,7 +25,9 @@ __device__ inline int ilog2(int m) { return 31 - __clz(m); }
 
 // ---- K4a ------------------------------------------------------------------------------------------
 // T threads per frame: 256, or 512 when the FFT buffer (M >= 4096: 70 KB) leaves room for only two workgroups per CU.
-template <int T>
+// BIG: the transform buffer does not fit the 160 KB of LDS (windows above 16384 samples, up to the reference's 65536): the same code runs on a
+// per-workgroup buffer in HBM (the barriers between passes order a workgroup's global writes and reads); slow, but the size is supported.
+template <int T, bool BIG>
 __global__ void __launch_bounds__(T, 4) ra_voc_modulator_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int64_t t0, int64_t n, int64_t j_lo,
                                                             int n_mod, int fpw) {
   // a workgroup takes fpw consecutive frames of its stream (workgroup launches amortised; the window weights and twiddles stay warm)
@@ -36,7 +38,8 @@ __global__ void __launch_bounds__(T, 4) ra_voc_modulator_kernel(RaParams p, RaBu
   int tid = threadIdx.x, M = p.voc_Mm;
   asm volatile("" : "+v"(tid), "+s"(M));
   const int W = p.voc_Wm, S = p.voc_S, log2M = ilog2(M);
-  double2 *z = reinterpret_cast<double2 *>(ra_smem_voc); // element i lives in slot ra_zslot(i, zs)
+  double2 *z = BIG ? b.voc_big + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * b.voc_big_slot
+                   : reinterpret_cast<double2 *>(ra_smem_voc); // element i lives in slot ra_zslot(i, zs)
   const int zs = ra_zshift(log2M);
   auto Z = [&](int i) -> double2 & { return z[ra_zslot(i, zs)]; };
   // twiddles of the first trip of the real-spectrum split, fetched before the FFT
@@ -124,7 +127,7 @@ __global__ void __launch_bounds__(T, 4) ra_voc_modulator_kernel(RaParams p, RaBu
 
 // ---- K4b ------------------------------------------------------------------------------------------
 // T threads per frame: one wavefront for the usual short carrier frames (L = 512: 32 radix-8 groups per pass), 256 for long ones.
-template <int T>
+template <int T, bool BIG>
 __global__ void __launch_bounds__(T) ra_voc_carrier_kernel(RaParams p, RaBuffers b, const float *__restrict__ carrier, int64_t t0, int64_t n, int64_t i_lo,
                                                           int64_t j_lo, int64_t n_mod, int n_car, int fpw) {
   // a workgroup takes fpw consecutive frames of its stream, like the modulator's (tid and M laundered against hoisting)
@@ -133,7 +136,8 @@ __global__ void __launch_bounds__(T) ra_voc_carrier_kernel(RaParams p, RaBuffers
   int tid = threadIdx.x, M = p.voc_Mc;
   asm volatile("" : "+v"(tid), "+s"(M));
   const int L = p.voc_Lc, S = p.voc_S, W = 2 * p.voc_S, B = p.voc_bands, log2M = ilog2(M);
-  double2 *z = reinterpret_cast<double2 *>(ra_smem_voc);  // [ra_zsize(M)] transform buffer
+  double2 *z = BIG ? b.voc_big + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * b.voc_big_slot
+                   : reinterpret_cast<double2 *>(ra_smem_voc);  // [ra_zsize(M)] transform buffer (BIG: in HBM, see the modulator)
   double2 *zin = z + ra_zsize(M);                      // [M] input of the inverse transform
   const int zs = ra_zshift(log2M);
   auto Z = [&](int i) -> double2 & { return z[ra_zslot(i, zs)]; };
@@ -243,7 +247,8 @@ __global__ void ra_voc_roll_kernel(RaParams p, RaBuffers b, const float *__restr
                                    int64_t n_car, int64_t n_mod) {
   const int s = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
   const int W = 2 * p.voc_S, Wm = p.voc_Wm, B = p.voc_bands;
-  double *tmp = reinterpret_cast<double *>(ra_smem_voc); // >= max(2*W doubles, Wm floats)
+  // staging buffer of max(2 W doubles, Wm floats): LDS, or (long strides / windows) this stream's part of the HBM scratch
+  double *tmp = b.voc_roll_tmp ? b.voc_roll_tmp + (size_t)s * b.voc_roll_slot : reinterpret_cast<double *>(ra_smem_voc);
   // carrier frames: new prev = frames (i_hi - 1, i_hi) where i_hi = i_lo + n_car - 1
   if (n_car > 0) {
     double *prev = b.voc_sig_prev + (size_t)s * 2 * W;
@@ -290,10 +295,10 @@ void ra_launch_vocoder(const RaParams &p, const RaBuffers &b, const float *d_voi
   RaFrameRange car = ra_frames_firing(W, S, t0, n);
   static unsigned long long attr_done = 0;
   ra_once_per_device(attr_done, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_modulator_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_modulator_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_carrier_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_carrier_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_modulator_kernel<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_modulator_kernel<512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_carrier_kernel<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_carrier_kernel<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_roll_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   if (mod.count > 0) {
@@ -303,26 +308,32 @@ void ra_launch_vocoder(const RaParams &p, const RaBuffers &b, const float *d_voi
     int fpw = 8;
     while (fpw > 1 && ((mod.count + fpw - 1) / fpw) * (int64_t)p.n_streams < 1024) fpw >>= 1;
     if (fpw_env > 0) fpw = fpw_env;
-    const dim3 grid((unsigned)((mod.count + fpw - 1) / fpw), (unsigned)p.n_streams);
     const size_t lds = (size_t)ra_zsize(p.voc_Mm) * sizeof(double2);
-    if (p.voc_Mm >= 4096) hipLaunchKernelGGL(ra_voc_modulator_kernel<512>, grid, dim3(512), lds, st, p, b, d_voice, t0, n, mod.lo, (int)mod.count, fpw);
-    else hipLaunchKernelGGL(ra_voc_modulator_kernel<256>, grid, dim3(256), lds, st, p, b, d_voice, t0, n, mod.lo, (int)mod.count, fpw);
+    const bool big = lds > (size_t)RA_LDS_LIMIT_BYTES;
+    if (big) fpw = (int)std::max<int64_t>(1, (mod.count * (int64_t)p.n_streams + RA_VOC_BIG_WORKGROUPS - 1) / RA_VOC_BIG_WORKGROUPS); // <= RA_VOC_BIG_WORKGROUPS + n_streams buffers
+    const dim3 grid((unsigned)((mod.count + fpw - 1) / fpw), (unsigned)p.n_streams);
+    if (big) hipLaunchKernelGGL((ra_voc_modulator_kernel<512, true>), grid, dim3(512), 0, st, p, b, d_voice, t0, n, mod.lo, (int)mod.count, fpw);
+    else if (p.voc_Mm >= 4096) hipLaunchKernelGGL((ra_voc_modulator_kernel<512, false>), grid, dim3(512), lds, st, p, b, d_voice, t0, n, mod.lo, (int)mod.count, fpw);
+    else hipLaunchKernelGGL((ra_voc_modulator_kernel<256, false>), grid, dim3(256), lds, st, p, b, d_voice, t0, n, mod.lo, (int)mod.count, fpw);
   }
   if (car.count > 0) {
     static const int cfpw_env = [] { const char *e = getenv("RA_VOC_CARRIER_FPW"); return e ? atoi(e) : 0; }();
     int cfpw = 8; // frames per workgroup, as for the modulator
     while (cfpw > 1 && ((car.count + cfpw - 1) / cfpw) * (int64_t)p.n_streams < 4096) cfpw >>= 1;
     if (cfpw_env > 0) cfpw = cfpw_env;
-    const dim3 grid((unsigned)((car.count + cfpw - 1) / cfpw), (unsigned)p.n_streams);
     const int Mc = std::max(p.voc_Mc, 1);
     const size_t lds = ((size_t)ra_zsize(Mc) + Mc) * sizeof(double2);
-    if (Mc <= 512) hipLaunchKernelGGL(ra_voc_carrier_kernel<64>, grid, dim3(64), lds, st, p, b, d_carrier, t0, n, car.lo, mod.lo, mod.count, (int)car.count, cfpw);
-    else hipLaunchKernelGGL(ra_voc_carrier_kernel<256>, grid, dim3(256), lds, st, p, b, d_carrier, t0, n, car.lo, mod.lo, mod.count, (int)car.count, cfpw);
+    const bool big = lds > (size_t)RA_LDS_LIMIT_BYTES;
+    if (big) cfpw = (int)std::max<int64_t>(1, (car.count * (int64_t)p.n_streams + RA_VOC_BIG_WORKGROUPS - 1) / RA_VOC_BIG_WORKGROUPS);
+    const dim3 grid((unsigned)((car.count + cfpw - 1) / cfpw), (unsigned)p.n_streams);
+    if (big) hipLaunchKernelGGL((ra_voc_carrier_kernel<256, true>), grid, dim3(256), 0, st, p, b, d_carrier, t0, n, car.lo, mod.lo, mod.count, (int)car.count, cfpw);
+    else if (Mc <= 512) hipLaunchKernelGGL((ra_voc_carrier_kernel<64, false>), grid, dim3(64), lds, st, p, b, d_carrier, t0, n, car.lo, mod.lo, mod.count, (int)car.count, cfpw);
+    else hipLaunchKernelGGL((ra_voc_carrier_kernel<256, false>), grid, dim3(256), lds, st, p, b, d_carrier, t0, n, car.lo, mod.lo, mod.count, (int)car.count, cfpw);
   }
   {
     unsigned gx = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
     hipLaunchKernelGGL(ra_voc_mix_kernel, dim3(gx, (unsigned)p.n_streams), dim3(256), 0, st, p, b, d_voice, d_carrier, carrier_d, t0, n, car.lo, car.count);
   }
-  size_t lds = std::max((size_t)2 * W * sizeof(double), (size_t)p.voc_Wm * sizeof(float));
+  size_t lds = b.voc_roll_tmp ? 0 : std::max((size_t)2 * W * sizeof(double), (size_t)p.voc_Wm * sizeof(float));
   hipLaunchKernelGGL(ra_voc_roll_kernel, dim3((unsigned)p.n_streams), dim3(256), lds, st, p, b, d_voice, d_carrier, n, car.lo, car.count, mod.count);
 }

@@ -317,6 +317,30 @@ def test_vocoder_variants(api, oracle, sig, kw):
     check_streams(api, oracle, x, carrier=car, **kw)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(vocoder_modulator_window_size_seconds=0.5),                                   # window 24000 -> FFT 32768: 256 KB of complex points, in HBM
+    dict(vocoder_modulator_window_size_seconds=1.4),                                   # clamped to the reference's 65536 (vocoder.cpp:94,111-115)
+    dict(vocoder_stride_seconds=0.12),                                                 # S = 5761: carrier FFT 16384, transform + inverse input in HBM
+    dict(vocoder_modulator_window_size_seconds=0.6, vocoder_stride_seconds=0.3),       # S = 14401: carrier FFT 32768, the history roll staged in HBM too
+])
+def test_vocoder_sizes_beyond_lds(api, oracle, sig, kw):
+    # the reference allows modulator FFTs up to 2^16 and carrier FFTs up to 2^17 (vocoder.cpp:94-96); frames that do not fit the 160 KB of
+    # LDS run the same transforms on per-workgroup buffers in HBM (ra_vocoder.hip: BIG)
+    n = 120000
+    x = sig.make_streams(2, n, kind="speech", base_seed=8)
+    car = np.stack([sig.carrier_stream(n, freq=82.0), sig.carrier_stream(n, freq=196.0)])
+    full = dict(VOC_KW, **kw)
+    check_streams(api, oracle, x, carrier=car, **full)
+    # and the block cut does not matter there either
+    cfg = api.default_config(**dict(PARITY_KW, **full))
+    with api.Context(cfg, 2, 0) as ctx:
+        whole = ctx.process_host(x, car)
+        ctx.reset()
+        cuts = [0, 17, 30001, 70000, n]
+        parts = [ctx.process_host(x[:, a:b], car[:, a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        assert np.array_equal(np.concatenate(parts, axis=1), whole)
+
+
 def test_vocoder_block_size_invariance(api, sig):
     n = 40000
     x = sig.make_streams(2, n, kind="speech")
