@@ -210,6 +210,26 @@ class Runner:
         self.torch.cuda.empty_cache()
 
 
+def time_compute_shim(api, calls=400):
+    """The reference's real-time seam, `ComputeFunc = bool(double*, int nFrames)` with nFrames <= 16 (simple_audio_context.h:24-26), through
+    ra_feed + ra_compute on a single-stream context: two copies, one block's launches and a synchronisation per call.  A correctness shim
+    (INTEGRATION.md section 2), timed here so that its cost is on record: 16 frames are 333 us of audio at 48 kHz."""
+    import numpy as np
+    cfg = api.default_config(analysis_volume=1.0, stereo_spread=0.0, carrier_volume=0.0, seed=1)
+    rng = np.random.default_rng(0)
+    x = (0.1 * rng.standard_normal(16 * (calls + 50))).astype(np.float32)
+    buf = np.zeros((16, 2), np.float64)
+    with api.Context(cfg, 1, 0) as ctx:
+        for k in range(50):   # warm-up (allocations, first frames)
+            ctx.feed(x[16 * k:16 * k + 16]); ctx.compute(buf, 16)
+        t0 = time.perf_counter()
+        for k in range(50, 50 + calls):
+            ctx.feed(x[16 * k:16 * k + 16]); ctx.compute(buf, 16)
+        dt = (time.perf_counter() - t0) / calls
+    return {"config": "ComputeFunc shim: one stream, ra_feed(16) + ra_compute(16) per call (window 4096, stride 1024, 64 partials)",
+            "us_per_call": dt * 1e6, "frames_per_call": 16, "x_realtime": 16 / SR / dt}
+
+
 def time_voice(api, torch, dev, S, seconds, steps):
     """SURVEY.md section 8 (f4), first slice: gen.voice in SWEEP mode, S synths of 16 channels, a sweep note every 50 ms per synth, output in HBM."""
     n = int(round(seconds * SR))
@@ -469,6 +489,7 @@ def main():
                                       dict(parity, window_size=8192, stride=2048, n_channels=128, use_autotune=1, autotune_type=0, autotune_scale_mode=0,
                                            autotune_root_note=0), 2000, 10.0, 2))
             others.append(time_voice(api, torch, dev, 256, 10.0, 2))
+            others.append(time_compute_shim(api))
         except Exception as e:  # a failure here must not cost the headline line
             others.append({"error": repr(e)})
         result["other_configs"] = others
