@@ -1622,7 +1622,24 @@ struct ra_voice {
   int64_t out_cap = 0;
   std::vector<std::deque<RaVoiceEv>> pending;
   std::vector<int64_t> last_sample;
+  // ---- one note per lane (the default; RA_VOICE_SERIAL=1 keeps the sample-serial kernel) ----
+  // The channel bookkeeping of ImplCRTP::onEvent over SoundEngine::tryAcquire (soundengine.h:291-308,457-467) is walked here: a channel is
+  // free iff no note is on and its ramp's envelope is finished; a note-off before that leaves the ramp unfinished and the channel lost.
+  bool serial = false;
+  int k_done2 = 0;                  // steps from a note's first step until its ramp's envelope is finished (probed on the device)
+  struct Chan { bool odd = false, lost = false; int64_t noteid = -1, t_on = 0; int live = -1; /* index into `live` of the note that is on, or -1 */ };
+  struct Live { int stream, chan; int64_t t_on, noteid, done, limit; float vel; };
+  std::vector<Chan> chans;          // [n_streams][P]
+  std::vector<Live> live;           // notes that still have steps to render
+  int64_t dropped_host = 0;
+  int slot_parity = 0;
+  void *note_slots = nullptr;       // [n_streams][P] VoiceChan: the state of the channel's note where it left the last block
+  void *notes_dev = nullptr;
+  int64_t notes_cap = 0;
+  double *accum = nullptr;          // [n_streams][n][2], zero between blocks
+  int64_t accum_cap = 0;
 };
+struct RaVoiceNoteHost { int64_t begin; int64_t noteid; int32_t stream, slot, steps, fresh; float vel; int32_t store; }; // = ra_voice.hip: RaVoiceNote
 
 int ra_voice_default_config(ra_voice_config *c) {
   if (!c) return fail(RA_EINVAL, "null config");
@@ -1693,6 +1710,18 @@ int ra_voice_create(const ra_voice_config *cfg, int32_t n_streams, int32_t devic
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v->ev_begin), sizeof(int32_t) * (n_streams + 1));
   if (e == hipSuccess) e = hipMemset(v->dropped, 0, sizeof(int32_t) * n_streams);
   if (e == hipSuccess) { ra_voice_launch_init(v->state, count, nullptr); e = hipDeviceSynchronize(); }
+  v->serial = std::getenv("RA_VOICE_SERIAL") != nullptr;
+  if (e == hipSuccess && !v->serial) {
+    v->chans.assign((size_t)n_streams * p.P, {});
+    e = hipMalloc(&v->note_slots, 2 * ra_voice_state_bytes() * (size_t)n_streams * p.P); // two sets, alternating by block
+    if (e == hipSuccess) {
+      v->k_done2 = ra_voice_probe_done2(p, v->dropped); // (the counter array serves as scratch; zeroed again below)
+      if (v->k_done2 < 0) e = hipErrorUnknown;
+      else e = hipMemset(v->dropped, 0, sizeof(int32_t) * n_streams);
+    }
+    static_assert(sizeof(RaVoiceNoteHost) == 40, "layout of the note descriptor");
+    if (e == hipSuccess && ra_voice_note_bytes() != sizeof(RaVoiceNoteHost)) e = hipErrorUnknown;
+  }
   if (e != hipSuccess) { ra_voice_destroy(v); return fail(RA_EHIP, std::string("ra_voice_create: ") + hipGetErrorString(e)); }
   *out = v;
   return RA_OK;
@@ -1703,6 +1732,7 @@ void ra_voice_destroy(ra_voice *v) {
   (void)hipSetDevice(v->device);
   (void)hipDeviceSynchronize();
   (void)hipFree(v->state); (void)hipFree(v->dropped); (void)hipFree(v->ev_begin); (void)hipFree(v->ev); (void)hipFree(v->out);
+  (void)hipFree(v->note_slots); (void)hipFree(v->notes_dev); (void)hipFree(v->accum);
   delete v;
 }
 
@@ -1726,8 +1756,81 @@ int ra_voice_events(ra_voice *v, const ra_voice_event *ev, int64_t n) {
   return RA_OK;
 }
 
+// the block with one note per lane: the events' bookkeeping here, the notes' samples on the device
+static int voice_block_notes(ra_voice *v, int64_t n, float *d_out) {
+  const int S = v->n_streams, P = v->p.P;
+  const int64_t t0 = v->t, t1 = v->t + n, K = v->k_done2;
+  for (int s = 0; s < S; ++s) {
+    auto &q = v->pending[s];
+    ra_voice::Chan *ch = v->chans.data() + (size_t)s * P;
+    while (!q.empty() && q.front().sample < t1) {
+      const RaVoiceEv e = q.front();
+      q.pop_front();
+      const int64_t te = std::max(e.sample, t0); // (events are not accepted before the frames already processed)
+      if (e.type == 0) { // onEvent(NoteOn): the first channel whose engine is finished (gen.crtp.h:397-405, soundengine.h:291-308)
+        int sel = -1;
+        for (int c = 0; c < P; ++c) if (!ch[c].odd && !ch[c].lost) { sel = c; break; }
+        if (sel < 0) { ++v->dropped_host; continue; }
+        ch[sel].odd = true; ch[sel].noteid = e.noteid; ch[sel].t_on = te;
+        ch[sel].live = (int)v->live.size();
+        v->live.push_back({s, sel, te, e.noteid, 0, K, e.vel});
+      } else { // NoteOff: the first channel that last played this note id; it reacts only while its note is on (gen.crtp.h:541-588)
+        int sel = -1;
+        for (int c = 0; c < P; ++c) if (ch[c].noteid == e.noteid) { sel = c; break; }
+        if (sel < 0 || !ch[sel].odd) continue;
+        const int64_t k = te - ch[sel].t_on; // steps the element took
+        ch[sel].odd = false;
+        if (k >= 1 && k < K) ch[sel].lost = true; // the ramp is left unfinished: isEnvelopeFinished_internal stays false (soundengine.h:457-467)
+        if (ch[sel].live >= 0) { ra_voice::Live &l = v->live[ch[sel].live]; l.limit = std::min(l.limit, k); }
+        ch[sel].live = -1;
+      }
+    }
+  }
+  std::vector<RaVoiceNoteHost> desc;
+  std::vector<ra_voice::Live> keep;
+  for (auto &l : v->live) {
+    const int64_t upto = std::min(l.limit, t1 - l.t_on); // steps taken by the end of this block
+    const int64_t steps = upto - l.done;
+    if (steps > 0) {
+      const bool goes_on = upto < l.limit;
+      desc.push_back({l.t_on + l.done, l.noteid, l.stream, l.stream * P + l.chan, (int32_t)steps, l.done == 0 ? 1 : 0, l.vel, goes_on ? 1 : 0});
+      l.done = upto;
+    }
+    ra_voice::Chan &c = v->chans[(size_t)l.stream * P + l.chan];
+    const bool mine = c.odd && c.t_on == l.t_on && c.noteid == l.noteid; // the channel's note that is on is this one
+    if (l.done < l.limit) { if (mine) c.live = (int)keep.size(); keep.push_back(l); }
+    else if (mine) c.live = -1; // rendered to its end; the channel stays taken until the note-off
+  }
+  v->live.swap(keep);
+  if ((int64_t)desc.size() > v->notes_cap) {
+    (void)hipFree(v->notes_dev);
+    v->notes_dev = nullptr;
+    v->notes_cap = std::max<int64_t>(1024, 2 * (int64_t)desc.size());
+    HIP_TRY(hipMalloc(&v->notes_dev, sizeof(RaVoiceNoteHost) * v->notes_cap));
+  }
+  if (n > v->accum_cap) {
+    (void)hipFree(v->accum);
+    v->accum = nullptr;
+    v->accum_cap = n;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&v->accum), sizeof(double) * 2 * (size_t)S * n));
+    HIP_TRY(hipMemset(v->accum, 0, sizeof(double) * 2 * (size_t)S * n));
+  }
+  if (!desc.empty()) HIP_TRY(hipMemcpy(v->notes_dev, desc.data(), sizeof(RaVoiceNoteHost) * desc.size(), hipMemcpyHostToDevice));
+  {
+    char *base = static_cast<char *>(v->note_slots);
+    const size_t set = ra_voice_state_bytes() * (size_t)S * P;
+    ra_voice_launch_notes(v->p, base + (v->slot_parity ? set : 0), base + (v->slot_parity ? 0 : set), v->notes_dev, (int)desc.size(), S, t0, n, v->accum, d_out, nullptr);
+    v->slot_parity ^= 1;
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  v->t += n;
+  return RA_OK;
+}
+
 static int voice_block(ra_voice *v, int64_t n, float *d_out) { // stages the block's events and runs it into d_out (device)
   HIP_TRY(hipSetDevice(v->device));
+  if (!v->serial) return voice_block_notes(v, n, d_out);
   const int S = v->n_streams;
   std::vector<RaVoiceEv> flat;
   std::vector<int32_t> begin(S + 1, 0);
@@ -1778,6 +1881,7 @@ int ra_voice_process_host(ra_voice *v, int64_t n, float *h_out) {
 
 int64_t ra_voice_dropped_note_ons(ra_voice *v) {
   if (!v) return fail(RA_EINVAL, "null context");
+  if (!v->serial) return v->dropped_host;
   HIP_TRY(hipSetDevice(v->device));
   std::vector<int32_t> d(v->n_streams);
   HIP_TRY(hipMemcpy(d.data(), v->dropped, sizeof(int32_t) * d.size(), hipMemcpyDeviceToHost));

@@ -285,6 +285,10 @@ struct RaVoiceParams {
 struct RaVoiceEv { int64_t sample, noteid; int32_t type, pad; float freq, vel; };
 size_t ra_voice_state_bytes();
 void ra_voice_launch_init(void *state, int count, hipStream_t st);
+size_t ra_voice_note_bytes();
+int ra_voice_probe_done2(const RaVoiceParams &p, int *d_scratch); // steps until the ramp's envelope is finished (-1: error)
+void ra_voice_launch_notes(const RaVoiceParams &p, const void *slots_in, void *slots_out, const void *notes, int n_notes, int n_streams, int64_t t0, int64_t n, double *accum, float *d_out,
+                           hipStream_t st);
 void ra_voice_launch(const RaVoiceParams &p, void *state, const RaVoiceEv *ev, const int32_t *ev_begin, int32_t *dropped, int n_streams, int64_t t0, int64_t n,
                      float *d_out, hipStream_t st);
 

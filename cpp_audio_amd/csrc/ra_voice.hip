@@ -77,6 +77,68 @@ __device__ inline void one_pole_volume(int &has, double &vol, double target, dou
   vol = y;
 }
 
+// One step of a sounding element (ImplCRTP::compute, gen.crtp.h:352-371, for one channel): SoundEngine::step, the outer volume, imag.
+__device__ inline void voice_step(VoiceChan &v, const RaVoiceParams &p, const RaEnvParams &ep, double &vL, double &vR) {
+ // ImplCRTP::compute, gen.crtp.h:352-371
+  // ---- SoundEngine::step: orchestrate_algos (soundengine.h:741-773) ----
+  if (v.spec_it != v.spec_end) {
+    const bool has_cur = v.spec_it >= 0 && v.spec_it < v.spec_end; // (silenceAfter is true for a SWEEP spec)
+    bool play = true;
+    if (v.c.state == ENV_PRESSED) {
+      const int remaining = v.c.reldelay; // countStepsToRelease
+      if (remaining > 0) play = false;
+      else if (remaining == 0 && has_cur) v.remaining_silence = 0; // articulative_pause_length: never set in SWEEP mode, taken as 0
+    }
+    if (play && has_cur && v.remaining_silence > 0) { --v.remaining_silence; play = false; }
+    if (play && (v.oddOn & 1)) { // playNextSpec :775-801: a finished ramp exists (two of the three never play)
+      ++v.spec_it;
+      if (v.spec_it != v.spec_end) {
+        v.lr_from = v.sp_from; v.lr_to = v.sp_to; v.lr_dur = v.sp_dur; v.lr_cur = v.sp_cur; v.lr_C = v.sp_C;
+        chan_forget_past_signals(v.c); v.l_has = 0;     // new_ramp->forgetPastSignals()
+        { double sn, cs; sincos(M_PI * v.start_angle, &sn, &cs); v.c.cre = cs; v.c.cim = sn; } // setStartAngle
+        v.c.target = (double)1.f;                       // spec volume (setVolume never called in SWEEP: 1.f)
+        v.c.state = ENV_SOON;                           // tryAcquire
+        const int time_to_release = (int)(.5f + v.lr_dur) - p.xfade_len;
+        env_on_key_pressed(v.c, 0);
+        env_on_key_released(v.c, max(time_to_release, 0));
+      }
+    }
+  }
+  // ---- step_algos (:423-436): the ramp steps unless it is finished ----
+  if (v.c.state != ENV_DONE2) {
+    env_step(v.c, ep);
+    double inc;
+    { // LogRamp::do_step, audioelement.h:2522-2542
+      if (v.lr_cur + (double).5f > v.lr_dur) { v.lr_cur = 0; const double tmp = v.lr_from; v.lr_from = v.lr_to; v.lr_to = tmp; }
+      inc = v.lr_from + (v.lr_to - v.lr_from) * (v.lr_cur / v.lr_dur);
+      const double f = v.lr_from + (v.lr_to - v.lr_from) * (v.lr_cur + (double).5f) / v.lr_dur;
+      v.lr_cur += v.lr_C * f;
+    }
+    // Mix::setAngleIncrements -> LoudnessVolumeAdjusted::setAngleIncrements (:1291-1298) -> SineOscillatorAlgo::setAngleIncrements
+    v.l_target = (double)loudness_volume(p, (float)(inc * 0.5 * (double)p.sample_rate));
+    osc_set_inc(v.c, inc);
+    { // SineOscillatorAlgo::step
+      const double re = v.c.cre * v.c.mre - v.c.cim * v.c.mim, im = v.c.cre * v.c.mim + v.c.cim * v.c.mre;
+      const double g = 0.5 * (3.0 - (re * re + im * im));
+      v.c.cre = re * g; v.c.cim = im * g;
+    }
+    one_pole_volume(v.l_has, v.l_vol, v.l_target, v.l_finit, v.l_k, v.l_y, fabs(v.c.inc));
+    int has = (v.c.flags & FL_HAS_VOL) ? 1 : 0;
+    one_pole_volume(has, v.c.vol, v.c.target, v.c.finit, v.c.k, v.c.y, fabs(ramp_angle_increments(p, v)));
+    v.c.flags |= FL_HAS_VOL;
+  }
+  // ---- the outer BaseVolumeAdjusted::step: SoundEngine::angleIncrements (:407-421) is the sounding ramp's, else 0 ----
+  const bool sounding = v.c.state == ENV_RELEASED || v.c.state == ENV_PRESSED;
+  one_pole_volume(v.o_has, v.o_vol, v.o_target, v.o_finit, v.o_k, v.o_y, sounding ? fabs(ramp_angle_increments(p, v)) : 0.0);
+  if (elem_rt_active(v) && sounding) {
+    double sum = 0.f;                                             // Mix::imag :1867-1873
+    sum += (double)p.sine_gain * (v.l_vol * (v.c.alias * v.c.cim));
+    const double mono = v.c.vol * (sum * v.c.value);             // ramp: VolumeAdjusted over Enveloped
+    vL = v.o_vol * (0.0 + v.c.gL * mono);                        // SoundEngine::imag(i): v{} += r.imag(i); BaseVolumeAdjusted::imag(i)
+    vR = v.o_vol * (0.0 + v.c.gR * mono);
+  }
+      }
+
 constexpr int VT = 16;
 
 __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_voice_kernel(RaVoiceParams p, VoiceChan *__restrict__ state, const RaVoiceEv *__restrict__ ev,
@@ -151,65 +213,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_voice_kernel(RaVoiceParams
     double *mine = tile + (size_t)l * (2 * VT + 1);
     for (int i = 0; i < m; ++i) {
       double vL = 0.0, vR = 0.0;
-      if (l < P && elem_rt_active(v)) { // ImplCRTP::compute, gen.crtp.h:352-371
-        // ---- SoundEngine::step: orchestrate_algos (soundengine.h:741-773) ----
-        if (v.spec_it != v.spec_end) {
-          const bool has_cur = v.spec_it >= 0 && v.spec_it < v.spec_end; // (silenceAfter is true for a SWEEP spec)
-          bool play = true;
-          if (v.c.state == ENV_PRESSED) {
-            const int remaining = v.c.reldelay; // countStepsToRelease
-            if (remaining > 0) play = false;
-            else if (remaining == 0 && has_cur) v.remaining_silence = 0; // articulative_pause_length: never set in SWEEP mode, taken as 0
-          }
-          if (play && has_cur && v.remaining_silence > 0) { --v.remaining_silence; play = false; }
-          if (play && (v.oddOn & 1)) { // playNextSpec :775-801: a finished ramp exists (two of the three never play)
-            ++v.spec_it;
-            if (v.spec_it != v.spec_end) {
-              v.lr_from = v.sp_from; v.lr_to = v.sp_to; v.lr_dur = v.sp_dur; v.lr_cur = v.sp_cur; v.lr_C = v.sp_C;
-              chan_forget_past_signals(v.c); v.l_has = 0;     // new_ramp->forgetPastSignals()
-              { double sn, cs; sincos(M_PI * v.start_angle, &sn, &cs); v.c.cre = cs; v.c.cim = sn; } // setStartAngle
-              v.c.target = (double)1.f;                       // spec volume (setVolume never called in SWEEP: 1.f)
-              v.c.state = ENV_SOON;                           // tryAcquire
-              const int time_to_release = (int)(.5f + v.lr_dur) - p.xfade_len;
-              env_on_key_pressed(v.c, 0);
-              env_on_key_released(v.c, max(time_to_release, 0));
-            }
-          }
-        }
-        // ---- step_algos (:423-436): the ramp steps unless it is finished ----
-        if (v.c.state != ENV_DONE2) {
-          env_step(v.c, ep);
-          double inc;
-          { // LogRamp::do_step, audioelement.h:2522-2542
-            if (v.lr_cur + (double).5f > v.lr_dur) { v.lr_cur = 0; const double tmp = v.lr_from; v.lr_from = v.lr_to; v.lr_to = tmp; }
-            inc = v.lr_from + (v.lr_to - v.lr_from) * (v.lr_cur / v.lr_dur);
-            const double f = v.lr_from + (v.lr_to - v.lr_from) * (v.lr_cur + (double).5f) / v.lr_dur;
-            v.lr_cur += v.lr_C * f;
-          }
-          // Mix::setAngleIncrements -> LoudnessVolumeAdjusted::setAngleIncrements (:1291-1298) -> SineOscillatorAlgo::setAngleIncrements
-          v.l_target = (double)loudness_volume(p, (float)(inc * 0.5 * (double)p.sample_rate));
-          osc_set_inc(v.c, inc);
-          { // SineOscillatorAlgo::step
-            const double re = v.c.cre * v.c.mre - v.c.cim * v.c.mim, im = v.c.cre * v.c.mim + v.c.cim * v.c.mre;
-            const double g = 0.5 * (3.0 - (re * re + im * im));
-            v.c.cre = re * g; v.c.cim = im * g;
-          }
-          one_pole_volume(v.l_has, v.l_vol, v.l_target, v.l_finit, v.l_k, v.l_y, fabs(v.c.inc));
-          int has = (v.c.flags & FL_HAS_VOL) ? 1 : 0;
-          one_pole_volume(has, v.c.vol, v.c.target, v.c.finit, v.c.k, v.c.y, fabs(ramp_angle_increments(p, v)));
-          v.c.flags |= FL_HAS_VOL;
-        }
-        // ---- the outer BaseVolumeAdjusted::step: SoundEngine::angleIncrements (:407-421) is the sounding ramp's, else 0 ----
-        const bool sounding = v.c.state == ENV_RELEASED || v.c.state == ENV_PRESSED;
-        one_pole_volume(v.o_has, v.o_vol, v.o_target, v.o_finit, v.o_k, v.o_y, sounding ? fabs(ramp_angle_increments(p, v)) : 0.0);
-        if (elem_rt_active(v) && sounding) {
-          double sum = 0.f;                                             // Mix::imag :1867-1873
-          sum += (double)p.sine_gain * (v.l_vol * (v.c.alias * v.c.cim));
-          const double mono = v.c.vol * (sum * v.c.value);             // ramp: VolumeAdjusted over Enveloped
-          vL = v.o_vol * (0.0 + v.c.gL * mono);                        // SoundEngine::imag(i): v{} += r.imag(i); BaseVolumeAdjusted::imag(i)
-          vR = v.o_vol * (0.0 + v.c.gR * mono);
-        }
-      }
+      if (l < P && elem_rt_active(v)) voice_step(v, p, ep, vL, vR);
       mine[i] = vL; mine[VT + i] = vR;
     }
     __syncthreads();
@@ -236,6 +240,78 @@ __global__ void ra_voice_init_kernel(VoiceChan *state, int count) {
   state[i] = v;
 }
 
+
+// ---- one note per lane -------------------------------------------------------------------------------------------------
+// A channel's state is made afresh by its note-on and the first step after it (forgetPastSignals, playNextSpec): a note's samples depend
+// on nothing but the note.  Which channel a note-on gets — or that it is dropped — is integer bookkeeping (a channel is free again iff
+// its note-off came after the ramp's envelope had finished, else it is lost for good), walked on the host (ra_capi.hip); here every
+// note of the block is stepped by a lane of its own, from its stored state if it began in an earlier block, and added into a double
+// accumulation buffer that a second kernel rounds to the float output.  The sum over a frame's notes is an atomic one: its association
+// is not the channel order of the serial kernel (1e-16 relative, a float ulp now and then).
+struct RaVoiceNote { int64_t begin; int64_t noteid; int32_t stream, slot, steps, fresh; float vel; int32_t store; }; // = ra_capi.hip: RaVoiceNoteHost
+
+__global__ void ra_voice_notes_kernel(RaVoiceParams p, const VoiceChan *__restrict__ slots_in, VoiceChan *__restrict__ slots_out, const RaVoiceNote *__restrict__ notes,
+                                      int n_notes, int64_t t0, int64_t n, double *__restrict__ accum) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool have = i < n_notes;
+  RaVoiceNote q;
+  if (have) q = notes[i]; else { q.steps = 0; q.slot = 0; q.fresh = 1; q.begin = t0; q.stream = 0; q.noteid = 0; q.vel = 0; q.store = 0; }
+  const RaEnvParams ep = {p.envA, 0, 0, p.envR, 0.f};
+  VoiceChan v;
+  if (have && !q.fresh) v = slots_in[q.slot]; // (written by the previous block: the two sets alternate, so a successor on the same channel cannot overwrite it)
+  else { // a free channel, then onEvent(NoteOn) and its one-shot exactly as in the serial kernel
+    memset(&v, 0, sizeof(v));
+    chan_init(v.c);
+    ++v.oddOn;
+    v.noteid = q.noteid;
+    v.remaining_silence = 0; v.start_angle = 0; v.o_has = 0;
+    v.o_target = p.base_volume * (double)q.vel;
+    {
+      const float pan_f = p.random_pan ? hash_uniform_pm1(p.seed + (uint64_t)q.stream, (uint64_t)q.noteid, 3) : p.pan;
+      double pan = (double)pan_f;
+      pan = fmin(pan, 1.); pan = fmax(pan, -1.);
+      const double ang = (0.25 * M_PI) * (pan + 1.);
+      v.c.gL = cos(ang); v.c.gR = sin(ang);
+    }
+    v.spec_it = -1; v.spec_end = 1;
+    v.sp_from = p.inc_low; v.sp_to = p.inc_high; v.sp_dur = p.n_frames; v.sp_cur = p.start_sample;
+    v.sp_C = (v.sp_to == v.sp_from) ? (double)1.f : -log(v.sp_from / v.sp_to) / (v.sp_to - v.sp_from);
+    v.start_angle = 0;
+    v.rt_active = 1;
+  }
+  double *o = accum + ((size_t)q.stream * n + (size_t)(q.begin - t0)) * 2;
+  for (int k = 0; k < q.steps; ++k) {
+    double vL = 0.0, vR = 0.0;
+    voice_step(v, p, ep, vL, vR);
+    if (vL != 0.0) atomicAdd(o + 2 * (size_t)k, vL);
+    if (vR != 0.0) atomicAdd(o + 2 * (size_t)k + 1, vR);
+  }
+  if (have && q.store) slots_out[q.slot] = v; // (at most one note per channel goes on into the next block)
+}
+
+// the float cast of SimpleAudioOutContext::step, and the buffer is zero again for the next block
+__global__ void ra_voice_cast_kernel(double *__restrict__ accum, float *__restrict__ out, size_t count) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    out[i] = (float)accum[i];
+    accum[i] = 0.0;
+  }
+}
+
+// steps of the ramp's envelope from the note's first step until it is finished (EnvelopeDone2): what decides whether a channel is free again
+__global__ void ra_voice_probe_kernel(RaVoiceParams p, int *out) {
+  const RaEnvParams ep = {p.envA, 0, 0, p.envR, 0.f};
+  Chan c;
+  chan_init(c);
+  chan_forget_past_signals(c);
+  c.state = ENV_SOON;
+  const int time_to_release = (int)(.5f + p.n_frames) - p.xfade_len;
+  env_on_key_pressed(c, 0);
+  env_on_key_released(c, max(time_to_release, 0));
+  int k = 0;
+  while (c.state != ENV_DONE2 && k < (1 << 30)) { env_step(c, ep); ++k; }
+  *out = k;
+}
+
 } // namespace
 
 size_t ra_voice_state_bytes() { return sizeof(VoiceChan); }
@@ -249,3 +325,21 @@ void ra_voice_launch(const RaVoiceParams &p, void *state, const RaVoiceEv *ev, c
   const size_t lds = (size_t)Ppad * (2 * VT + 1) * sizeof(double) + 16;
   hipLaunchKernelGGL(ra_voice_kernel, dim3((unsigned)n_streams), dim3((unsigned)Ppad), lds, st, p, static_cast<VoiceChan *>(state), ev, ev_begin, dropped, t0, n, d_out);
 }
+
+size_t ra_voice_note_bytes() { return sizeof(RaVoiceNote); }
+int ra_voice_probe_done2(const RaVoiceParams &p, int *d_scratch) {
+  hipLaunchKernelGGL(ra_voice_probe_kernel, dim3(1), dim3(1), 0, nullptr, p, d_scratch);
+  int k = -1;
+  if (hipMemcpy(&k, d_scratch, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return k;
+}
+void ra_voice_launch_notes(const RaVoiceParams &p, const void *slots_in, void *slots_out, const void *notes, int n_notes, int n_streams, int64_t t0, int64_t n, double *accum, float *d_out,
+                           hipStream_t st) {
+  if (n <= 0) return;
+  if (n_notes > 0)
+    hipLaunchKernelGGL(ra_voice_notes_kernel, dim3((unsigned)((n_notes + 63) / 64)), dim3(64), 0, st, p, static_cast<const VoiceChan *>(slots_in),
+                       static_cast<VoiceChan *>(slots_out), static_cast<const RaVoiceNote *>(notes), n_notes, t0, n, accum);
+  const size_t count = (size_t)n_streams * (size_t)n * 2;
+  hipLaunchKernelGGL(ra_voice_cast_kernel, dim3((unsigned)std::min<size_t>((count + 255) / 256, 65536)), dim3(256), 0, st, accum, d_out, count);
+}
+

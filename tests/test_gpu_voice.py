@@ -86,6 +86,38 @@ def test_voice_output_resident_in_hbm_equals_host_output(api):
     assert np.any(host != 0) and np.array_equal(out.cpu().numpy(), host)
 
 
+def test_one_note_per_lane_equals_the_sample_serial_kernel(api, monkeypatch):
+    # the default renders every note of a block in a lane of its own and walks the channel bookkeeping on the host; RA_VOICE_SERIAL=1 (read
+    # when the object is created) keeps the one-wave-per-synth kernel.  Same samples (the sum over a frame's notes associates differently),
+    # same dropped note-ons — with three channels, early releases (lost channels) and long notes that span blocks.
+    rng = np.random.default_rng(17)
+    S, n = 4, 90000
+    rows, nid = [], 0
+    for s in range(S):
+        t = 0
+        for _ in range(30):
+            t += int(rng.integers(100, 4000))
+            nid += 1
+            rows.append((t, s, 0, nid, 440.0, float(rng.uniform(0.2, 1.0))))
+            rows.append((t + int(rng.integers(1, 30000)), s, 1, nid, 0.0, 0.0))
+    rows.sort(key=lambda r: (r[1], r[0]))
+    cfg = api.voice_default_config(seed=3, random_pan=1, n_channels=3, length_exponent=1.5)
+    res = []
+    for serial in (False, True):
+        if serial:
+            monkeypatch.setenv("RA_VOICE_SERIAL", "1")
+        else:
+            monkeypatch.delenv("RA_VOICE_SERIAL", raising=False)
+        with api.Voice(cfg, S, 0) as v:
+            v.events(rows)
+            out = np.concatenate([v.process(m) for m in (5, 20000, 1, 30000, n - 50006)], axis=1)
+            res.append((out.astype(np.float64), v.dropped_note_ons()))
+    monkeypatch.delenv("RA_VOICE_SERIAL", raising=False)
+    assert np.sqrt(np.mean(res[1][0] ** 2)) > 1e-3 and res[1][1] > 0
+    assert res[0][1] == res[1][1]
+    assert np.max(np.abs(res[0][0] - res[1][0])) < 2e-7
+
+
 def test_voice_argument_errors(api):
     for kw in (dict(n_channels=0), dict(low_freq=0.0), dict(length_ms=0.0), dict(loudness_ref_freq_index=16), dict(length_ms=10.0, length_exponent=0.0, xfade_length_seconds=0.04)):
         with pytest.raises(api.RaError) as e:
