@@ -202,8 +202,8 @@ __device__ inline void regime_setup(Chan &c, const SynConst &k, double inv_dur, 
 #endif
 constexpr int TD = RA_TILE_DEPTH; // tile depth of the regime renderer
 static_assert(TD == 8 || TD == 16, "tile depth");
-constexpr int TROW = 2 * TD + 1; // its LDS tile is lane-major: [Ppad][TROW] doubles, entry out * TD + frame (odd row length: conflict-free both ways)
-constexpr int TROW_MONO = TD + 1; // stereo_spread 0: every channel has the same two gains, applied after the channel sum
+constexpr int TROW_MONO = TD + 1; // the LDS tile is lane-major: [Ppad][TROW_MONO] doubles, one value per frame (odd row length: conflict-free both ways)
+constexpr int TSTEREO_EXTRA = 2;   // stereo: behind a workgroup's tile, the channels' two gains [Ppad] double2 (in doubles per channel)
 
 // LEN steps (a whole tile, or half of one) of a lane whose wave has no transition inside them: straight-line code, no state machine.
 // GLIDE: some lane of the wave glides (the others run the same code with the identity rotation, alpha = 1, beta = 0);
@@ -261,7 +261,7 @@ __device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, dou
     if (HI) d1 += d2;
     return y * (cim * va);
   };
-  auto put = [&](int i, double v) { if (MONO) mine[i] = v; else { mine[i] = c.gL * v; mine[TD + i] = c.gR * v; } };
+  auto put = [&](int i, double v) { mine[i] = v; }; // (stereo: the gains are applied in the channel sum)
   if (RA_ABL & 1) return;
   put(0, step(std::true_type{}));
   if (LEN) {
@@ -295,12 +295,16 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
   Regime r;
   regime_setup(c, k, inv_dur, r);
   clk.mark(21);
-  constexpr int ROW = MONO ? TROW_MONO : TROW;
+  constexpr int ROW = TROW_MONO;
   double *mine = tile + l * ROW;                                                // this lane's row
+  // stereo: every channel has its own two gains (StereoPanned, stereo.h:18-27); the lanes that sum a frame read them from LDS, so the tile
+  // holds one value per frame and channel as in the mono kernel (half the LDS of a tile of gL v, gR v pairs: three waves per SIMD)
+  double2 *gains = reinterpret_cast<double2 *>(tile + (size_t)Ppad * ROW);
+  if (!MONO) gains[l] = make_double2(c.gL, c.gR);
   // reduction role of lanes 0..63: frame fr of output ch over a quarter of the channels (MONO: frame fr over an eighth)
   // the 64 reducing lanes: output value o (frame fr of channel ch; entries of a row are laid out [ch][fr]) over one of NPART channel groups
-  constexpr int NOUT = MONO ? TD : 2 * TD, NPART = 64 / NOUT;
-  const int o = l & (NOUT - 1), fr = o & (TD - 1), ch = o / TD, part = (l & 63) / NOUT;
+  constexpr int NOUT = TD, NPART = 64 / NOUT;
+  const int o = l & (NOUT - 1), fr = o & (TD - 1), part = (l & 63) / NOUT;
   const double *col = tile + (part * (Ppad / NPART)) * ROW + o;
   double gLm = 0.0, gRm = 0.0;
   if (MONO) { const double ang = (0.25 * M_PI) * (0.0 + 1.); gLm = cos(ang); gRm = sin(ang); } // stereo(0), stereo.h:18-27, as at note-on
@@ -408,7 +412,7 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
       }
       r.pending += LEN; r.steps_left -= LEN;
     } else {
-      for (int i = 0; i < LEN; ++i) { row[i] = 0.0; if (!MONO) row[TD + i] = 0.0; }
+      for (int i = 0; i < LEN; ++i) row[i] = 0.0;
     }
     clk.lap<0>();
     return true;
@@ -448,49 +452,46 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
         else v = checked_step();
       }
       stepped0 = false;
-      if (MONO) mine[pos] = v; else { mine[pos] = c.gL * v; mine[TD + pos] = c.gR * v; }
+      mine[pos] = v;
       ++pos;
       clk.lap<1>();
     }
     if (Ppad > 64) __syncthreads(); // one wave: its LDS operations execute in order, no barrier needed
     if (l < 64 && !(RA_ABL & 2)) { // NOUT outputs x NPART channel groups
-      double acc = 0.0;
+      double acc = 0.0, accR = 0.0; // mono: the sum; stereo: left and right
       if (fr < m) {
         const double *q = col;
         constexpr int NJ = 64 / NPART; // channels of a group per 64-channel block
-        for (int blk = 0; blk < (Ppad >> 6); ++blk, q += NJ * ROW) {
+        const double2 *g = gains + part * (Ppad / NPART);
+        for (int blk = 0; blk < (Ppad >> 6); ++blk, q += NJ * ROW, g += NJ) {
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) acc += q[j * ROW];
+          for (int j = 0; j < NJ; ++j) {
+            if (MONO) acc += q[j * ROW];
+            else { const double v = q[j * ROW]; const double2 gg = g[j]; acc += gg.x * v; accR += gg.y * v; }
+          }
         }
       }
       if (!packed) acc += lane_xor32_low(acc);
       if (NPART >= 4) acc += lane_xor16_even(acc);
       if (NPART >= 8) acc += lane_ror8(acc);
+      if (!MONO) {
+        if (!packed) accR += lane_xor32_low(accR);
+        if (NPART >= 4) accR += lane_xor16_even(accR);
+        if (NPART >= 8) accR += lane_ror8(accR);
+      }
       const int lo_lane = packed ? (l & 31) : l; // packed: lanes 32.. hold the second hop's frames (even rows of 16: where the swaps are valid)
       const int64_t t_mine = (packed && l >= 32) ? t + dB : t;
-      if (MONO) {
-        if (lo_lane < NOUT && fr < m) {
-          const int64_t rel = (t_mine - t0) + fr;
-          double oL = gLm * acc, oR = gRm * acc;
-          if (mix) { oL += mix[rel]; oR += mix[rel]; }
-          if (out) { // one 8-byte store per frame when the caller's buffer allows it (two 4-byte stores make partial-line writes)
-            float *op = out + ((size_t)s * n + rel) * 2;
-            if ((reinterpret_cast<uintptr_t>(out) & 7) == 0) *reinterpret_cast<float2 *>(op) = make_float2((float)oL, (float)oR);
-            else { op[0] = (float)oL; op[1] = (float)oR; }
-          }
-          if (out_d) { out_d[((size_t)s * n + rel) * 2] = oL; out_d[((size_t)s * n + rel) * 2 + 1] = oR; }
-          if (fb_mono) fb_mono[rel] = (float)(oL + oR); // what the post processor publishes to the analysis (lib.cpp:1262-1272, pubsub.cpp:92)
-        }
-      } else {
-        const bool w = lo_lane < NOUT && fr < m;
+      if (lo_lane < NOUT && fr < m) {
         const int64_t rel = (t_mine - t0) + fr;
-        if (w && mix) acc += mix[rel];
-        const double other = (TD == 8) ? lane_ror8(acc) : lane_xor16_even(acc); // the other output channel of the same frame (lane +- TD)
-        if (w) {
-          if (out) out[((size_t)s * n + rel) * 2 + ch] = (float)acc;
-          if (out_d) out_d[((size_t)s * n + rel) * 2 + ch] = acc;
-          if (fb_mono && ch == 0) fb_mono[rel] = (float)(acc + other);
+        double oL = MONO ? gLm * acc : acc, oR = MONO ? gRm * acc : accR;
+        if (mix) { oL += mix[rel]; oR += mix[rel]; }
+        if (out) { // one 8-byte store per frame when the caller's buffer allows it (two 4-byte stores make partial-line writes)
+          float *op = out + ((size_t)s * n + rel) * 2;
+          if ((reinterpret_cast<uintptr_t>(out) & 7) == 0) *reinterpret_cast<float2 *>(op) = make_float2((float)oL, (float)oR);
+          else { op[0] = (float)oL; op[1] = (float)oR; }
         }
+        if (out_d) { out_d[((size_t)s * n + rel) * 2] = oL; out_d[((size_t)s * n + rel) * 2 + 1] = oR; }
+        if (fb_mono) fb_mono[rel] = (float)(oL + oR); // what the post processor publishes to the analysis (lib.cpp:1262-1272, pubsub.cpp:92)
       }
     }
     if (Ppad > 64) __syncthreads();
@@ -692,7 +693,7 @@ __device__ inline void render_pair(const RaParams &p, const RaBuffers &b, const 
   const unsigned long long wg_t0 = clk.t;
   const SynConst k = syn_const(p, s);
   const double *mix = (p.voc_enabled && b.voc_mix) ? b.voc_mix + (size_t)s * sp.n : nullptr;
-  double *tile = reinterpret_cast<double *>(ra_smem_syn) + (size_t)wy * Ppad * (MONO ? TROW_MONO : TROW);
+  double *tile = reinterpret_cast<double *>(ra_smem_syn) + (size_t)wy * Ppad * (TROW_MONO + (MONO ? 0 : TSTEREO_EXTRA));
   float *fb_mono = (b.fb_block && !p.post_limit) ? b.fb_block + (size_t)s * sp.n : nullptr; // with post "limit" the limiter publishes
 
   // sounding channels of both hops: every wave looks at all of them (Ppad / 64 state words per lane and hop), so the decision needs no barrier
@@ -783,12 +784,11 @@ void ra_launch_synth_render(const RaParams &p, const RaBuffers &b, const RaSpan 
   // hops per workgroup (single-wave streams).  The chip starts ~16 M workgroups per second: with packed pairs half of the one-wave workgroups
   // leave at once and the 17 k workgroups of a chunk took longer to start than to run.  Two hops per workgroup, measured on configs[1] with
   // packing: render alone 9.2 -> 8.3 ms, step 14.9 -> 13.7 ms; four: 16.3 ms (a four-wave workgroup wants a slot on every SIMD at once).
-  // The stereo kernel's tile is twice the size: two of them per workgroup leave room for 8 waves per CU only (19.0 -> 20.2 ms): one hop there.
   static const int group_env = std::getenv("RA_RENDER_GROUP") ? std::atoi(std::getenv("RA_RENDER_GROUP")) : 0;
-  const int group_want = group_env > 0 ? group_env : (p.stereo_spread == 0.f ? 2 : 1);
+  const int group_want = group_env > 0 ? group_env : 2;
   const unsigned group = (p.Ppad == 64) ? (unsigned)std::min(std::max(group_want, 1), RA_MAX_CHANNELS / 64) : 1u; // hops per workgroup
   const dim3 grid((unsigned)((sp.nfb + 1 + group - 1) / group), (unsigned)p.n_streams), block((unsigned)p.Ppad, group);
-  const size_t lds = (size_t)group * p.Ppad * (p.stereo_spread == 0.f ? TROW_MONO : TROW) * sizeof(double); // the 8-frame tiles only
+  const size_t lds = (size_t)group * p.Ppad * (TROW_MONO + (p.stereo_spread == 0.f ? 0 : TSTEREO_EXTRA)) * sizeof(double); // the tiles (+ the gains)
   if (p.stereo_spread == 0.f) hipLaunchKernelGGL(ra_synth_render_mono_kernel, grid, block, lds, st, p, b, sp, d_out, d_out_d);
   else hipLaunchKernelGGL(ra_synth_render_kernel, grid, block, lds, st, p, b, sp, d_out, d_out_d);
 }
