@@ -121,6 +121,7 @@ def test_hop_parallel_vs_reference_order(api, sig):
     dict(stereo_spread=1.0),                                                                   # two sums per frame
     dict(stereo_spread=1.0, window_size=8192, stride=2048, n_channels=128, use_autotune=1),    # two waves per hop: the second leaves when packed
     dict(stereo_spread=0.0, n_channels=16, min_volume=0.002),                                  # few channels: every pair packs
+    dict(stereo_spread=0.7, n_channels=256, window_size=2048, stride=512),                     # four waves per hop, three of them leave when packed
 ])
 def test_packed_hop_pairs_equal_unpacked(api, sig, kw):
     # ra_synth.hip: render_pair renders two hops with <= 32 sounding channels each in the two halves of one wave; reference_order 4 turns
