@@ -16,6 +16,7 @@
 // and three one-pole updates with re-derived coefficients: ~300 instructions on one wave per stream — correct first, not yet fast.
 #include "ra_chan.cuh"
 #include <algorithm>
+#include <cstdlib>
 
 extern __shared__ __align__(16) unsigned char ra_smem_voice[];
 
@@ -24,7 +25,7 @@ namespace {
 struct VoiceChan {
   Chan c;   // the ramp: envelope, sine oscillator (cre, cim, mre, mim, alias, inc), its own volume filter (vol, target, finit, k, y, flags), gains
   // LogRamp (audioelement.h:2464-2572)
-  double lr_from, lr_to, lr_cur, lr_dur, lr_C;
+  double lr_from, lr_to, lr_cur, lr_dur, lr_C, lr_inv; // lr_inv = 1 / lr_dur
   // the loudness adjustment's BaseVolumeAdjusted
   double l_vol, l_target, l_finit, l_k, l_y;
   // the outer VolumeAdjusted<SoundEngine>
@@ -33,27 +34,29 @@ struct VoiceChan {
   double sp_from, sp_to, sp_dur, sp_cur, sp_C;
   double start_angle;
   int64_t noteid;
-  int oddOn, rt_active, spec_it, spec_end, remaining_silence, l_has, o_has, pad;
+  int oddOn, rt_active, spec_it, spec_end, remaining_silence, l_has, o_has, loud_k; // loud_k: the loudness table interval the sweep is in
 };
 
 __device__ inline bool ramp_rt_active(const VoiceChan &v) { return rt_active(v.c); }
 __device__ inline bool engine_finished(const VoiceChan &v) { return !(v.oddOn & 1) && !ramp_rt_active(v); } // isEnvelopeFinished_internal
 __device__ inline bool elem_rt_active(const VoiceChan &v) { return v.rt_active && !engine_finished(v); }
 
-// loudness::equal_loudness_volume_from_freq, include/loudness.h:246-274 over :157-186 (float arithmetic)
-__device__ inline float loudness_volume(const RaVoiceParams &p, float freq) {
-  int min_ = 0, max_ = 28;
-  do {
-    const int center = (min_ + max_) / 2;
-    if (freq < p.loud_freqs[center]) max_ = center; else min_ = center;
-  } while (max_ - min_ >= 2);
-  int k; float ratio;
-  if (freq <= p.loud_freqs[min_]) { k = min_; ratio = 1.f; }
-  else if (freq >= p.loud_freqs[max_]) { k = max_; ratio = 1.f; }
-  else { k = max_; ratio = (freq - p.loud_freqs[min_]) / (p.loud_freqs[max_] - p.loud_freqs[min_]); }
-  const float db = (ratio == 1.f) ? p.loud_elv[k] : ratio * p.loud_elv[k] + (1.f - ratio) * p.loud_elv[k - 1];
+// loudness::equal_loudness_volume_from_freq, include/loudness.h:246-274 over :157-186 (float arithmetic).  The reference finds the table
+// interval by bisection on every call; a sweep moves through the 29 frequencies in order, so the interval of the previous sample is
+// carried in `k` (freqs[k] <= freq < freqs[k + 1], clamped to 0 .. 27) and walked: the same interval, a step or two per note.  The final
+// powf(10, x) runs as exp2f(x log2 10): a float ulp or two from the reference's pow on a gain (tolerance 1e-5).
+__device__ inline float loudness_volume(const RaVoiceParams &p, const float *__restrict__ lf, const float *__restrict__ le, float freq, int &k) {
+  k = min(max(k, 0), 27);
+  while (k < 27 && freq >= lf[k + 1]) ++k;
+  while (k > 0 && freq < lf[k]) --k;
+  const int min_ = k, max_ = k + 1; // what the bisection of loudness.h:231-244 ends with
+  int kk; float ratio;
+  if (freq <= lf[min_]) { kk = min_; ratio = 1.f; }
+  else if (freq >= lf[max_]) { kk = max_; ratio = 1.f; }
+  else { kk = max_; ratio = (freq - lf[min_]) / (lf[max_] - lf[min_]); }
+  const float db = (ratio == 1.f) ? le[kk] : ratio * le[kk] + (1.f - ratio) * le[kk - 1];
   if (db > p.max_db) return 1.f;
-  return powf(10.f, p.log_ratio * (db - p.max_db) / 20.f);
+  return exp2f((p.log_ratio * (db - p.max_db) / 20.f) * 3.32192809488736f);
 }
 
 // FreqCtrl_::angleIncrements (audioelement.h:3117-3124) over Mix::angleIncrements (:1856-1865)
@@ -63,22 +66,49 @@ __device__ inline double ramp_angle_increments(const RaVoiceParams &p, const Voi
   if (minAngle != 0.) return minAngle;
   return v.lr_from;
 }
+__device__ inline double one_pole_k(double inc_abs) { // a / (1 + a), a = pi inc: v_rcp_f64 and two Newton steps instead of the IEEE division (an ulp)
+  const double a = M_PI * inc_abs, d = 1.0 + a;
+  double r = __builtin_amdgcn_rcp(d);
+  r = r * fma(-d, r, 2.0);
+  r = r * fma(-d, r, 2.0);
+  return a * r;
+}
 __device__ inline void one_pole_volume(int &has, double &vol, double target, double &finit, double &k, double &y, double inc_abs) { // BaseVolumeAdjusted::step :1195-1216
   if (!has) {
     finit = inc_abs;
-    const double a = M_PI * finit;
-    k = a / (1.0 + a);
+    k = one_pole_k(finit);
     y = target;
     has = 1;
   } else if (vol != target) {
-    if (finit != inc_abs) { finit = inc_abs; const double a = M_PI * finit; k = a / (1.0 + a); }
+    if (finit != inc_abs) { finit = inc_abs; k = one_pole_k(finit); }
   }
   y = y + k * (target - y);
   vol = y;
 }
 
+// SineOscillatorAlgo::setAngleIncrements (audioelement.h:2404-2411) on a sweep: the increment moves a little every sample, so the rotation
+// (cos, sin)(pi f) follows it by the small angle pi (f - f_prev) (fifth-order series, |d| ~ 1e-4: exact to rounding) instead of a sincos
+// per sample, and the anti-aliasing gain (:466-483) only divides where it is not 0 or 1.
+__device__ inline void voice_osc_set_inc(Chan &c, double f) {
+  if (c.inc == f) return;
+  const double d = M_PI * (f - c.inc);
+  if (c.inc != 0. && fabs(d) < 1e-2) {
+    const double d2 = d * d;
+    const double sd = d * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0), cd = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
+    const double mr = fma(c.mre, cd, -(c.mim * sd)), mi = fma(c.mre, sd, c.mim * cd);
+    c.mre = mr; c.mim = mi;
+  } else {
+    double sn, cs;
+    sincos(M_PI * f, &sn, &cs);
+    c.mre = cs; c.mim = sn;
+  }
+  c.inc = f;
+  c.alias = (f == 0.) ? 1. : (f > 1.) ? 0. : (f < 0.25 && f > 0.) ? 1. : alias_mult(f);
+}
+
 // One step of a sounding element (ImplCRTP::compute, gen.crtp.h:352-371, for one channel): SoundEngine::step, the outer volume, imag.
-__device__ inline void voice_step(VoiceChan &v, const RaVoiceParams &p, const RaEnvParams &ep, double &vL, double &vR) {
+__device__ inline void voice_step(VoiceChan &v, const RaVoiceParams &p, const float *__restrict__ lf, const float *__restrict__ le, const RaEnvParams &ep, double &vL,
+                                  double &vR) {
  // ImplCRTP::compute, gen.crtp.h:352-371
   // ---- SoundEngine::step: orchestrate_algos (soundengine.h:741-773) ----
   if (v.spec_it != v.spec_end) {
@@ -93,7 +123,7 @@ __device__ inline void voice_step(VoiceChan &v, const RaVoiceParams &p, const Ra
     if (play && (v.oddOn & 1)) { // playNextSpec :775-801: a finished ramp exists (two of the three never play)
       ++v.spec_it;
       if (v.spec_it != v.spec_end) {
-        v.lr_from = v.sp_from; v.lr_to = v.sp_to; v.lr_dur = v.sp_dur; v.lr_cur = v.sp_cur; v.lr_C = v.sp_C;
+        v.lr_from = v.sp_from; v.lr_to = v.sp_to; v.lr_dur = v.sp_dur; v.lr_cur = v.sp_cur; v.lr_C = v.sp_C; v.lr_inv = 1.0 / v.sp_dur;
         chan_forget_past_signals(v.c); v.l_has = 0;     // new_ramp->forgetPastSignals()
         { double sn, cs; sincos(M_PI * v.start_angle, &sn, &cs); v.c.cre = cs; v.c.cim = sn; } // setStartAngle
         v.c.target = (double)1.f;                       // spec volume (setVolume never called in SWEEP: 1.f)
@@ -110,13 +140,14 @@ __device__ inline void voice_step(VoiceChan &v, const RaVoiceParams &p, const Ra
     double inc;
     { // LogRamp::do_step, audioelement.h:2522-2542
       if (v.lr_cur + (double).5f > v.lr_dur) { v.lr_cur = 0; const double tmp = v.lr_from; v.lr_from = v.lr_to; v.lr_to = tmp; }
-      inc = v.lr_from + (v.lr_to - v.lr_from) * (v.lr_cur / v.lr_dur);
-      const double f = v.lr_from + (v.lr_to - v.lr_from) * (v.lr_cur + (double).5f) / v.lr_dur;
+      const double inv_dur = v.lr_inv; // the two divisions by the note's constant duration as multiplications (an ulp on the increment)
+      inc = v.lr_from + (v.lr_to - v.lr_from) * (v.lr_cur * inv_dur);
+      const double f = v.lr_from + (v.lr_to - v.lr_from) * ((v.lr_cur + (double).5f) * inv_dur);
       v.lr_cur += v.lr_C * f;
     }
     // Mix::setAngleIncrements -> LoudnessVolumeAdjusted::setAngleIncrements (:1291-1298) -> SineOscillatorAlgo::setAngleIncrements
-    v.l_target = (double)loudness_volume(p, (float)(inc * 0.5 * (double)p.sample_rate));
-    osc_set_inc(v.c, inc);
+    v.l_target = (double)loudness_volume(p, lf, le, (float)(inc * 0.5 * (double)p.sample_rate), v.loud_k);
+    voice_osc_set_inc(v.c, inc);
     { // SineOscillatorAlgo::step
       const double re = v.c.cre * v.c.mre - v.c.cim * v.c.mim, im = v.c.cre * v.c.mim + v.c.cim * v.c.mre;
       const double g = 0.5 * (3.0 - (re * re + im * im));
@@ -147,6 +178,9 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_voice_kernel(RaVoiceParams
   const int s = blockIdx.x, l = threadIdx.x, Ppad = blockDim.x, P = p.P;
   double *tile = reinterpret_cast<double *>(ra_smem_voice);       // [Ppad][2 * VT + 1]
   int *xi = reinterpret_cast<int *>(tile + (size_t)Ppad * (2 * VT + 1));
+  float *lf = reinterpret_cast<float *>(xi + 4), *le = lf + 29; // the loudness tables (a dynamically indexed kernel-argument array would live in scratch)
+  if (l < 29) { lf[l] = p.loud_freqs[l]; le[l] = p.loud_elv[l]; }
+  __syncthreads();
   VoiceChan v = state[(size_t)s * Ppad + l];
   const RaEnvParams ep = {p.envA, 0, 0, p.envR, 0.f}; // setAHDSR(AHDSR{xfade_len, LINEAR, 0, 0, LINEAR, xfade_len, LINEAR, 1.}), soundengine.h:790
   int e = ev_begin[s];
@@ -213,7 +247,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_voice_kernel(RaVoiceParams
     double *mine = tile + (size_t)l * (2 * VT + 1);
     for (int i = 0; i < m; ++i) {
       double vL = 0.0, vR = 0.0;
-      if (l < P && elem_rt_active(v)) voice_step(v, p, ep, vL, vR);
+      if (l < P && elem_rt_active(v)) voice_step(v, p, lf, le, ep, vL, vR);
       mine[i] = vL; mine[VT + i] = vR;
     }
     __syncthreads();
@@ -250,17 +284,20 @@ __global__ void ra_voice_init_kernel(VoiceChan *state, int count) {
 // is not the channel order of the serial kernel (1e-16 relative, a float ulp now and then).
 struct RaVoiceNote { int64_t begin; int64_t noteid; int32_t stream, slot, steps, fresh; float vel; int32_t store; }; // = ra_capi.hip: RaVoiceNoteHost
 
-__global__ void ra_voice_notes_kernel(RaVoiceParams p, const VoiceChan *__restrict__ slots_in, VoiceChan *__restrict__ slots_out, const RaVoiceNote *__restrict__ notes,
+__global__ void __launch_bounds__(64) ra_voice_notes_kernel(RaVoiceParams p, const VoiceChan *__restrict__ slots_in, VoiceChan *__restrict__ slots_out, const RaVoiceNote *__restrict__ notes,
                                       int n_notes, int64_t t0, int64_t n, double *__restrict__ accum) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool have = i < n_notes;
   RaVoiceNote q;
   if (have) q = notes[i]; else { q.steps = 0; q.slot = 0; q.fresh = 1; q.begin = t0; q.stream = 0; q.noteid = 0; q.vel = 0; q.store = 0; }
   const RaEnvParams ep = {p.envA, 0, 0, p.envR, 0.f};
+  __shared__ float lf[29], le[29]; // (a dynamically indexed kernel-argument array would live in scratch)
+  for (int j = threadIdx.x; j < 29; j += blockDim.x) { lf[j] = p.loud_freqs[j]; le[j] = p.loud_elv[j]; }
+  __syncthreads();
   VoiceChan v;
   if (have && !q.fresh) v = slots_in[q.slot]; // (written by the previous block: the two sets alternate, so a successor on the same channel cannot overwrite it)
   else { // a free channel, then onEvent(NoteOn) and its one-shot exactly as in the serial kernel
-    memset(&v, 0, sizeof(v));
+    v = VoiceChan{};
     chan_init(v.c);
     ++v.oddOn;
     v.noteid = q.noteid;
@@ -282,7 +319,7 @@ __global__ void ra_voice_notes_kernel(RaVoiceParams p, const VoiceChan *__restri
   double *o = accum + ((size_t)q.stream * n + (size_t)(q.begin - t0)) * 2;
   for (int k = 0; k < q.steps; ++k) {
     double vL = 0.0, vR = 0.0;
-    voice_step(v, p, ep, vL, vR);
+    voice_step(v, p, lf, le, ep, vL, vR);
     if (vL != 0.0) atomicAdd(o + 2 * (size_t)k, vL);
     if (vR != 0.0) atomicAdd(o + 2 * (size_t)k + 1, vR);
   }
@@ -322,7 +359,7 @@ void ra_voice_launch(const RaVoiceParams &p, void *state, const RaVoiceEv *ev, c
                      float *d_out, hipStream_t st) {
   if (n <= 0) return;
   const int Ppad = ((p.P + 63) / 64) * 64;
-  const size_t lds = (size_t)Ppad * (2 * VT + 1) * sizeof(double) + 16;
+  const size_t lds = (size_t)Ppad * (2 * VT + 1) * sizeof(double) + 16 + 58 * sizeof(float);
   hipLaunchKernelGGL(ra_voice_kernel, dim3((unsigned)n_streams), dim3((unsigned)Ppad), lds, st, p, static_cast<VoiceChan *>(state), ev, ev_begin, dropped, t0, n, d_out);
 }
 
@@ -336,9 +373,12 @@ int ra_voice_probe_done2(const RaVoiceParams &p, int *d_scratch) {
 void ra_voice_launch_notes(const RaVoiceParams &p, const void *slots_in, void *slots_out, const void *notes, int n_notes, int n_streams, int64_t t0, int64_t n, double *accum, float *d_out,
                            hipStream_t st) {
   if (n <= 0) return;
-  if (n_notes > 0)
-    hipLaunchKernelGGL(ra_voice_notes_kernel, dim3((unsigned)((n_notes + 63) / 64)), dim3(64), 0, st, p, static_cast<const VoiceChan *>(slots_in),
+  if (n_notes > 0) {
+    // notes per wavefront (tuning aid): measured on 256 synths x 10 s, 64: 71.5 ms, 32: 69.3 ms, 16: 94.9 ms per step
+    static const int per_wave = [] { const char *e = getenv("RA_VOICE_NOTES_PER_WAVE"); const int v = e ? atoi(e) : 32; return v >= 1 && v <= 64 ? v : 32; }();
+    hipLaunchKernelGGL(ra_voice_notes_kernel, dim3((unsigned)((n_notes + per_wave - 1) / per_wave)), dim3(per_wave), 0, st, p, static_cast<const VoiceChan *>(slots_in),
                        static_cast<VoiceChan *>(slots_out), static_cast<const RaVoiceNote *>(notes), n_notes, t0, n, accum);
+  }
   const size_t count = (size_t)n_streams * (size_t)n * 2;
   hipLaunchKernelGGL(ra_voice_cast_kernel, dim3((unsigned)std::min<size_t>((count + 255) / 256, 65536)), dim3(256), 0, st, accum, d_out, count);
 }
