@@ -316,12 +316,37 @@ __global__ void __launch_bounds__(64) ra_voice_notes_kernel(RaVoiceParams p, con
     v.start_angle = 0;
     v.rt_active = 1;
   }
-  double *o = accum + ((size_t)q.stream * n + (size_t)(q.begin - t0)) * 2;
-  for (int k = 0; k < q.steps; ++k) {
-    double vL = 0.0, vR = 0.0;
-    voice_step(v, p, lf, le, ep, vL, vR);
-    if (vL != 0.0) atomicAdd(o + 2 * (size_t)k, vL);
-    if (vR != 0.0) atomicAdd(o + 2 * (size_t)k + 1, vR);
+  // A lane's frames are consecutive in the accumulation buffer, but the lanes of a wave are far apart: one atomic per lane and frame
+  // is 64 cache lines per instruction (29 of 75 ms per 256 synths x 10 s).  So a lane parks NS frames in LDS and the block then adds
+  // every lane's run as one contiguous piece of 2 NS doubles.
+  constexpr int NS = 16;
+  __shared__ double stage[64][2 * NS + 1];
+  __shared__ long long run_base[64];
+  __shared__ int run_steps[64], max_steps;
+  const int tl = threadIdx.x, nt = blockDim.x; // nt = 32 or 64
+  if (tl == 0) max_steps = 0;
+  __syncthreads();
+  run_base[tl] = (long long)(((size_t)q.stream * n + (size_t)(q.begin - t0)) * 2);
+  run_steps[tl] = q.steps;
+  if (q.steps > 0) atomicMax(&max_steps, q.steps);
+  __syncthreads();
+  const int most = max_steps;
+  for (int k0 = 0; k0 < most; k0 += NS) {
+    for (int j = 0; j < NS; ++j) {
+      double vL = 0.0, vR = 0.0;
+      if (k0 + j < q.steps) voice_step(v, p, lf, le, ep, vL, vR);
+      stage[tl][2 * j] = vL; stage[tl][2 * j + 1] = vR;
+    }
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+      const int cnt = min(NS, run_steps[t] - k0); // frames of lane t in this piece (uniform over the block)
+      if (cnt <= 0) continue;
+      if (tl < 2 * cnt) {
+        const double x = stage[t][tl];
+        if (x != 0.0) atomicAdd(accum + run_base[t] + 2 * (long long)k0 + tl, x);
+      }
+    }
+    __syncthreads();
   }
   if (have && q.store) slots_out[q.slot] = v; // (at most one note per channel goes on into the next block)
 }
@@ -375,7 +400,7 @@ void ra_voice_launch_notes(const RaVoiceParams &p, const void *slots_in, void *s
   if (n <= 0) return;
   if (n_notes > 0) {
     // notes per wavefront (tuning aid): measured on 256 synths x 10 s, 64: 71.5 ms, 32: 69.3 ms, 16: 94.9 ms per step
-    static const int per_wave = [] { const char *e = getenv("RA_VOICE_NOTES_PER_WAVE"); const int v = e ? atoi(e) : 32; return v >= 1 && v <= 64 ? v : 32; }();
+    static const int per_wave = [] { const char *e = getenv("RA_VOICE_NOTES_PER_WAVE"); const int v = e ? atoi(e) : 32; return v == 64 ? 64 : 32; }();
     hipLaunchKernelGGL(ra_voice_notes_kernel, dim3((unsigned)((n_notes + per_wave - 1) / per_wave)), dim3(per_wave), 0, st, p, static_cast<const VoiceChan *>(slots_in),
                        static_cast<VoiceChan *>(slots_out), static_cast<const RaVoiceNote *>(notes), n_notes, t0, n, accum);
   }
