@@ -81,7 +81,8 @@ EXPORTED_SYMBOLS = [
     "ra_feed", "ra_compute", "ra_get_stats", "ra_get_events", "ra_get_frame_pitches", "ra_resynth_notes", "ra_sqmag",
     "ra_set_profiling", "ra_get_kernel_ms", "ra_get_kernel_launches", "ra_render_note",
     "ra_carrier_events", "ra_get_carrier", "ra_set_pipeline_serial", "ra_deduce_notes",
-    "ra_voice_default_config", "ra_voice_create", "ra_voice_destroy", "ra_voice_events", "ra_voice_process_host", "ra_voice_process_device", "ra_voice_dropped_note_ons",
+    "ra_voice_default_config", "ra_voice_program", "ra_voice_expand_note", "ra_voice_create", "ra_voice_destroy", "ra_voice_events", "ra_voice_process_host", "ra_voice_process_device",
+    "ra_voice_process_device_async", "ra_voice_set_hip_stream", "ra_voice_synchronize", "ra_voice_get_kernel_ms", "ra_voice_dropped_note_ons",
 ]
 
 _lib = None
@@ -307,20 +308,31 @@ def deduce_notes(signal, sr, half_window_size, window_center_stride, window_kind
     return notes
 
 
+VOICE_BIRDS, VOICE_ROBOTS, VOICE_SWEEP, VOICE_WIND = 0, 1, 2, 3
+XFADE_FREQ_NO, XFADE_FREQ_NONTRIVIAL, XFADE_FREQ_ALL = 0, 1, 2
+ITP_NAMES = ["LINEAR", "PROPORTIONAL_VALUE_DERIVATIVE", "EASE_IN_QUAD", "EASE_OUT_QUAD", "EASE_INOUT_QUAD", "EASE_IN_CUBIC", "EASE_OUT_CUBIC", "EASE_INOUT_CUBIC",
+             "EASE_IN_QUART", "EASE_OUT_QUART", "EASE_INOUT_QUART", "EASE_IN_QUINT", "EASE_OUT_QUINT", "EASE_INOUT_QUINT", "EASE_IN_SINE", "EASE_OUT_SINE",
+             "EASE_INOUT_SINE", "EASE_IN_EXPO", "EASE_OUT_EXPO", "EASE_INOUT_EXPO", "EASE_IN_CIRC", "EASE_OUT_CIRC", "EASE_INOUT_CIRC"]
+ITP = {n: i for i, n in enumerate(ITP_NAMES)}  # include/resynth_amd.h: enum ra_itp
+
+
 class RaVoiceConfig(C.Structure):
-    """Mirror of include/resynth_amd.h:ra_voice_config (the SWEEP program of gen.voice, de-normalised)."""
+    """Mirror of include/resynth_amd.h:ra_voice_config (a gen.voice program, de-normalised)."""
     _fields_ = [("sample_rate", C.c_int32), ("n_channels", C.c_int32), ("length_ms", C.c_float), ("length_exponent", C.c_float),
                 ("xfade_length_seconds", C.c_float), ("low_freq", C.c_float), ("high_freq", C.c_float), ("sine_gain", C.c_float),
                 ("loudness_level", C.c_float), ("loudness_compensation_amount", C.c_float), ("loudness_ref_freq_index", C.c_int32),
-                ("pan", C.c_float), ("random_pan", C.c_int32), ("seed", C.c_uint64)]
+                ("pan", C.c_float), ("random_pan", C.c_int32), ("seed", C.c_uint64),
+                ("mode", C.c_int32), ("interpolation", C.c_int32), ("markov_start_node", C.c_int32), ("markov_pre_tries", C.c_int32),
+                ("markov_min_path_length", C.c_int32), ("markov_additional_tries", C.c_int32), ("articulative_pause_seconds", C.c_float),
+                ("freq_scatter", C.c_float), ("length_exponent_scatter", C.c_float), ("phase_ratio1", C.c_float), ("phase_ratio2", C.c_float),
+                ("d1", C.c_float), ("d2", C.c_float), ("harmonic_attenuation", C.c_float), ("xfade_freq", C.c_int32),
+                ("freq_transition_seconds", C.c_float), ("freq_interpolation", C.c_int32), ("seed_param", C.c_int32)]
 
 
 VOICE_EVENT_DTYPE = np.dtype([("sample", "<i8"), ("stream", "<i4"), ("type", "<i4"), ("noteid", "<i8"), ("frequency", "<f4"), ("velocity", "<f4")])
 
 
-def voice_default_config(**kw):
-    c = RaVoiceConfig()
-    _check(lib().ra_voice_default_config(C.byref(c)))
+def _voice_cfg_set(c, kw):
     for k, v in kw.items():
         if not hasattr(c, k):
             raise AttributeError(k)
@@ -328,8 +340,39 @@ def voice_default_config(**kw):
     return c
 
 
+def voice_default_config(**kw):
+    c = RaVoiceConfig()
+    _check(lib().ra_voice_default_config(C.byref(c)))
+    return _voice_cfg_set(c, kw)
+
+
+def voice_program(mode, index, **kw):
+    """One of the reference's own programs (gen.voice.h:700-761).  Returns (config, name)."""
+    c = RaVoiceConfig()
+    name = C.c_char_p()
+    _check(lib().ra_voice_program(int(mode), int(index), C.byref(c), C.byref(name)))
+    return _voice_cfg_set(c, kw), name.value.decode()
+
+
+def voice_expand_note(cfg, frequency, stream_seed, seed_value, noteid=1, spec_cap=64, play_cap=64):
+    """Host-only: the ramp specs and the schedule of one note-on (ra_voice_expand_note).  Returns dict(specs_d [n,4], specs_i [n,3], vol [n],
+    played [m,4], done_step, gain_left)."""
+    sd = np.zeros((spec_cap, 4), np.float64)
+    si = np.zeros((spec_cap, 3), np.int32)
+    sv = np.zeros(spec_cap, np.float32)
+    pl = np.zeros((play_cap, 4), np.int64)
+    info = np.zeros(4, np.int64)
+    L = lib()
+    L.ra_voice_expand_note.argtypes = [C.POINTER(RaVoiceConfig), C.c_float, C.c_uint64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                       C.c_void_p, C.c_int64, C.c_void_p]
+    _check(L.ra_voice_expand_note(C.byref(cfg), float(frequency), int(stream_seed), int(seed_value), int(noteid), _p(sd), _p(si), _p(sv), spec_cap, _p(pl), play_cap, _p(info)))
+    ns, npl = int(info[0]), int(info[1])
+    gain = np.array([info[3]], np.int64).astype(np.int32).view(np.float32)[0]
+    return dict(specs_d=sd[:ns], specs_i=si[:ns], vol=sv[:ns], played=pl[:npl], done_step=int(info[2]), gain_left=float(gain))
+
+
 class Voice:
-    """n_streams gen.voice synths in SWEEP mode on one GPU (ra_voice_create .. ra_voice_destroy)."""
+    """n_streams gen.voice synths (SWEEP, BIRDS or ROBOTS) on one GPU (ra_voice_create .. ra_voice_destroy)."""
 
     def __init__(self, cfg, n_streams, device=0):
         self.n_streams = int(n_streams)
@@ -341,6 +384,10 @@ class Voice:
         L.ra_voice_events.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.ra_voice_process_host.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         L.ra_voice_process_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        L.ra_voice_process_device_async.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        L.ra_voice_set_hip_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.ra_voice_synchronize.argtypes = [C.c_void_p]
+        L.ra_voice_get_kernel_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
         L.ra_voice_dropped_note_ons.argtypes = [C.c_void_p]
         L.ra_voice_dropped_note_ons.restype = C.c_int64
         _check(L.ra_voice_create(C.byref(cfg), self.n_streams, int(device), C.byref(self._h)))
@@ -377,6 +424,23 @@ class Voice:
     def process_device(self, n_frames, d_out_ptr):
         """d_out_ptr: device pointer to [n_streams][n_frames][2] float32 (e.g. a torch tensor's data_ptr())."""
         _check(lib().ra_voice_process_device(self._h, int(n_frames), C.c_void_p(int(d_out_ptr))))
+
+    def process_device_async(self, n_frames, d_out_ptr):
+        """Enqueues the block on the object's stream and returns (ra_voice_process_device_async); synchronize() waits."""
+        _check(lib().ra_voice_process_device_async(self._h, int(n_frames), C.c_void_p(int(d_out_ptr))))
+
+    def set_hip_stream(self, stream_ptr):
+        _check(lib().ra_voice_set_hip_stream(self._h, C.c_void_p(int(stream_ptr or 0))))
+
+    def synchronize(self):
+        _check(lib().ra_voice_synchronize(self._h))
+
+    def kernel_ms(self, reset=False):
+        """({'pre': ms, 'render': ms}, launches) accumulated since the last reset (the first call switches the timing on)."""
+        ms = np.zeros(2, np.float64)
+        ln = np.zeros(2, np.int64)
+        _check(lib().ra_voice_get_kernel_ms(self._h, _p(ms), _p(ln), 1 if reset else 0))
+        return {"pre": float(ms[0]), "render": float(ms[1])}, int(ln[0])
 
     def dropped_note_ons(self):
         return _check(lib().ra_voice_dropped_note_ons(self._h))

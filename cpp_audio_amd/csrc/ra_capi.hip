@@ -1,6 +1,7 @@
 // Host side of libresynth_amd.so: context, constant tables, block scheduling, the C ABI of include/resynth_amd.h.
 // There is no CPU fallback: every compute entry point needs a HIP device and fails with RA_ENODEVICE otherwise.
 #include "ra_internal.h"
+#include "ra_voice_host.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -1608,49 +1609,151 @@ int64_t ra_resynth_notes(const ra_note *notes, int32_t n_notes, int32_t stride, 
   return T;
 }
 
-// ---- gen.voice, SWEEP mode --------------------------------------------------------------------------------------------------------
+// ---- gen.voice: SWEEP, BIRDS, ROBOTS (K9) ----------------------------------------------------------------------------------------------
+// The host's share of a block (ra_voice_host.hpp does the per-note work): ImplCRTP::onEvent's channel bookkeeping over
+// SoundEngine::tryAcquire (soundengine.h:301-317, 470-480), the notes' ramps cut into the block's jobs, the jobs of a stream packed into
+// slots whose jobs never overlap, the state slots the two kernels exchange.  Everything a block uploads goes through one pinned staging
+// buffer of two (an event says when its copies have drained), so ra_voice_process_device_async returns without waiting for the device.
 struct ra_voice {
   ra_voice_config cfg;
   RaVoiceParams p;
-  int device = 0, n_streams = 0, Ppad = 0;
+  int device = 0, n_streams = 0;
   int64_t t = 0;
-  void *state = nullptr;
-  int32_t *dropped = nullptr, *ev_begin = nullptr;
-  RaVoiceEv *ev = nullptr;
-  int64_t ev_cap = 0;
+  hipStream_t stream = nullptr;
   float *out = nullptr;
   int64_t out_cap = 0;
-  std::vector<std::deque<RaVoiceEv>> pending;
+  std::vector<std::deque<ra_voice_event>> pending;
   std::vector<int64_t> last_sample;
-  // ---- one note per lane (the default; RA_VOICE_SERIAL=1 keeps the sample-serial kernel) ----
-  // The channel bookkeeping of ImplCRTP::onEvent over SoundEngine::tryAcquire (soundengine.h:291-308,457-467) is walked here: a channel is
-  // free iff no note is on and its ramp's envelope is finished; a note-off before that leaves the ramp unfinished and the channel lost.
-  bool serial = false;
-  int k_done2 = 0;                  // steps from a note's first step until its ramp's envelope is finished (probed on the device)
-  struct Chan { bool odd = false, lost = false; int64_t noteid = -1, t_on = 0; int live = -1; /* index into `live` of the note that is on, or -1 */ };
-  struct Live { int stream, chan; int64_t t_on, noteid, done, limit; float vel; };
-  std::vector<Chan> chans;          // [n_streams][P]
-  std::vector<Live> live;           // notes that still have steps to render
-  int64_t dropped_host = 0;
-  int slot_parity = 0;
-  void *note_slots = nullptr;       // [n_streams][P] VoiceChan: the state of the channel's note where it left the last block
-  void *notes_dev = nullptr;
-  int64_t notes_cap = 0;
-  double *accum = nullptr;          // [n_streams][n][2], zero between blocks
-  int64_t accum_cap = 0;
+  std::vector<int32_t> seed_counter;   // `thread_local int seed` of setupAudioElement (gen.voice.h:910): one per stream here
+  // a channel is free iff no note is on and every ramp of its engine is finished; a note-off while a ramp is busy leaves that ramp
+  // unfinished for good (nothing steps the element any more): the channel is lost (isEnvelopeFinished_internal, soundengine.h:470-480)
+  struct Chan { bool odd = false, lost = false; int64_t noteid = -1, t_on = 0; int live = -1; std::vector<std::pair<int64_t, int64_t>> busy; /* element steps [k0, k1) */ };
+  struct LiveRamp { rav::Spec spec; int64_t k; int32_t T; int32_t carry; };
+  struct Live { int32_t stream, chan; int64_t t_on, noteid, limit; double fL, fR; int32_t A, R; std::vector<LiveRamp> ramps; };
+  std::vector<Chan> chans;             // [n_streams][P]
+  std::vector<Live> live;              // notes that still have samples to render
+  int64_t dropped = 0;
+  rav::Note scratch;
+  // device side
+  static constexpr int kTile = 256;
+  RaVoiceJob *d_jobs = nullptr; int32_t *d_order = nullptr, *d_slot_begin = nullptr;
+  int64_t jobs_cap = 0, slots_cap = 0, order_cap = 0;
+  RaVoiceState *d_states[2] = {nullptr, nullptr};
+  int64_t states_cap[2] = {0, 0};
+  int parity = 0;
+  struct Staging { void *h = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool used = false; } staging[2];
+  int stage_parity = 0;
+  // timing
+  struct Timed { hipEvent_t a, b, c; };
+  std::vector<Timed> timed;
+  std::vector<hipEvent_t> ev_pool;
+  bool profiling = false;
+  double ms[2] = {0, 0};
+  int64_t launches[2] = {0, 0};
+  // per-block scratch vectors (kept to avoid reallocation)
+  struct JobRec { RaVoiceJob j; int32_t end; };
+  std::vector<std::vector<JobRec>> by_stream;
+  std::vector<int64_t> slot_end;
 };
-struct RaVoiceNoteHost { int64_t begin; int64_t noteid; int32_t stream, slot, steps, fresh; float vel; int32_t store; }; // = ra_voice.hip: RaVoiceNote
 
-int ra_voice_default_config(ra_voice_config *c) {
-  if (!c) return fail(RA_EINVAL, "null config");
+namespace {
+struct VoiceProgram { const char *name; int start, pre, path, extra; int itp; float scat, length, ex, ex_scat, pause, xfade; int xfade_freq; float freq_xfade; float d1, d2, att, low, high; };
+// ImplBase::getPrograms (gen.voice.h:700-761): make_bird(start, pre, path, extra, itp, freq_scat, length, exponent, exponent scatter, pause, xfade, xfade_freq,
+// freq_xfade, freq_itp) — whose FREQ_TRANSITION_INTERPOLATION is written from `itp`, not `freq_itp` (:607-612), kept —, make_robot(start, pre, path, extra,
+// pause, itp, freq_scat, length, exponent, exponent scatter, xfade, d1, d2, attenuation), make_sweep(itp, length, exponent, xfade, low, high)
+const VoiceProgram kBirds[] = {
+    {"Standard & Cute bird", 0, 0, 1, 0, RA_ITP_EASE_INOUT_CIRC, 0.f, 93.f, 2.f, .5f, 0.02267f, 0.0295f, RA_XFADE_FREQ_NO, 0.14f, 0, 0, 0, 0, 0},
+    {"Scat bird", 0, 0, 3, 17, RA_ITP_EASE_INOUT_CIRC, 0.015f, 10.f, 2.f, .5f, 0.0445f, 0.0177f, RA_XFADE_FREQ_NONTRIVIAL, 0.363f, 0, 0, 0, 0, 0},
+    {"Rhythmic bird", 1, 0, 3, 11, RA_ITP_EASE_INOUT_CIRC, 0.f, 19.8f, 2.f, 0.f, 0.03188f, 0.01138f, RA_XFADE_FREQ_ALL, 0.0182f, 0, 0, 0, 0, 0},
+    {"Slow bird", 0, 2, 1, 0, RA_ITP_EASE_IN_EXPO, 0.f, 73.7f, 2.f, .5f, 0.02267f, 0.0295f, RA_XFADE_FREQ_NO, 0.14f, 0, 0, 0, 0, 0},
+    {"BiTone bird", 1, 0, 2, 0, RA_ITP_EASE_IN_EXPO, .414f, 78.6f, 2.f, .5f, 0.09755f, 0.0295f, RA_XFADE_FREQ_NO, 0.14f, 0, 0, 0, 0, 0},
+    {"Happy bird 1", 1, 0, 4, 0, RA_ITP_EASE_IN_EXPO, .414f, 78.6f, 2.f, .5f, 0.1326f, 0.0454f, RA_XFADE_FREQ_NO, 0.14f, 0, 0, 0, 0, 0},
+    {"Happy bird 2", 1, 0, 4, 0, RA_ITP_EASE_IN_EXPO, .414f, 63.9f, 1.19f, 1.f, 0.1326f, 0.0454f, RA_XFADE_FREQ_NO, 0.14f, 0, 0, 0, 0, 0},
+    {"Laughing bird", 1, 0, 2, 0, RA_ITP_EASE_IN_EXPO, .414f, 78.6f, 2.f, .5f, 0.2193f, 0.0295f, RA_XFADE_FREQ_ALL, 0.0725f, 0, 0, 0, 0, 0},
+    {"Talkative bird", 0, 0, 6, 0, RA_ITP_EASE_INOUT_CIRC, 0.12f, 93.3f, 2.f, .5f, 0.152f, 0.05f, RA_XFADE_FREQ_NONTRIVIAL, 0.0998f, 0, 0, 0, 0, 0}};
+const VoiceProgram kRobots[] = {
+    {"R2D2", 0, 0, 1, 1, RA_ITP_LINEAR, 0.f, 19.8f, 2.1f, 0.39f, 0.0835f, 0.0053f, 0, 0.f, 6, 12, .98f, 0, 0},
+    {"Communication", 0, 0, 16, 14, RA_ITP_EASE_INOUT_CIRC, 0.f, 10.f, 1.89f, 1.f, 0.03188f, 0.0053f, 0, 0.f, 6, 10, .98f, 0, 0}};
+const VoiceProgram kSweeps[] = {
+    {"Sweep 1", 0, 0, 0, 0, RA_ITP_LINEAR, 0.f, 73.f, 5.f, 0.f, 0.f, 0.0109f, 0, 0.f, 0, 0, 0, 0.0009f, 20000.f},
+    {"Fullrange", 0, 0, 0, 0, RA_ITP_LINEAR, 0.f, 500.f, 5.f, 0.f, 0.f, 0.0109f, 0, 0.f, 0, 0, 0, 0.000226f, 20000.f}};
+
+void voice_common_defaults(ra_voice_config *c) { // make_common, gen.voice.h:474-531 + include/loudness_init_values.h
   std::memset(c, 0, sizeof(*c));
   c->sample_rate = 48000;
   c->n_channels = 16;
-  c->length_ms = 73.f; c->length_exponent = 5.f; c->xfade_length_seconds = 0.0109f; // make_sweep(LINEAR, 73, 5, 0.0109, ...), gen.voice.h:752-754
+  c->sine_gain = 1.f;
+  c->loudness_level = 30.f; c->loudness_compensation_amount = 1.f; c->loudness_ref_freq_index = 5;
+  c->pan = 0.f;
   c->low_freq = 100.f; c->high_freq = 20000.f;
-  c->sine_gain = 1.f;                                                               // make_common, gen.voice.h:497-529
-  c->loudness_level = 30.f; c->loudness_compensation_amount = 1.f; c->loudness_ref_freq_index = 5; // include/loudness_init_values.h
-  c->pan = 0.f; c->random_pan = 0;
+  c->freq_interpolation = RA_ITP_EASE_IN_EXPO;
+}
+int pow2_ceil_log2(int v) { int k = 0; while ((1 << k) < v) ++k; return k; }
+} // namespace
+
+int ra_voice_default_config(ra_voice_config *c) {
+  if (!c) return fail(RA_EINVAL, "null config");
+  voice_common_defaults(c);
+  c->mode = RA_VOICE_SWEEP;
+  c->interpolation = RA_ITP_LINEAR;
+  c->length_ms = 73.f; c->length_exponent = 5.f; c->xfade_length_seconds = 0.0109f; // make_sweep(LINEAR, 73, 5, 0.0109, ...), gen.voice.h:752-754
+  c->random_pan = 0;
+  return RA_OK;
+}
+
+int ra_voice_program(int32_t mode, int32_t index, ra_voice_config *c, const char **name) {
+  if (!c) return fail(RA_EINVAL, "null config");
+  const VoiceProgram *tab = nullptr;
+  int count = 0;
+  if (mode == RA_VOICE_BIRDS) { tab = kBirds; count = 9; }
+  else if (mode == RA_VOICE_ROBOTS) { tab = kRobots; count = 2; }
+  else if (mode == RA_VOICE_SWEEP) { tab = kSweeps; count = 2; }
+  else return fail(RA_EINVAL, "ra_voice_program: mode must be RA_VOICE_BIRDS, RA_VOICE_ROBOTS or RA_VOICE_SWEEP (WIND is not built)");
+  if (index < 0 || index >= count) return fail(RA_EINVAL, "ra_voice_program: no such program");
+  const VoiceProgram &g = tab[index];
+  voice_common_defaults(c);
+  c->mode = mode;
+  c->random_pan = 1; // make_common stores RANDOM_PAN = !true = 0, which setupAudioElement reads as "random" (gen.voice.h:511,983)
+  c->seed_param = 0; // SEED 0: another seed per note
+  c->interpolation = g.itp;
+  c->length_ms = g.length; c->length_exponent = g.ex; c->xfade_length_seconds = g.xfade;
+  if (mode == RA_VOICE_SWEEP) { c->low_freq = g.low; c->high_freq = g.high; }
+  else {
+    c->markov_start_node = g.start; c->markov_pre_tries = g.pre; c->markov_min_path_length = g.path; c->markov_additional_tries = g.extra;
+    c->articulative_pause_seconds = g.pause; c->freq_scatter = g.scat; c->length_exponent_scatter = g.ex_scat;
+  }
+  if (mode == RA_VOICE_BIRDS) { c->xfade_freq = g.xfade_freq; c->freq_transition_seconds = g.freq_xfade; c->freq_interpolation = g.itp; }
+  if (mode == RA_VOICE_ROBOTS) { c->d1 = g.d1; c->d2 = g.d2; c->harmonic_attenuation = g.att; }
+  if (name) *name = g.name;
+  return RA_OK;
+}
+
+int ra_voice_expand_note(const ra_voice_config *cfg, float frequency, uint64_t stream_seed, int32_t seed_value, int64_t noteid, double *spec_d, int32_t *spec_i, float *spec_vol,
+                         int64_t spec_cap, int64_t *played, int64_t played_cap, int64_t *info) {
+  if (!cfg) return fail(RA_EINVAL, "null config");
+  const char *why = nullptr;
+  if (rav::config_error(*cfg, why)) return fail(RA_EINVAL, why);
+  if (!(frequency > 0.f)) return fail(RA_EINVAL, "a note-on needs a frequency > 0 (soundengine.h:972-975)");
+  rav::Note note;
+  rav::expand_note(*cfg, frequency, stream_seed, seed_value, noteid, note);
+  const int64_t ns = (int64_t)note.specs.size(), np = (int64_t)note.plays.size();
+  if (info) {
+    double pan = std::min(1., std::max(-1., (double)note.pan));
+    const float gl = (float)std::cos(0.25 * M_PI * (pan + 1.));
+    int32_t bits;
+    std::memcpy(&bits, &gl, 4);
+    info[0] = ns; info[1] = np; info[2] = note.done_step; info[3] = bits;
+  }
+  for (int64_t i = 0; i < ns && i < spec_cap; ++i) {
+    const rav::Spec &s = note.specs[i];
+    if (spec_d) { spec_d[4 * i] = s.from; spec_d[4 * i + 1] = s.to; spec_d[4 * i + 2] = s.dur; spec_d[4 * i + 3] = s.start; }
+    if (spec_i) { spec_i[3 * i] = s.interp; spec_i[3 * i + 1] = s.silence ? 1 : 0; spec_i[3 * i + 2] = 0; }
+    if (spec_vol) spec_vol[i] = s.vol;
+  }
+  for (int64_t i = 0; i < np && i < played_cap; ++i)
+    if (played) { played[4 * i] = note.plays[i].k; played[4 * i + 1] = note.plays[i].ramp; played[4 * i + 2] = note.plays[i].spec; played[4 * i + 3] = note.plays[i].T; }
+  if ((spec_d || spec_i || spec_vol) && ns > spec_cap) return fail(RA_EOVERFLOW, "ra_voice_expand_note: spec capacity too small");
+  if (played && np > played_cap) return fail(RA_EOVERFLOW, "ra_voice_expand_note: play capacity too small");
   return RA_OK;
 }
 
@@ -1659,37 +1762,20 @@ int ra_voice_create(const ra_voice_config *cfg, int32_t n_streams, int32_t devic
   *out = nullptr;
   const ra_voice_config &c = *cfg;
   if (n_streams < 1) return fail(RA_EINVAL, "n_streams must be >= 1");
-  if (c.sample_rate < 1000) return fail(RA_EINVAL, "sample_rate is too small");
-  if (c.n_channels < 1 || c.n_channels > RA_MAX_CHANNELS) return fail(RA_EINVAL, "n_channels must be in 1..256");
-  if (!(c.low_freq > 0.f) || !(c.high_freq > 0.f)) return fail(RA_EINVAL, "the sweep's ends must be positive frequencies (LogRamp, audioelement.h:2566-2567)");
-  if (!(c.length_ms > 0.f) || !(c.length_exponent >= 0.f) || c.length_exponent > 7.f) return fail(RA_EINVAL, "bad length / length exponent");
-  if (!(c.xfade_length_seconds >= 0.f)) return fail(RA_EINVAL, "bad xfade length");
-  if (c.loudness_ref_freq_index < 0 || c.loudness_ref_freq_index > 15) return fail(RA_EINVAL, "loudness_ref_freq_index must be in 0..15");
-  if (!(c.loudness_compensation_amount >= 0.f && c.loudness_compensation_amount <= 1.f)) return fail(RA_EINVAL, "loudness_compensation_amount must be in 0..1");
+  const char *why = nullptr;
+  if (rav::config_error(c, why)) return fail(RA_EINVAL, why);
+  if (c.mode == RA_VOICE_SWEEP) { // the one spec of a sweep is known now: refuse here what playNextSpec asserts (soundengine.h:797-799)
+    float len = c.length_ms;
+    len *= std::pow(2.f, c.length_exponent);
+    const float n_frames = static_cast<float>(rav::ms_to_frames(len, c.sample_rate));
+    if (!(n_frames > 0.f)) return fail(RA_EINVAL, "length is too small");
+    if (static_cast<int>(.5f + n_frames) - rav::xfade_len_of(c) < 0) return fail(RA_EINVAL, "the sweep is shorter than its cross-fade (soundengine.h:797-799)");
+  }
   RaVoiceParams p;
   std::memset(&p, 0, sizeof(p));
   p.sample_rate = c.sample_rate;
-  p.P = c.n_channels;
-  p.xfade_len = static_cast<int>(0.5f + (c.xfade_length_seconds * c.sample_rate));       // setEnvelopeCharacTime, gen.voice.h:893
-  const int min_dt = c.sample_rate / 1000;                                                  // setAHDSR, audioelement.h:923-952
-  p.envA = std::max(p.xfade_len, min_dt);
-  p.envR = std::max(p.xfade_len, min_dt);
-  { // SoundEngine::do_initialize + create_sweep's node 0 (soundengine.h:700-713,1001-1044): length * 2^exponent, in frames
-    if (ms_to_frames(c.length_ms, c.sample_rate) <= 0) return fail(RA_EINVAL, "length is too small");
-    float len = c.length_ms;
-    len *= std::pow(2.f, c.length_exponent);
-    const float n_frames = static_cast<float>(ms_to_frames(len, c.sample_rate));
-    if (!(n_frames > 0.f)) return fail(RA_EINVAL, "length is too small");
-    p.n_frames = n_frames;
-    p.start_sample = 0.f * n_frames; // phase_ratio1 (never set in SWEEP mode: 0) * n_frames
-    if (static_cast<int>(.5f + p.n_frames) - p.xfade_len < 0) return fail(RA_EINVAL, "the sweep is shorter than its cross-fade (soundengine.h:796)");
-  }
-  p.inc_low = static_cast<double>(2 * c.low_freq / c.sample_rate);   // freq_to_angle_increment<float>, sound.functions.h:58-62
-  p.inc_high = static_cast<double>(2 * c.high_freq / c.sample_rate);
-  p.base_volume = (static_cast<double>(0.1f) * 1.) / static_cast<double>(0.1f); // LoudnessVolumeAdjusted::baseVolume, audioelement.h:1279,2370
   p.sine_gain = c.sine_gain;
   p.log_ratio = c.loudness_compensation_amount;
-  p.pan = c.pan; p.random_pan = c.random_pan ? 1 : 0; p.seed = c.seed;
   { // include/loudness.h:199-229
     int li = static_cast<int>(c.loudness_level * .1f) - 2;
     li = std::max(0, li); li = std::min(8, li);
@@ -1701,27 +1787,15 @@ int ra_voice_create(const ra_voice_config *cfg, int32_t n_streams, int32_t devic
   if (device < 0 || device >= ndev) return fail(RA_EINVAL, "device ordinal out of range");
   HIP_TRY(hipSetDevice(device));
   ra_voice *v = new ra_voice();
-  v->cfg = c; v->p = p; v->device = device; v->n_streams = n_streams; v->Ppad = ((p.P + 63) / 64) * 64;
+  v->cfg = c; v->p = p; v->device = device; v->n_streams = n_streams;
   v->pending.assign(n_streams, {});
   v->last_sample.assign(n_streams, 0);
-  const int count = n_streams * v->Ppad;
-  hipError_t e = hipMalloc(&v->state, ra_voice_state_bytes() * count);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v->dropped), sizeof(int32_t) * n_streams);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v->ev_begin), sizeof(int32_t) * (n_streams + 1));
-  if (e == hipSuccess) e = hipMemset(v->dropped, 0, sizeof(int32_t) * n_streams);
-  if (e == hipSuccess) { ra_voice_launch_init(v->state, count, nullptr); e = hipDeviceSynchronize(); }
-  v->serial = std::getenv("RA_VOICE_SERIAL") != nullptr;
-  if (e == hipSuccess && !v->serial) {
-    v->chans.assign((size_t)n_streams * p.P, {});
-    e = hipMalloc(&v->note_slots, 2 * ra_voice_state_bytes() * (size_t)n_streams * p.P); // two sets, alternating by block
-    if (e == hipSuccess) {
-      v->k_done2 = ra_voice_probe_done2(p, v->dropped); // (the counter array serves as scratch; zeroed again below)
-      if (v->k_done2 < 0) e = hipErrorUnknown;
-      else e = hipMemset(v->dropped, 0, sizeof(int32_t) * n_streams);
-    }
-    static_assert(sizeof(RaVoiceNoteHost) == 40, "layout of the note descriptor");
-    if (e == hipSuccess && ra_voice_note_bytes() != sizeof(RaVoiceNoteHost)) e = hipErrorUnknown;
-  }
+  v->seed_counter.assign(n_streams, 0);
+  v->chans.assign((size_t)n_streams * c.n_channels, {});
+  v->by_stream.assign(n_streams, {});
+  v->profiling = std::getenv("RA_VOICE_PROFILE") != nullptr;
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&v->staging[i].done, hipEventDisableTiming);
   if (e != hipSuccess) { ra_voice_destroy(v); return fail(RA_EHIP, std::string("ra_voice_create: ") + hipGetErrorString(e)); }
   *out = v;
   return RA_OK;
@@ -1731,9 +1805,27 @@ void ra_voice_destroy(ra_voice *v) {
   if (!v) return;
   (void)hipSetDevice(v->device);
   (void)hipDeviceSynchronize();
-  (void)hipFree(v->state); (void)hipFree(v->dropped); (void)hipFree(v->ev_begin); (void)hipFree(v->ev); (void)hipFree(v->out);
-  (void)hipFree(v->note_slots); (void)hipFree(v->notes_dev); (void)hipFree(v->accum);
+  (void)hipFree(v->out); (void)hipFree(v->d_jobs); (void)hipFree(v->d_order); (void)hipFree(v->d_slot_begin);
+  (void)hipFree(v->d_states[0]); (void)hipFree(v->d_states[1]);
+  for (auto &s : v->staging) { if (s.h) (void)hipHostFree(s.h); if (s.done) (void)hipEventDestroy(s.done); }
+  for (auto &t : v->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); (void)hipEventDestroy(t.c); }
+  for (auto &e : v->ev_pool) (void)hipEventDestroy(e);
   delete v;
+}
+
+int ra_voice_set_hip_stream(ra_voice *v, void *hip_stream) {
+  if (!v) return fail(RA_EINVAL, "null context");
+  HIP_TRY(hipSetDevice(v->device));
+  HIP_TRY(hipStreamSynchronize(v->stream)); // what was enqueued on the old stream is finished before anything follows on the new one
+  v->stream = static_cast<hipStream_t>(hip_stream);
+  return RA_OK;
+}
+
+int ra_voice_synchronize(ra_voice *v) {
+  if (!v) return fail(RA_EINVAL, "null context");
+  HIP_TRY(hipSetDevice(v->device));
+  HIP_TRY(hipStreamSynchronize(v->stream));
+  return RA_OK;
 }
 
 int ra_voice_events(ra_voice *v, const ra_voice_event *ev, int64_t n) {
@@ -1747,119 +1839,236 @@ int ra_voice_events(ra_voice *v, const ra_voice_event *ev, int64_t n) {
     if (e.sample < v->t) return fail(RA_EINVAL, at + "its frame has already been processed");
     if (e.sample < v->last_sample[e.stream]) return fail(RA_EINVAL, at + "samples of a stream must not decrease");
     if (e.type == 0 && !(e.velocity > 0.f)) return fail(RA_EINVAL, at + "a note-on needs a velocity > 0 (gen.crtp.h:391)");
-    if (e.type == 0 && !(e.frequency > 0.f)) return fail(RA_EINVAL, at + "a note-on needs a frequency > 0 (soundengine.h:1012-1015)");
-    RaVoiceEv d;
-    d.sample = e.sample; d.noteid = e.noteid; d.type = e.type; d.pad = 0; d.freq = e.frequency; d.vel = e.velocity;
-    v->pending[e.stream].push_back(d);
+    if (e.type == 0 && !(e.frequency > 0.f)) return fail(RA_EINVAL, at + "a note-on needs a frequency > 0 (soundengine.h:972-975)");
+    v->pending[e.stream].push_back(e);
     v->last_sample[e.stream] = e.sample;
   }
   return RA_OK;
 }
 
-// the block with one note per lane: the events' bookkeeping here, the notes' samples on the device
-static int voice_block_notes(ra_voice *v, int64_t n, float *d_out) {
-  const int S = v->n_streams, P = v->p.P;
-  const int64_t t0 = v->t, t1 = v->t + n, K = v->k_done2;
+namespace {
+int voice_grow_bytes(void **ptr, int64_t &cap, int64_t need, size_t elem, hipStream_t st) { // device buffers only grow; the stream is drained before one is replaced
+  if (need <= cap) return RA_OK;
+  HIP_TRY(hipStreamSynchronize(st));
+  (void)hipFree(*ptr);
+  *ptr = nullptr;
+  cap = std::max<int64_t>(1024, need + need / 2);
+  HIP_TRY(hipMalloc(ptr, elem * (size_t)cap));
+  return RA_OK;
+}
+#define voice_grow(ptr, cap, need, st) voice_grow_bytes(reinterpret_cast<void **>(ptr), cap, need, sizeof(**(ptr)), st)
+
+// the block's events: ImplCRTP::onEvent (gen.crtp.h:389-449, 541-588) with the engine's acquisition rule
+void voice_block_events(ra_voice *v, int64_t t0, int64_t t1) {
+  const int S = v->n_streams, P = v->cfg.n_channels;
   for (int s = 0; s < S; ++s) {
     auto &q = v->pending[s];
     ra_voice::Chan *ch = v->chans.data() + (size_t)s * P;
     while (!q.empty() && q.front().sample < t1) {
-      const RaVoiceEv e = q.front();
+      const ra_voice_event e = q.front();
       q.pop_front();
       const int64_t te = std::max(e.sample, t0); // (events are not accepted before the frames already processed)
-      if (e.type == 0) { // onEvent(NoteOn): the first channel whose engine is finished (gen.crtp.h:397-405, soundengine.h:291-308)
+      if (e.type == 0) { // NoteOn: the first channel whose engine is finished
         int sel = -1;
         for (int c = 0; c < P; ++c) if (!ch[c].odd && !ch[c].lost) { sel = c; break; }
-        if (sel < 0) { ++v->dropped_host; continue; }
-        ch[sel].odd = true; ch[sel].noteid = e.noteid; ch[sel].t_on = te;
-        ch[sel].live = (int)v->live.size();
-        v->live.push_back({s, sel, te, e.noteid, 0, K, e.vel});
-      } else { // NoteOff: the first channel that last played this note id; it reacts only while its note is on (gen.crtp.h:541-588)
+        if (sel < 0) { ++v->dropped; continue; }
+        // setupAudioElement: the reseed (gen.voice.h:910-925), the chain, the schedule
+        int32_t seed_value = 0;
+        if (v->cfg.mode != RA_VOICE_SWEEP) {
+          int32_t &sc = v->seed_counter[s];
+          if (v->cfg.seed_param) sc = v->cfg.seed_param;
+          else if (sc == 257) sc = 1;
+          else ++sc;
+          seed_value = sc;
+        }
+        rav::Note &note = v->scratch;
+        rav::expand_note(v->cfg, e.frequency, v->cfg.seed + (uint64_t)s, seed_value, e.noteid, note);
+        ra_voice::Chan &c = ch[sel];
+        c.odd = true; c.noteid = e.noteid; c.t_on = te;
+        c.busy.clear();
+        ra_voice::Live l;
+        l.stream = s; l.chan = sel; l.t_on = te; l.noteid = e.noteid; l.limit = INT64_MAX; l.A = note.A; l.R = note.R;
+        {
+          const double o_vol = ((static_cast<double>(0.1f) * 1.) / static_cast<double>(0.1f)) * (double)e.velocity; // Element::baseVolume * velocity (gen.crtp.h:425; audioelement.h:1279,2370)
+          double pan = (double)note.pan;
+          pan = std::min(pan, 1.); pan = std::max(pan, -1.);
+          const double ang = (0.25 * M_PI) * (pan + 1.); // stereo(), include/stereo.h:18-27
+          l.fL = o_vol * std::cos(ang); l.fR = o_vol * std::sin(ang);
+        }
+        for (const rav::Play &pl : note.plays) {
+          c.busy.emplace_back(pl.k, pl.T > 0 ? pl.k + pl.T + note.R + 16 : pl.k + 16);
+          if (pl.T > 0 && pl.T + note.R - 1 > 0) l.ramps.push_back({note.specs[pl.spec], pl.k, pl.T, -1});
+        }
+        if (!l.ramps.empty()) { c.live = (int)v->live.size(); v->live.push_back(std::move(l)); }
+        else c.live = -1;
+      } else { // NoteOff: the first channel that last played this note id; it reacts only while its note is on
         int sel = -1;
         for (int c = 0; c < P; ++c) if (ch[c].noteid == e.noteid) { sel = c; break; }
         if (sel < 0 || !ch[sel].odd) continue;
         const int64_t k = te - ch[sel].t_on; // steps the element took
         ch[sel].odd = false;
-        if (k >= 1 && k < K) ch[sel].lost = true; // the ramp is left unfinished: isEnvelopeFinished_internal stays false (soundengine.h:457-467)
+        for (const auto &b : ch[sel].busy) if (k >= b.first && k < b.second) { ch[sel].lost = true; break; }
         if (ch[sel].live >= 0) { ra_voice::Live &l = v->live[ch[sel].live]; l.limit = std::min(l.limit, k); }
         ch[sel].live = -1;
       }
     }
   }
-  std::vector<RaVoiceNoteHost> desc;
-  std::vector<ra_voice::Live> keep;
-  for (auto &l : v->live) {
-    const int64_t upto = std::min(l.limit, t1 - l.t_on); // steps taken by the end of this block
-    const int64_t steps = upto - l.done;
-    if (steps > 0) {
-      const bool goes_on = upto < l.limit;
-      desc.push_back({l.t_on + l.done, l.noteid, l.stream, l.stream * P + l.chan, (int32_t)steps, l.done == 0 ? 1 : 0, l.vel, goes_on ? 1 : 0});
-      l.done = upto;
-    }
-    ra_voice::Chan &c = v->chans[(size_t)l.stream * P + l.chan];
-    const bool mine = c.odd && c.t_on == l.t_on && c.noteid == l.noteid; // the channel's note that is on is this one
-    if (l.done < l.limit) { if (mine) c.live = (int)keep.size(); keep.push_back(l); }
-    else if (mine) c.live = -1; // rendered to its end; the channel stays taken until the note-off
-  }
-  v->live.swap(keep);
-  if ((int64_t)desc.size() > v->notes_cap) {
-    (void)hipFree(v->notes_dev);
-    v->notes_dev = nullptr;
-    v->notes_cap = std::max<int64_t>(1024, 2 * (int64_t)desc.size());
-    HIP_TRY(hipMalloc(&v->notes_dev, sizeof(RaVoiceNoteHost) * v->notes_cap));
-  }
-  if (n > v->accum_cap) {
-    (void)hipFree(v->accum);
-    v->accum = nullptr;
-    v->accum_cap = n;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&v->accum), sizeof(double) * 2 * (size_t)S * n));
-    HIP_TRY(hipMemset(v->accum, 0, sizeof(double) * 2 * (size_t)S * n));
-  }
-  if (!desc.empty()) HIP_TRY(hipMemcpy(v->notes_dev, desc.data(), sizeof(RaVoiceNoteHost) * desc.size(), hipMemcpyHostToDevice));
-  {
-    char *base = static_cast<char *>(v->note_slots);
-    const size_t set = ra_voice_state_bytes() * (size_t)S * P;
-    ra_voice_launch_notes(v->p, base + (v->slot_parity ? set : 0), base + (v->slot_parity ? 0 : set), v->notes_dev, (int)desc.size(), S, t0, n, v->accum, d_out, nullptr);
-    v->slot_parity ^= 1;
-  }
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
-  v->t += n;
-  return RA_OK;
 }
 
-static int voice_block(ra_voice *v, int64_t n, float *d_out) { // stages the block's events and runs it into d_out (device)
+void *voice_stage(ra_voice *v, size_t bytes, int &err) { // the pinned staging buffer of this block (waits for the block before last to have drained it)
+  ra_voice::Staging &sg = v->staging[v->stage_parity];
+  err = RA_OK;
+  if (sg.used) { if (hipEventSynchronize(sg.done) != hipSuccess) { err = fail(RA_EHIP, "hipEventSynchronize(staging)"); return nullptr; } }
+  if (bytes > sg.cap) {
+    if (sg.h) (void)hipHostFree(sg.h);
+    sg.h = nullptr;
+    sg.cap = bytes + bytes / 2 + 4096;
+    if (hipHostMalloc(&sg.h, sg.cap, hipHostMallocDefault) != hipSuccess) { sg.cap = 0; err = fail(RA_EHIP, "hipHostMalloc(staging)"); return nullptr; }
+  }
+  return sg.h;
+}
+
+int voice_block(ra_voice *v, int64_t n, float *d_out) {
   HIP_TRY(hipSetDevice(v->device));
-  if (!v->serial) return voice_block_notes(v, n, d_out);
-  const int S = v->n_streams;
-  std::vector<RaVoiceEv> flat;
-  std::vector<int32_t> begin(S + 1, 0);
+  if (n > INT32_MAX / 4) return fail(RA_EINVAL, "a block must have fewer than 2^29 frames");
+  const int S = v->n_streams, L = ra_voice::kTile;
+  const int64_t t0 = v->t, t1 = v->t + n;
+  voice_block_events(v, t0, t1);
+  // ---- the live notes' ramps -> this block's jobs, per stream ----
+  for (auto &b : v->by_stream) b.clear();
+  int64_t n_states = 0, n_jobs = 0;
+  {
+    std::vector<ra_voice::Live> keep;
+    keep.reserve(v->live.size());
+    for (auto &l : v->live) {
+      bool more = false;
+      for (auto &r : l.ramps) {
+        if (r.T <= 0) continue;
+        const int64_t k_last = std::min(r.k + r.T + l.R - 2, l.limit); // the ramp's last sounding element step (1-based), cut by the note-off
+        const int64_t fa = std::max(l.t_on + r.k - 1, t0), fz = std::min(l.t_on + k_last - 1, t1 - 1);
+        if (l.t_on + k_last - 1 >= t1) more = true;
+        if (fa > fz) continue;
+        ra_voice::JobRec jr;
+        RaVoiceJob &j = jr.j;
+        j.from = r.spec.from; j.to = r.spec.to; j.dur = r.spec.dur; j.cur0 = r.spec.start;
+        j.vol = (double)r.spec.vol; j.fL = l.fL; j.fR = l.fR;
+        j.begin = (int32_t)(fa - t0); j.n = (int32_t)(fz - fa + 1);
+        j.j0 = (int32_t)(fa - l.t_on - r.k + 2);
+        j.T = r.T; j.A = l.A; j.R = l.R; j.interp = r.spec.interp;
+        j.state_in = (j.j0 == 1) ? -1 : r.carry;
+        j.stream = l.stream; j.slot = 0;
+        const bool goes_on = l.t_on + k_last - 1 >= t1;
+        const int32_t tiles = (j.begin + j.n - 1) / L - j.begin / L;
+        j.state_tiles = (int32_t)n_states;
+        n_states += tiles;
+        j.state_out = goes_on ? (int32_t)n_states++ : -1;
+        r.carry = j.state_out;
+        jr.end = j.begin + j.n;
+        v->by_stream[l.stream].push_back(jr);
+        ++n_jobs;
+      }
+      const bool mine_on = v->chans[(size_t)l.stream * v->cfg.n_channels + l.chan].live >= 0 &&
+                           v->live[v->chans[(size_t)l.stream * v->cfg.n_channels + l.chan].live].noteid == l.noteid &&
+                           v->live[v->chans[(size_t)l.stream * v->cfg.n_channels + l.chan].live].t_on == l.t_on;
+      if (more) { if (mine_on) v->chans[(size_t)l.stream * v->cfg.n_channels + l.chan].live = (int)keep.size(); keep.push_back(std::move(l)); }
+      else if (mine_on) v->chans[(size_t)l.stream * v->cfg.n_channels + l.chan].live = -1; // rendered to its end; the channel stays taken until the note-off
+    }
+    v->live.swap(keep);
+  }
+  // ---- slots: a stream's jobs in begin order, each into the lowest slot that is free again (greedy interval colouring) ----
+  int g_needed = 1;
   for (int s = 0; s < S; ++s) {
-    begin[s] = static_cast<int32_t>(flat.size());
-    auto &q = v->pending[s];
-    while (!q.empty() && q.front().sample < v->t + n) { flat.push_back(q.front()); q.pop_front(); }
+    auto &jobs = v->by_stream[s];
+    std::sort(jobs.begin(), jobs.end(), [](const ra_voice::JobRec &a, const ra_voice::JobRec &b) { return a.j.begin < b.j.begin; });
+    v->slot_end.clear();
+    for (auto &jr : jobs) {
+      int sl = -1;
+      for (size_t k = 0; k < v->slot_end.size(); ++k) if (v->slot_end[k] <= jr.j.begin) { sl = (int)k; break; }
+      if (sl < 0) { sl = (int)v->slot_end.size(); v->slot_end.push_back(0); }
+      v->slot_end[sl] = jr.end;
+      jr.j.slot = sl;
+    }
+    g_needed = std::max(g_needed, (int)v->slot_end.size());
   }
-  begin[S] = static_cast<int32_t>(flat.size());
-  if (static_cast<int64_t>(flat.size()) > v->ev_cap) {
-    (void)hipFree(v->ev);
-    v->ev = nullptr;
-    v->ev_cap = std::max<int64_t>(256, 2 * static_cast<int64_t>(flat.size()));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&v->ev), sizeof(RaVoiceEv) * v->ev_cap));
+  const int g_log2 = pow2_ceil_log2(g_needed), g = 1 << g_log2;
+  if (g > 1024) return fail(RA_EINTERNAL, "more than 1024 overlapping ramps in a stream");
+  // ---- staging image: jobs sorted by (stream, slot, begin), the slots' offsets, the pre-pass order (longest first) ----
+  const int64_t n_slots = (int64_t)S * g + 1;
+  const size_t bytes_jobs = sizeof(RaVoiceJob) * (size_t)n_jobs, bytes_slots = sizeof(int32_t) * (size_t)n_slots, bytes_order = sizeof(int32_t) * (size_t)n_jobs;
+  int err = RA_OK;
+  char *h = static_cast<char *>(voice_stage(v, bytes_jobs + bytes_slots + bytes_order + 64, err));
+  if (err) return err;
+  RaVoiceJob *hj = reinterpret_cast<RaVoiceJob *>(h);
+  int32_t *hs = reinterpret_cast<int32_t *>(h + bytes_jobs), *ho = hs + n_slots;
+  int64_t at = 0, n_work = 0;
+  {
+    std::vector<int32_t> fill(g);
+    for (int s = 0; s < S; ++s) {
+      auto &jobs = v->by_stream[s];
+      std::fill(fill.begin(), fill.end(), 0);
+      for (auto &jr : jobs) ++fill[jr.j.slot];
+      int64_t o = at;
+      for (int k = 0; k < g; ++k) { hs[(size_t)s * g + k] = (int32_t)o; const int c = fill[k]; fill[k] = (int32_t)o; o += c; }
+      for (auto &jr : jobs) hj[fill[jr.j.slot]++] = jr.j; // (begin order within a slot is the order of `jobs`)
+      at = o;
+    }
+    hs[(size_t)S * g] = (int32_t)at;
+    for (int64_t i = 0; i < n_jobs; ++i) {
+      const RaVoiceJob &j = hj[i];
+      if (j.state_out >= 0 || (j.begin + j.n - 1) / L > j.begin / L) ho[n_work++] = (int32_t)i;
+    }
+    std::sort(ho, ho + n_work, [hj](int32_t a, int32_t b) { return hj[a].n > hj[b].n; });
   }
-  if (!flat.empty()) HIP_TRY(hipMemcpy(v->ev, flat.data(), sizeof(RaVoiceEv) * flat.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(v->ev_begin, begin.data(), sizeof(int32_t) * begin.size(), hipMemcpyHostToDevice));
-  ra_voice_launch(v->p, v->state, v->ev, v->ev_begin, v->dropped, S, v->t, n, d_out, nullptr);
+  // ---- device buffers, copies, launches ----
+  RA_TRY(voice_grow(&v->d_jobs, v->jobs_cap, n_jobs + 1, v->stream));
+  static_assert(sizeof(RaVoiceJob) == 104, "layout of the job record");
+  RA_TRY(voice_grow(&v->d_order, v->order_cap, n_jobs + 1, v->stream));
+  RA_TRY(voice_grow(&v->d_slot_begin, v->slots_cap, n_slots, v->stream));
+  const int cur = v->parity, prev = cur ^ 1;
+  RA_TRY(voice_grow(&v->d_states[cur], v->states_cap[cur], n_states + 1, v->stream));
+  if (!v->d_states[prev]) RA_TRY(voice_grow(&v->d_states[prev], v->states_cap[prev], 1, v->stream));
+  if (n_jobs) HIP_TRY(hipMemcpyAsync(v->d_jobs, hj, bytes_jobs, hipMemcpyHostToDevice, v->stream));
+  HIP_TRY(hipMemcpyAsync(v->d_slot_begin, hs, bytes_slots, hipMemcpyHostToDevice, v->stream));
+  if (n_work) HIP_TRY(hipMemcpyAsync(v->d_order, ho, sizeof(int32_t) * (size_t)n_work, hipMemcpyHostToDevice, v->stream));
+  {
+    ra_voice::Staging &sg = v->staging[v->stage_parity];
+    HIP_TRY(hipEventRecord(sg.done, v->stream));
+    sg.used = true;
+    v->stage_parity ^= 1;
+  }
+  ra_voice::Timed tm{nullptr, nullptr, nullptr};
+  if (v->profiling) {
+    hipEvent_t *evs[3] = {&tm.a, &tm.b, &tm.c};
+    for (auto *pe : evs) {
+      if (!v->ev_pool.empty()) { *pe = v->ev_pool.back(); v->ev_pool.pop_back(); }
+      else HIP_TRY(hipEventCreate(pe));
+    }
+    HIP_TRY(hipEventRecord(tm.a, v->stream));
+  }
+  ra_voice_launch_pre(v->p, v->d_jobs, v->d_order, (int)n_work, v->d_states[prev], v->d_states[cur], L, v->stream);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
+  if (v->profiling) HIP_TRY(hipEventRecord(tm.b, v->stream));
+  if (ra_voice_launch_render(v->p, v->d_jobs, v->d_slot_begin, v->d_states[prev], v->d_states[cur], S, n, L, g_log2, d_out, v->stream) != 0)
+    return fail(RA_EHIP, "ra_voice: hipFuncSetAttribute(render)");
+  HIP_TRY(hipGetLastError());
+  if (v->profiling) { HIP_TRY(hipEventRecord(tm.c, v->stream)); v->timed.push_back(tm); ++v->launches[0]; ++v->launches[1]; }
+  v->parity ^= 1;
   v->t += n;
   return RA_OK;
 }
+} // namespace
 
-int ra_voice_process_device(ra_voice *v, int64_t n, float *d_out) {
+int ra_voice_process_device_async(ra_voice *v, int64_t n, float *d_out) {
   if (!v) return fail(RA_EINVAL, "null context");
   if (n < 0 || (n > 0 && !d_out)) return fail(RA_EINVAL, "bad output");
   if (n == 0) return RA_OK;
   return voice_block(v, n, d_out);
+}
+
+int ra_voice_process_device(ra_voice *v, int64_t n, float *d_out) {
+  RA_TRY(ra_voice_process_device_async(v, n, d_out));
+  if (n > 0) HIP_TRY(hipStreamSynchronize(v->stream));
+  return RA_OK;
 }
 
 int ra_voice_process_host(ra_voice *v, int64_t n, float *h_out) {
@@ -1869,25 +2078,40 @@ int ra_voice_process_host(ra_voice *v, int64_t n, float *h_out) {
   HIP_TRY(hipSetDevice(v->device));
   const int S = v->n_streams;
   if (n > v->out_cap) {
+    HIP_TRY(hipStreamSynchronize(v->stream));
     (void)hipFree(v->out);
     v->out = nullptr;
     v->out_cap = n;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&v->out), sizeof(float) * 2 * static_cast<size_t>(S) * n));
   }
   if (int r = voice_block(v, n, v->out)) return r;
-  HIP_TRY(hipMemcpy(h_out, v->out, sizeof(float) * 2 * static_cast<size_t>(S) * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpyAsync(h_out, v->out, sizeof(float) * 2 * static_cast<size_t>(S) * n, hipMemcpyDeviceToHost, v->stream));
+  HIP_TRY(hipStreamSynchronize(v->stream));
   return RA_OK;
 }
 
 int64_t ra_voice_dropped_note_ons(ra_voice *v) {
   if (!v) return fail(RA_EINVAL, "null context");
-  if (!v->serial) return v->dropped_host;
+  return v->dropped;
+}
+
+int ra_voice_get_kernel_ms(ra_voice *v, double *ms2, int64_t *launches2, int32_t reset) {
+  if (!v) return fail(RA_EINVAL, "null context");
   HIP_TRY(hipSetDevice(v->device));
-  std::vector<int32_t> d(v->n_streams);
-  HIP_TRY(hipMemcpy(d.data(), v->dropped, sizeof(int32_t) * d.size(), hipMemcpyDeviceToHost));
-  int64_t tot = 0;
-  for (int32_t x : d) tot += x;
-  return tot;
+  HIP_TRY(hipStreamSynchronize(v->stream));
+  for (auto &t : v->timed) {
+    float a = 0.f, b = 0.f;
+    HIP_TRY(hipEventElapsedTime(&a, t.a, t.b));
+    HIP_TRY(hipEventElapsedTime(&b, t.b, t.c));
+    v->ms[0] += a; v->ms[1] += b;
+    v->ev_pool.push_back(t.a); v->ev_pool.push_back(t.b); v->ev_pool.push_back(t.c);
+  }
+  v->timed.clear();
+  if (ms2) { ms2[0] = v->ms[0]; ms2[1] = v->ms[1]; }
+  if (launches2) { launches2[0] = v->launches[0]; launches2[1] = v->launches[1]; }
+  if (reset) { v->ms[0] = v->ms[1] = 0; v->launches[0] = v->launches[1] = 0; }
+  v->profiling = true; // (the first call switches the per-block events on)
+  return RA_OK;
 }
 
 } // extern "C"

@@ -270,27 +270,31 @@ struct RaSpan {
   int64_t seg0;       // first slot of this chunk's nfb + 1 segments in seg_sd / seg_si
 };
 
-// ---- gen.voice, SWEEP mode (ra_voice.hip) ----
+// ---- gen.voice (ra_voice.hip; the host half is ra_voice_host.hpp) ----
 struct RaVoiceParams {
-  int sample_rate, P;
-  int envA, envR, xfade_len;       // setAHDSR(AHDSR{xfade_len, 0, 0, xfade_len, 1.}) and setEnvelopeCharacTime
-  double inc_low, inc_high;        // freq_to_angle_increment<float>(LOW_FREQ / HIGH_FREQ), widened
-  double n_frames, start_sample;   // the ramp spec's duration and start (phase_ratio1 * n_frames = 0 in SWEEP mode)
-  double base_volume;              // Element::baseVolume
-  float sine_gain, log_ratio, max_db, pan;
-  int random_pan;
-  uint64_t seed;
+  int sample_rate;
+  float sine_gain, log_ratio, max_db;
   float loud_freqs[29], loud_elv[29]; // include/loudness.h:9-39 and the equal-loudness row of the configured level (:199-216)
 };
-struct RaVoiceEv { int64_t sample, noteid; int32_t type, pad; float freq, vel; };
-size_t ra_voice_state_bytes();
-void ra_voice_launch_init(void *state, int count, hipStream_t st);
-size_t ra_voice_note_bytes();
-int ra_voice_probe_done2(const RaVoiceParams &p, int *d_scratch); // steps until the ramp's envelope is finished (-1: error)
-void ra_voice_launch_notes(const RaVoiceParams &p, const void *slots_in, void *slots_out, const void *notes, int n_notes, int n_streams, int64_t t0, int64_t n, double *accum, float *d_out,
-                           hipStream_t st);
-void ra_voice_launch(const RaVoiceParams &p, void *state, const RaVoiceEv *ev, const int32_t *ev_begin, int32_t *dropped, int n_streams, int64_t t0, int64_t n,
-                     float *d_out, hipStream_t st);
+// One ramp of one note inside one block (a job): the LogRamp spec, the output factors, the envelope's three integers, where its samples
+// lie in the block, and the state slots the two kernels exchange.
+struct RaVoiceJob {
+  double from, to, dur, cur0;   // LogRamp::setup(from, to, duration, start sample)
+  double vol, fL, fR;           // the ramp's volume (spec volume); Element::baseVolume * velocity * the note's stereo gains
+  int32_t begin, n;             // block-relative frame of the first step taken in this block; steps taken in this block
+  int32_t j0;                   // index (1-based) of that first step within the ramp
+  int32_t T, A, R;              // steps until the key release; attack and release lengths
+  int32_t interp;               // ra_itp
+  int32_t state_in;             // slot (previous block's buffer) of the state before step j0, -1: j0 == 1
+  int32_t state_tiles;          // first slot (this block's buffer) of the states at the tile boundaries the job crosses
+  int32_t state_out;            // slot (this block's buffer) for the state after the block's last step, -1: the job ends in this block
+  int32_t stream, slot;
+};
+struct RaVoiceState { double cur, theta, y; int32_t swapped, loud_k; };
+void ra_voice_launch_pre(const RaVoiceParams &p, const RaVoiceJob *jobs, const int32_t *order, int n_work, const RaVoiceState *st_prev, RaVoiceState *st_cur, int L,
+                         hipStream_t st);
+int ra_voice_launch_render(const RaVoiceParams &p, const RaVoiceJob *jobs, const int32_t *slot_begin, const RaVoiceState *st_prev, const RaVoiceState *st_cur, int n_streams,
+                           int64_t n, int L, int g_log2, float *d_out, hipStream_t st);
 
 // launchers (defined next to their kernels)
 void ra_launch_analysis(const RaParams &p, const RaBuffers &b, const float *d_voice, int64_t t0, int64_t n, int64_t f_lo, int64_t fb0, int64_t nfb_chunk,

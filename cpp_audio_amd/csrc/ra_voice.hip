@@ -1,20 +1,29 @@
-// K9 — gen.voice, SWEEP mode (first slice): voice::Impl_<..., Mode::SWEEP, ...> (reference include/gen.voice.h:1087-1190)
-// = ImplCRTP::compute / onEvent (include/gen.crtp.h:350-622; SynchronizePhase::No, DefaultStartPhase::Zero) over
-// VolumeAdjusted<SoundEngine<SWEEP, 2, ...>> (include/soundengine.h:240-1127), its ramps being
+// K9 — gen.voice: voice::Impl_<..., MODE, ...> (reference include/gen.voice.h:1087-1190) = ImplCRTP::compute / onEvent
+// (include/gen.crtp.h:350-622) over VolumeAdjusted<SoundEngine<MODE, 2, ...>> (include/soundengine.h:240-1127), MODE = SWEEP, BIRDS, ROBOTS,
+// the engine's ramps being
 //   StereoPanned<VolumeAdjusted<Enveloped<FreqCtrl_<Mix<LoudnessVolumeAdjusted<SineOscillatorAlgo<double>>>, LogRamp<double>>, AHDSREnvelope>>>.
 //
-// The same skeleton as the other synth kernels: one workgroup per stream, lane = channel, samples in order in 16-sample tiles, the
-// channels summed in channel order.  What SWEEP reduces the sound engine to (the CPU restatement keeps the general shape):
-//   * the Markov chain of create_sweep (soundengine.h:697-720) is one certain transition whose LEAVE lambda builds the single ramp spec,
-//     and both mersenne<> draws on the way are inert (min_exp == max_exp): initialize_sweep is deterministic arithmetic, done at note-on;
-//   * of the engine's three ramps only one ever plays: get_ramps (:275-290) hands playNextSpec the LAST finished ramp, all three are
-//     finished when a note starts, and a SWEEP note has one spec — a lane carries that one ramp;
-//   * reference behaviour kept as it is: Mix::angleIncrements() never exceeds 0 (audioelement.h:1856-1865), so the volume filters see
-//     the control's `from`; a note-off silences the element at once and leaves its ramp unfinished (soundengine.h:345-353), which
-//     makes the channel unavailable for good (isEnvelopeFinished_internal, :457-467).
-// Per sample a ramp costs a sincos (the increment moves every sample), a float pow (the equal-loudness volume, include/loudness.h:246-274)
-// and three one-pole updates with re-derived coefficients: ~300 instructions on one wave per stream — correct first, not yet fast.
-#include "ra_chan.cuh"
+// What a ramp is, once the host has run the note's Markov chain and the orchestration's schedule (ra_voice_host.hpp): a JOB — a LogRamp
+// spec, a start frame, an envelope given by three integers — whose samples depend on nothing but the job:
+//   * playNextSpec (soundengine.h:776-803) makes the ramp's state afresh: the control is copied from the spec, forgetPastSignals, start
+//     angle 0 (DefaultStartPhase::Zero), an AHDSR{xfade_len, 0, 0, xfade_len, 1} whose minimum change duration nobody sets;
+//   * the ramp's own VolumeAdjusted and the element's outer one are fed a constant target from their first step on: y + k (target - y)
+//     stays the target exactly, whatever k — they are constants (spec volume; Element::baseVolume * velocity);
+//   * the envelope's value is a function of the step index j: j / A up to 1 while pressed (T steps), top (1 - m / R) after the release;
+//   * the oscillator's phasor after step j is polar(pi * (inc_1 + ... + inc_j)) up to its renormalisation: the phase is a running sum;
+//   * what does carry state from sample to sample: LogRamp's warped time `cur` (audioelement.h:2522-2542), that phase sum, and the
+//     loudness volume's one-pole, whose coefficient follows the increment (LoudnessVolumeAdjusted, :1275-1317 over :1195-1216).
+// So a block runs as two kernels:
+//   pre-pass  one lane per job, samples in order, only that three-number recurrence (no oscillator, no envelope, no output): it leaves
+//             the state at every tile boundary the job crosses (tile = 256 frames) and at the block's end (carried to the next block);
+//   render    one wavefront per group of (stream, tile) units; a lane = one SLOT of a unit — the host packs a stream's jobs into
+//             g = 2^k slots such that the jobs of a slot never overlap — steps the slot's jobs through the tile from the stored states with
+//             the very same recurrence code, adds oscillator, envelope and gains, and the wave sums the slots of each unit in slot order:
+//             every output sample is written once, by a fixed-order sum (bit-reproducible; no atomics).
+// Reference behaviour kept as it is: Mix::angleIncrements() never exceeds 0 (audioelement.h:1856-1865) — it only ever reaches the two
+// constant volume filters; a note-off silences the element at once (soundengine.h:345-353) — the host cuts the note's jobs there;
+// LogRamp's constant is 1.f when from == to (:2570).
+#include "ra_internal.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -22,29 +31,18 @@ extern __shared__ __align__(16) unsigned char ra_smem_voice[];
 
 namespace {
 
-struct VoiceChan {
-  Chan c;   // the ramp: envelope, sine oscillator (cre, cim, mre, mim, alias, inc), its own volume filter (vol, target, finit, k, y, flags), gains
-  // LogRamp (audioelement.h:2464-2572)
-  double lr_from, lr_to, lr_cur, lr_dur, lr_C, lr_inv; // lr_inv = 1 / lr_dur
-  // the loudness adjustment's BaseVolumeAdjusted
-  double l_vol, l_target, l_finit, l_k, l_y;
-  // the outer VolumeAdjusted<SoundEngine>
-  double o_vol, o_target, o_finit, o_k, o_y;
-  // the single ramp spec (RampSpecs, soundengine.h:1046-1120)
-  double sp_from, sp_to, sp_dur, sp_cur, sp_C;
-  double start_angle;
-  int64_t noteid;
-  int oddOn, rt_active, spec_it, spec_end, remaining_silence, l_has, o_has, loud_k; // loud_k: the loudness table interval the sweep is in
+constexpr int TS = 8; // samples a lane parks in LDS before the wave sums the slots
+
+struct Ramp { // the registers of a lane while it steps a job
+  double cur, from, to, dur, inv_dur, C, l2r; // LogRamp; l2r = log2(to / from) (PROPORTIONAL_VALUE_DERIVATIVE only)
+  double theta, y;                            // phase sum (units of pi, kept in [0, 2)); the loudness volume
+  int interp, loud_k, swapped;
 };
 
-__device__ inline bool ramp_rt_active(const VoiceChan &v) { return rt_active(v.c); }
-__device__ inline bool engine_finished(const VoiceChan &v) { return !(v.oddOn & 1) && !ramp_rt_active(v); } // isEnvelopeFinished_internal
-__device__ inline bool elem_rt_active(const VoiceChan &v) { return v.rt_active && !engine_finished(v); }
-
 // loudness::equal_loudness_volume_from_freq, include/loudness.h:246-274 over :157-186 (float arithmetic).  The reference finds the table
-// interval by bisection on every call; a sweep moves through the 29 frequencies in order, so the interval of the previous sample is
-// carried in `k` (freqs[k] <= freq < freqs[k + 1], clamped to 0 .. 27) and walked: the same interval, a step or two per note.  The final
-// powf(10, x) runs as exp2f(x log2 10): a float ulp or two from the reference's pow on a gain (tolerance 1e-5).
+// interval by bisection on every call; a ramp moves through the 29 frequencies in order, so the interval of the previous sample is
+// carried in `k` (freqs[k] <= freq < freqs[k + 1], clamped to 0 .. 27) and walked: the same interval.  The final powf(10, x) runs as
+// exp2f(x log2 10): a float ulp or two from the reference's pow on a gain.
 __device__ inline float loudness_volume(const RaVoiceParams &p, const float *__restrict__ lf, const float *__restrict__ le, float freq, int &k) {
   k = min(max(k, 0), 27);
   while (k < 27 && freq >= lf[k + 1]) ++k;
@@ -59,352 +57,271 @@ __device__ inline float loudness_volume(const RaVoiceParams &p, const float *__r
   return exp2f((p.log_ratio * (db - p.max_db) / 20.f) * 3.32192809488736f);
 }
 
-// FreqCtrl_::angleIncrements (audioelement.h:3117-3124) over Mix::angleIncrements (:1856-1865)
-__device__ inline double ramp_angle_increments(const RaVoiceParams &p, const VoiceChan &v) {
-  double minAngle = 0;
-  if (p.sine_gain != 0.f) minAngle = fmin(minAngle, v.c.inc);
-  if (minAngle != 0.) return minAngle;
-  return v.lr_from;
-}
-__device__ inline double one_pole_k(double inc_abs) { // a / (1 + a), a = pi inc: v_rcp_f64 and two Newton steps instead of the IEEE division (an ulp)
+__device__ inline double one_pole_k(double inc_abs) { // a / (1 + a), a = pi inc (Filter<LOW_PASS>): v_rcp_f64 and two Newton steps (an ulp)
   const double a = M_PI * inc_abs, d = 1.0 + a;
   double r = __builtin_amdgcn_rcp(d);
   r = r * fma(-d, r, 2.0);
   r = r * fma(-d, r, 2.0);
   return a * r;
 }
-__device__ inline void one_pole_volume(int &has, double &vol, double target, double &finit, double &k, double &y, double inc_abs) { // BaseVolumeAdjusted::step :1195-1216
-  if (!has) {
-    finit = inc_abs;
-    k = one_pole_k(finit);
-    y = target;
-    has = 1;
-  } else if (vol != target) {
-    if (finit != inc_abs) { finit = inc_abs; k = one_pole_k(finit); }
+
+// itp::interpolate(kind, t, b, c, d) as decided (Penner's equations): every one of them is b + c g(t / d)
+__device__ inline double ease01(int kind, double u, double l2r) {
+  switch (kind) {
+    case RA_ITP_EASE_IN_QUAD: return u * u;
+    case RA_ITP_EASE_OUT_QUAD: return -u * (u - 2.0);
+    case RA_ITP_EASE_INOUT_QUAD: { const double v = 2.0 * u; if (v < 1.0) return 0.5 * v * v; const double w = v - 1.0; return -0.5 * (w * (w - 2.0) - 1.0); }
+    case RA_ITP_EASE_IN_CUBIC: return u * u * u;
+    case RA_ITP_EASE_OUT_CUBIC: { const double w = u - 1.0; return w * w * w + 1.0; }
+    case RA_ITP_EASE_INOUT_CUBIC: { const double v = 2.0 * u; if (v < 1.0) return 0.5 * v * v * v; const double w = v - 2.0; return 0.5 * (w * w * w + 2.0); }
+    case RA_ITP_EASE_IN_QUART: { const double u2 = u * u; return u2 * u2; }
+    case RA_ITP_EASE_OUT_QUART: { const double w = u - 1.0, w2 = w * w; return -(w2 * w2 - 1.0); }
+    case RA_ITP_EASE_INOUT_QUART: { const double v = 2.0 * u; if (v < 1.0) { const double v2 = v * v; return 0.5 * v2 * v2; } const double w = v - 2.0, w2 = w * w; return -0.5 * (w2 * w2 - 2.0); }
+    case RA_ITP_EASE_IN_QUINT: { const double u2 = u * u; return u2 * u2 * u; }
+    case RA_ITP_EASE_OUT_QUINT: { const double w = u - 1.0, w2 = w * w; return w2 * w2 * w + 1.0; }
+    case RA_ITP_EASE_INOUT_QUINT: { const double v = 2.0 * u; if (v < 1.0) { const double v2 = v * v; return 0.5 * v2 * v2 * v; } const double w = v - 2.0, w2 = w * w; return 0.5 * (w2 * w2 * w + 2.0); }
+    case RA_ITP_EASE_IN_SINE: return 1.0 - cospi(0.5 * u);
+    case RA_ITP_EASE_OUT_SINE: return sinpi(0.5 * u);
+    case RA_ITP_EASE_INOUT_SINE: return -0.5 * (cospi(u) - 1.0);
+    case RA_ITP_EASE_IN_EXPO: return (u == 0.0) ? 0.0 : exp2(10.0 * (u - 1.0));
+    case RA_ITP_EASE_OUT_EXPO: return (u == 1.0) ? 1.0 : 1.0 - exp2(-10.0 * u);
+    case RA_ITP_EASE_INOUT_EXPO: {
+      if (u == 0.0) return 0.0;
+      if (u == 1.0) return 1.0;
+      const double v = 2.0 * u;
+      if (v < 1.0) return 0.5 * exp2(10.0 * (v - 1.0));
+      return 0.5 * (2.0 - exp2(-10.0 * (v - 1.0)));
+    }
+    case RA_ITP_EASE_IN_CIRC: return -(sqrt(1.0 - u * u) - 1.0);
+    case RA_ITP_EASE_OUT_CIRC: { const double w = u - 1.0; return sqrt(1.0 - w * w); }
+    case RA_ITP_EASE_INOUT_CIRC: { const double v = 2.0 * u; if (v < 1.0) return -0.5 * (sqrt(1.0 - v * v) - 1.0); const double w = v - 2.0; return 0.5 * (sqrt(1.0 - w * w) + 1.0); }
+    default: return u;
   }
-  y = y + k * (target - y);
-  vol = y;
 }
 
-// SineOscillatorAlgo::setAngleIncrements (audioelement.h:2404-2411) on a sweep: the increment moves a little every sample, so the rotation
-// (cos, sin)(pi f) follows it by the small angle pi (f - f_prev) (fifth-order series, |d| ~ 1e-4: exact to rounding) instead of a sincos
-// per sample, and the anti-aliasing gain (:466-483) only divides where it is not 0 or 1.
-__device__ inline void voice_osc_set_inc(Chan &c, double f) {
-  if (c.inc == f) return;
-  const double d = M_PI * (f - c.inc);
-  if (c.inc != 0. && fabs(d) < 1e-2) {
-    const double d2 = d * d;
-    const double sd = d * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0), cd = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
-    const double mr = fma(c.mre, cd, -(c.mim * sd)), mi = fma(c.mre, sd, c.mim * cd);
-    c.mre = mr; c.mim = mi;
-  } else {
-    double sn, cs;
-    sincos(M_PI * f, &sn, &cs);
-    c.mre = cs; c.mim = sn;
-  }
-  c.inc = f;
-  c.alias = (f == 0.) ? 1. : (f > 1.) ? 0. : (f < 0.25 && f > 0.) ? 1. : alias_mult(f);
+// LogRamp::do_step (audioelement.h:2522-2542): the increment of this step; `cur` moves on by C times the increment half a sample later.
+// The two divisions by the ramp's constant duration are multiplications by its reciprocal (an ulp on the increment).
+__device__ inline double ramp_inc(Ramp &r) {
+  if (r.cur + 0.5 > r.dur) { r.cur = 0.0; const double t = r.from; r.from = r.to; r.to = t; r.l2r = -r.l2r; r.swapped ^= 1; }
+  const double d = r.to - r.from, u = r.cur * r.inv_dur;
+  double inc;
+  if (r.interp == RA_ITP_LINEAR) inc = fma(d, u, r.from);
+  else if (r.interp == RA_ITP_PROPORTIONAL_VALUE_DERIVATIVE) inc = r.from * exp2(u * r.l2r);
+  else inc = fma(d, ease01(r.interp, u, r.l2r), r.from);
+  const double f = fma(d, (r.cur + 0.5) * r.inv_dur, r.from);
+  r.cur = fma(r.C, f, r.cur);
+  return inc;
 }
 
-// One step of a sounding element (ImplCRTP::compute, gen.crtp.h:352-371, for one channel): SoundEngine::step, the outer volume, imag.
-__device__ inline void voice_step(VoiceChan &v, const RaVoiceParams &p, const float *__restrict__ lf, const float *__restrict__ le, const RaEnvParams &ep, double &vL,
-                                  double &vR) {
- // ImplCRTP::compute, gen.crtp.h:352-371
-  // ---- SoundEngine::step: orchestrate_algos (soundengine.h:741-773) ----
-  if (v.spec_it != v.spec_end) {
-    const bool has_cur = v.spec_it >= 0 && v.spec_it < v.spec_end; // (silenceAfter is true for a SWEEP spec)
-    bool play = true;
-    if (v.c.state == ENV_PRESSED) {
-      const int remaining = v.c.reldelay; // countStepsToRelease
-      if (remaining > 0) play = false;
-      else if (remaining == 0 && has_cur) v.remaining_silence = 0; // articulative_pause_length: never set in SWEEP mode, taken as 0
-    }
-    if (play && has_cur && v.remaining_silence > 0) { --v.remaining_silence; play = false; }
-    if (play && (v.oddOn & 1)) { // playNextSpec :775-801: a finished ramp exists (two of the three never play)
-      ++v.spec_it;
-      if (v.spec_it != v.spec_end) {
-        v.lr_from = v.sp_from; v.lr_to = v.sp_to; v.lr_dur = v.sp_dur; v.lr_cur = v.sp_cur; v.lr_C = v.sp_C; v.lr_inv = 1.0 / v.sp_dur;
-        chan_forget_past_signals(v.c); v.l_has = 0;     // new_ramp->forgetPastSignals()
-        { double sn, cs; sincos(M_PI * v.start_angle, &sn, &cs); v.c.cre = cs; v.c.cim = sn; } // setStartAngle
-        v.c.target = (double)1.f;                       // spec volume (setVolume never called in SWEEP: 1.f)
-        v.c.state = ENV_SOON;                           // tryAcquire
-        const int time_to_release = (int)(.5f + v.lr_dur) - p.xfade_len;
-        env_on_key_pressed(v.c, 0);
-        env_on_key_released(v.c, max(time_to_release, 0));
-      }
-    }
-  }
-  // ---- step_algos (:423-436): the ramp steps unless it is finished ----
-  if (v.c.state != ENV_DONE2) {
-    env_step(v.c, ep);
-    double inc;
-    { // LogRamp::do_step, audioelement.h:2522-2542
-      if (v.lr_cur + (double).5f > v.lr_dur) { v.lr_cur = 0; const double tmp = v.lr_from; v.lr_from = v.lr_to; v.lr_to = tmp; }
-      const double inv_dur = v.lr_inv; // the two divisions by the note's constant duration as multiplications (an ulp on the increment)
-      inc = v.lr_from + (v.lr_to - v.lr_from) * (v.lr_cur * inv_dur);
-      const double f = v.lr_from + (v.lr_to - v.lr_from) * ((v.lr_cur + (double).5f) * inv_dur);
-      v.lr_cur += v.lr_C * f;
-    }
-    // Mix::setAngleIncrements -> LoudnessVolumeAdjusted::setAngleIncrements (:1291-1298) -> SineOscillatorAlgo::setAngleIncrements
-    v.l_target = (double)loudness_volume(p, lf, le, (float)(inc * 0.5 * (double)p.sample_rate), v.loud_k);
-    voice_osc_set_inc(v.c, inc);
-    { // SineOscillatorAlgo::step
-      const double re = v.c.cre * v.c.mre - v.c.cim * v.c.mim, im = v.c.cre * v.c.mim + v.c.cim * v.c.mre;
-      const double g = 0.5 * (3.0 - (re * re + im * im));
-      v.c.cre = re * g; v.c.cim = im * g;
-    }
-    one_pole_volume(v.l_has, v.l_vol, v.l_target, v.l_finit, v.l_k, v.l_y, fabs(v.c.inc));
-    int has = (v.c.flags & FL_HAS_VOL) ? 1 : 0;
-    one_pole_volume(has, v.c.vol, v.c.target, v.c.finit, v.c.k, v.c.y, fabs(ramp_angle_increments(p, v)));
-    v.c.flags |= FL_HAS_VOL;
-  }
-  // ---- the outer BaseVolumeAdjusted::step: SoundEngine::angleIncrements (:407-421) is the sounding ramp's, else 0 ----
-  const bool sounding = v.c.state == ENV_RELEASED || v.c.state == ENV_PRESSED;
-  one_pole_volume(v.o_has, v.o_vol, v.o_target, v.o_finit, v.o_k, v.o_y, sounding ? fabs(ramp_angle_increments(p, v)) : 0.0);
-  if (elem_rt_active(v) && sounding) {
-    double sum = 0.f;                                             // Mix::imag :1867-1873
-    sum += (double)p.sine_gain * (v.l_vol * (v.c.alias * v.c.cim));
-    const double mono = v.c.vol * (sum * v.c.value);             // ramp: VolumeAdjusted over Enveloped
-    vL = v.o_vol * (0.0 + v.c.gL * mono);                        // SoundEngine::imag(i): v{} += r.imag(i); BaseVolumeAdjusted::imag(i)
-    vR = v.o_vol * (0.0 + v.c.gR * mono);
-  }
-      }
-
-constexpr int VT = 16;
-
-__global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_voice_kernel(RaVoiceParams p, VoiceChan *__restrict__ state, const RaVoiceEv *__restrict__ ev,
-                                                                   const int32_t *__restrict__ ev_begin, int32_t *__restrict__ dropped_out, int64_t t0,
-                                                                   int64_t n, float *__restrict__ out) {
-  const int s = blockIdx.x, l = threadIdx.x, Ppad = blockDim.x, P = p.P;
-  double *tile = reinterpret_cast<double *>(ra_smem_voice);       // [Ppad][2 * VT + 1]
-  int *xi = reinterpret_cast<int *>(tile + (size_t)Ppad * (2 * VT + 1));
-  float *lf = reinterpret_cast<float *>(xi + 4), *le = lf + 29; // the loudness tables (a dynamically indexed kernel-argument array would live in scratch)
-  if (l < 29) { lf[l] = p.loud_freqs[l]; le[l] = p.loud_elv[l]; }
-  __syncthreads();
-  VoiceChan v = state[(size_t)s * Ppad + l];
-  const RaEnvParams ep = {p.envA, 0, 0, p.envR, 0.f}; // setAHDSR(AHDSR{xfade_len, LINEAR, 0, 0, LINEAR, xfade_len, LINEAR, 1.}), soundengine.h:790
-  int e = ev_begin[s];
-  const int e_end = ev_begin[s + 1];
-  int dropped = 0;
-  constexpr int64_t kNever = 0x7fffffffffffffffll;
-  int64_t next_ev = (e < e_end) ? ev[e].sample : kNever;
-  float *o = out + (size_t)s * n * 2;
-  int64_t t = t0;
-  const int64_t t_end = t0 + n;
-  while (t < t_end) {
-    if (next_ev <= t) { // Impl_::doProcessing (gen.voice.h:1159-1165): the events of this frame reach the synth before out.step
-      const RaVoiceEv q = ev[e];
-      ++e;
-      next_ev = (e < e_end) ? ev[e].sample : kNever;
-      if (l == 0) xi[0] = 0x7fffffff;
-      __syncthreads();
-      if (q.type == 0) { // onEvent(NoteOn), gen.crtp.h:389-449 + one-shot :455-527
-        if (l < P && engine_finished(v)) atomicMin(&xi[0], l); // SoundEngine::tryAcquire :291-308
-        __syncthreads();
-        const int sel = xi[0];
-        if (sel == 0x7fffffff) { if (l == 0) ++dropped; }
-        else if (l == sel) {
-          ++v.oddOn;
-          v.noteid = q.noteid;
-          v.remaining_silence = 0; v.start_angle = 0; v.o_has = 0;                 // forgetPastSignals: VolumeAdjusted + SoundEngine :314-317
-          v.o_target = p.base_volume * (double)q.vel;                               // Element::baseVolume * velocity, gen.crtp.h:425
-          // setupAudioElement (gen.voice.h:883-1003): parameters are uniform; the pan is per note
-          {
-            const float pan_f = p.random_pan ? hash_uniform_pm1(p.seed + (uint64_t)s, (uint64_t)q.noteid, 3) : p.pan;
-            double pan = (double)pan_f;
-            pan = fmin(pan, 1.); pan = fmax(pan, -1.);
-            const double ang = (0.25 * M_PI) * (pan + 1.);
-            v.c.gL = cos(ang); v.c.gR = sin(ang);                                   // stereo(), include/stereo.h:18-27
-          }
-          // engine.setAngleIncrements (soundengine.h:403-405) + initialize_sweep (:905-918) -> do_initialize (:1001-1044) -> node 0's LEAVE
-          // lambda (:700-713); base_freq > 0 and n_frames > 0 were checked on the host
-          v.spec_it = -1; v.spec_end = 1;
-          v.sp_from = p.inc_low; v.sp_to = p.inc_high; v.sp_dur = p.n_frames; v.sp_cur = p.start_sample;
-          v.sp_C = (v.sp_to == v.sp_from) ? (double)1.f : -log(v.sp_from / v.sp_to) / (v.sp_to - v.sp_from);
-          // the one-shot: setPhase = setStartAngle(0) (DefaultStartPhase::Zero), onKeyPressed (soundengine.h:333-337)
-          v.start_angle = 0;
-          v.rt_active = 1;
-        }
-      } else { // NoteOff one-shot, gen.crtp.h:541-588
-        if (l < P && v.noteid == q.noteid) atomicMin(&xi[0], l);
-        __syncthreads();
-        if (l == xi[0] && (v.oddOn & 1)) { // canHandleExplicitKeyReleaseNow = goOn(); onKeyReleased :345-353
-          v.rt_active = 0;
-          ++v.oddOn;                                         // stop(i)
-          env_on_key_released(v.c, 0);                       // every ramp's onKeyReleased: only a KeyPressed one reacts
-        }
-      }
-      __syncthreads();
-      continue;
-    }
-    const int64_t seg_end = min(t_end, next_ev);
-    if (!__syncthreads_or(l < P && elem_rt_active(v))) {
-      for (int64_t r = (t - t0) * 2 + l; r < (seg_end - t0) * 2; r += blockDim.x) o[r] = 0.f;
-      t = seg_end;
-      continue;
-    }
-    const int m = (int)min((int64_t)VT, seg_end - t);
-    double *mine = tile + (size_t)l * (2 * VT + 1);
-    for (int i = 0; i < m; ++i) {
-      double vL = 0.0, vR = 0.0;
-      if (l < P && elem_rt_active(v)) voice_step(v, p, lf, le, ep, vL, vR);
-      mine[i] = vL; mine[VT + i] = vR;
-    }
-    __syncthreads();
-    if (l < 2 * m) { // buffer[2 i + j] += c.elem.imag(j), channels in index order; then the float cast of SimpleAudioOutContext::step
-      const int fr = l >> 1, ch = l & 1;
-      double acc = 0.0;
-      for (int q = 0; q < P; ++q) acc += tile[(size_t)q * (2 * VT + 1) + ch * VT + fr];
-      o[(t - t0 + fr) * 2 + ch] = (float)acc;
-    }
-    __syncthreads();
-    t += m;
-  }
-  state[(size_t)s * Ppad + l] = v;
-  if (l == 0 && dropped) dropped_out[s] += dropped;
+// One step of what carries state: the increment, the phase sum, the loudness volume (LoudnessVolumeAdjusted::setAngleIncrements
+// :1291-1298, BaseVolumeAdjusted::step :1195-1216: the filter starts at its first target; its coefficient is re-derived from the
+// increment whenever the volume still differs from the target — when it does not, the coefficient does not matter).
+__device__ inline double ramp_advance(Ramp &r, const RaVoiceParams &p, const float *__restrict__ lf, const float *__restrict__ le, bool first) {
+  const double inc = ramp_inc(r);
+  double th = r.theta + inc;
+  th -= 2.0 * floor(th * 0.5);
+  r.theta = th;
+  const double tgt = (double)loudness_volume(p, lf, le, (float)(inc * 0.5 * (double)p.sample_rate), r.loud_k);
+  r.y = first ? tgt : fma(one_pole_k(fabs(inc)), tgt - r.y, r.y);
+  return inc;
 }
 
-__global__ void ra_voice_init_kernel(VoiceChan *state, int count) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  VoiceChan v;
-  memset(&v, 0, sizeof(v));
-  chan_init(v.c);
-  v.noteid = -1;
-  state[i] = v;
+__device__ inline void ramp_load(Ramp &r, const RaVoiceJob &J, const RaVoiceState *st) { // st == nullptr: the job's first step is next
+  r.from = J.from; r.to = J.to; r.dur = J.dur; r.inv_dur = 1.0 / J.dur;
+  r.C = (J.to == J.from) ? (double)1.f : -log(J.from / J.to) / (J.to - J.from); // get_linear_proportionality_constant :2560-2571 (symmetric in from / to)
+  r.interp = J.interp;
+  r.l2r = (J.interp == RA_ITP_PROPORTIONAL_VALUE_DERIVATIVE) ? log2(J.to / J.from) : 0.0;
+  if (st) {
+    r.cur = st->cur; r.theta = st->theta; r.y = st->y; r.loud_k = st->loud_k; r.swapped = st->swapped;
+    if (r.swapped) { const double t = r.from; r.from = r.to; r.to = t; r.l2r = -r.l2r; }
+  } else { r.cur = J.cur0; r.theta = 0.0; r.y = 0.0; r.loud_k = 14; r.swapped = 0; }
+}
+__device__ inline void ramp_store(const Ramp &r, RaVoiceState *st) {
+  st->cur = r.cur; st->theta = r.theta; st->y = r.y; st->loud_k = r.loud_k; st->swapped = r.swapped;
 }
 
-
-// ---- one note per lane -------------------------------------------------------------------------------------------------
-// A channel's state is made afresh by its note-on and the first step after it (forgetPastSignals, playNextSpec): a note's samples depend
-// on nothing but the note.  Which channel a note-on gets — or that it is dropped — is integer bookkeeping (a channel is free again iff
-// its note-off came after the ramp's envelope had finished, else it is lost for good), walked on the host (ra_capi.hip); here every
-// note of the block is stepped by a lane of its own, from its stored state if it began in an earlier block, and added into a double
-// accumulation buffer that a second kernel rounds to the float output.  The sum over a frame's notes is an atomic one: its association
-// is not the channel order of the serial kernel (1e-16 relative, a float ulp now and then).
-struct RaVoiceNote { int64_t begin; int64_t noteid; int32_t stream, slot, steps, fresh; float vel; int32_t store; }; // = ra_capi.hip: RaVoiceNoteHost
-
-__global__ void __launch_bounds__(64) ra_voice_notes_kernel(RaVoiceParams p, const VoiceChan *__restrict__ slots_in, VoiceChan *__restrict__ slots_out, const RaVoiceNote *__restrict__ notes,
-                                      int n_notes, int64_t t0, int64_t n, double *__restrict__ accum) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool have = i < n_notes;
-  RaVoiceNote q;
-  if (have) q = notes[i]; else { q.steps = 0; q.slot = 0; q.fresh = 1; q.begin = t0; q.stream = 0; q.noteid = 0; q.vel = 0; q.store = 0; }
-  const RaEnvParams ep = {p.envA, 0, 0, p.envR, 0.f};
-  __shared__ float lf[29], le[29]; // (a dynamically indexed kernel-argument array would live in scratch)
+__device__ inline void load_tables(const RaVoiceParams &p, float *lf, float *le) { // (a dynamically indexed kernel-argument array would live in scratch)
   for (int j = threadIdx.x; j < 29; j += blockDim.x) { lf[j] = p.loud_freqs[j]; le[j] = p.loud_elv[j]; }
   __syncthreads();
-  VoiceChan v;
-  if (have && !q.fresh) v = slots_in[q.slot]; // (written by the previous block: the two sets alternate, so a successor on the same channel cannot overwrite it)
-  else { // a free channel, then onEvent(NoteOn) and its one-shot exactly as in the serial kernel
-    v = VoiceChan{};
-    chan_init(v.c);
-    ++v.oddOn;
-    v.noteid = q.noteid;
-    v.remaining_silence = 0; v.start_angle = 0; v.o_has = 0;
-    v.o_target = p.base_volume * (double)q.vel;
-    {
-      const float pan_f = p.random_pan ? hash_uniform_pm1(p.seed + (uint64_t)q.stream, (uint64_t)q.noteid, 3) : p.pan;
-      double pan = (double)pan_f;
-      pan = fmin(pan, 1.); pan = fmax(pan, -1.);
-      const double ang = (0.25 * M_PI) * (pan + 1.);
-      v.c.gL = cos(ang); v.c.gR = sin(ang);
-    }
-    v.spec_it = -1; v.spec_end = 1;
-    v.sp_from = p.inc_low; v.sp_to = p.inc_high; v.sp_dur = p.n_frames; v.sp_cur = p.start_sample;
-    v.sp_C = (v.sp_to == v.sp_from) ? (double)1.f : -log(v.sp_from / v.sp_to) / (v.sp_to - v.sp_from);
-    v.start_angle = 0;
-    v.rt_active = 1;
+}
+
+// ---- pre-pass: the states a block's render needs -------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) ra_voice_pre_kernel(RaVoiceParams p, const RaVoiceJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_work,
+                                                           const RaVoiceState *__restrict__ st_prev, RaVoiceState *__restrict__ st_cur, int L) {
+  __shared__ float lf[29], le[29];
+  load_tables(p, lf, le);
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_work) return;
+  const RaVoiceJob J = jobs[order[w]];
+  Ramp r;
+  ramp_load(r, J, J.state_in >= 0 ? st_prev + J.state_in : nullptr);
+  // steps up to the last state somebody reads: the block's end if the job goes on, else the last tile boundary it crosses
+  const int last = J.begin + J.n; // (exclusive)
+  const int steps = (J.state_out >= 0) ? J.n : ((last - 1) / L) * L - J.begin;
+  int next_b = (J.begin / L + 1) * L; // the next tile boundary
+  int slot = J.state_tiles;
+  int j = J.j0;
+  for (int i = 0; i < steps; ++i, ++j) {
+    if (J.begin + i == next_b) { ramp_store(r, st_cur + slot); ++slot; next_b += L; }
+    ramp_advance(r, p, lf, le, j == 1);
   }
-  // A lane's frames are consecutive in the accumulation buffer, but the lanes of a wave are far apart: one atomic per lane and frame
-  // is 64 cache lines per instruction (29 of 75 ms per 256 synths x 10 s).  So a lane parks NS frames in LDS and the block then adds
-  // every lane's run as one contiguous piece of 2 NS doubles.
-  constexpr int NS = 16;
-  __shared__ double stage[64][2 * NS + 1];
-  __shared__ long long run_base[64];
-  __shared__ int run_steps[64], max_steps;
-  const int tl = threadIdx.x, nt = blockDim.x; // nt = 32 or 64
-  if (tl == 0) max_steps = 0;
-  __syncthreads();
-  run_base[tl] = (long long)(((size_t)q.stream * n + (size_t)(q.begin - t0)) * 2);
-  run_steps[tl] = q.steps;
-  if (q.steps > 0) atomicMax(&max_steps, q.steps);
-  __syncthreads();
-  const int most = max_steps;
-  for (int k0 = 0; k0 < most; k0 += NS) {
-    for (int j = 0; j < NS; ++j) {
-      double vL = 0.0, vR = 0.0;
-      if (k0 + j < q.steps) voice_step(v, p, lf, le, ep, vL, vR);
-      stage[tl][2 * j] = vL; stage[tl][2 * j + 1] = vR;
+  if (J.begin + steps == next_b && J.begin + steps < last) { ramp_store(r, st_cur + slot); } // the boundary the loop ended on
+  if (J.state_out >= 0) ramp_store(r, st_cur + J.state_out);
+}
+
+// ---- render --------------------------------------------------------------------------------------------------------------------------
+// sin(pi x) for x in [0, 2): the device library's sinpi does its own reduction; x is already small
+__device__ inline double osc_imag(double theta) { return sinpi(theta); }
+__device__ inline double alias_gain(double inc) { // freqAliasingMultiplicator, audioelement.h:466-483
+  if (inc == 0.0) return 1.0;
+  if (inc > 0.0 && inc <= 0.25) return 1.0;
+  const double half_n = 1.0 / inc;
+  if (half_n < 1.0) return 0.0;
+  if (half_n > 4.0) return 1.0;
+  return (half_n - 1.0) * (1.0 / 3.0);
+}
+
+struct Seg { // the piece of a job a lane renders inside its tile
+  Ramp r;
+  double vol, fL, fR, inv_A, inv_R, top;
+  int lo, hi, j, T, A;
+};
+
+__device__ inline void seg_open(Seg &g, const RaVoiceJob &J, int f_lo, int f_hi, int q, int L, const RaVoiceState *__restrict__ st_prev, const RaVoiceState *__restrict__ st_cur) {
+  g.lo = max(J.begin, f_lo);
+  g.hi = min(J.begin + J.n, f_hi);
+  const RaVoiceState *st;
+  if (g.lo == J.begin) st = (J.state_in >= 0) ? st_prev + J.state_in : nullptr;
+  else st = st_cur + J.state_tiles + (q - (J.begin / L + 1));
+  ramp_load(g.r, J, st);
+  g.j = J.j0 + (g.lo - J.begin);
+  g.T = J.T; g.A = J.A;
+  g.inv_A = 1.0 / (double)J.A; g.inv_R = 1.0 / (double)J.R;
+  g.top = (J.T < J.A) ? (double)J.T * g.inv_A : 1.0; // the envelope's value when the key is released (startReleased, audioelement.h:836-841)
+  g.vol = J.vol; g.fL = J.fL; g.fR = J.fR;
+}
+
+template <int MAXT>
+__global__ void __launch_bounds__(MAXT) ra_voice_render_kernel(RaVoiceParams p, const RaVoiceJob *__restrict__ jobs, const int32_t *__restrict__ slot_begin,
+                                                                const RaVoiceState *__restrict__ st_prev, const RaVoiceState *__restrict__ st_cur, int n_streams, int n,
+                                                                int L, int n_tiles, int g_log2, float *__restrict__ out) {
+  const int l = threadIdx.x, nt = blockDim.x, g = 1 << g_log2;
+  double *tile = reinterpret_cast<double *>(ra_smem_voice); // [nt][2 TS + 1]: L then R samples of the lane
+  float *lf = reinterpret_cast<float *>(tile + (size_t)nt * (2 * TS + 1)), *le = lf + 29;
+  load_tables(p, lf, le);
+  const int U = nt >> g_log2;                       // (stream, tile) units of this workgroup
+  const long long unit0 = (long long)blockIdx.x * U, n_units = (long long)n_streams * n_tiles;
+  const int u = l >> g_log2, s = l & (g - 1);
+  const long long unit = unit0 + u;
+  const bool valid = unit < n_units;
+  const int stream = valid ? (int)(unit / n_tiles) : 0, q = valid ? (int)(unit % n_tiles) : 0;
+  const int f_lo = q * L, f_hi = min(n, f_lo + L);
+  // the slot's jobs are disjoint and in time order: the first one that ends after the tile's begin
+  int jb = 0, je = 0;
+  if (valid) {
+    jb = slot_begin[(size_t)stream * g + s];
+    je = slot_begin[(size_t)stream * g + s + 1];
+    int lo = jb, hi = je;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (jobs[mid].begin + jobs[mid].n > f_lo) hi = mid; else lo = mid + 1;
     }
-    __syncthreads();
-    for (int t = 0; t < nt; ++t) {
-      const int cnt = min(NS, run_steps[t] - k0); // frames of lane t in this piece (uniform over the block)
-      if (cnt <= 0) continue;
-      if (tl < 2 * cnt) {
-        const double x = stage[t][tl];
-        if (x != 0.0) atomicAdd(accum + run_base[t] + 2 * (long long)k0 + tl, x);
+    jb = lo;
+  }
+  Seg sg;
+  bool have = false;
+  if (jb < je) {
+    const RaVoiceJob J = jobs[jb];
+    if (J.begin < f_hi) { seg_open(sg, J, f_lo, f_hi, q, L, st_prev, st_cur); have = true; }
+  }
+  double *mine = tile + (size_t)l * (2 * TS + 1);
+  const int n_out = U * TS * 2;
+  for (int base = 0; base < L; base += TS) { // (every unit of the workgroup has the same tile length but the block's last tile may be cut: f_hi)
+    const int fb = f_lo + base;
+    const bool work = have && sg.lo < fb + TS && fb < f_hi; // (sg.hi > fb holds: finished segments are replaced at once)
+    if (!__syncthreads_or(work ? 1 : 0)) {
+      for (int t = l; t < n_out; t += nt) {
+        const int uu = t / (TS * 2), i = (t >> 1) % TS, ch = t & 1;
+        const long long un = unit0 + uu;
+        if (un >= n_units) continue;
+        const int st2 = (int)(un / n_tiles), q2 = (int)(un % n_tiles);
+        const int f = q2 * L + base + i;
+        if (f < min(n, q2 * L + L)) out[((size_t)st2 * n + f) * 2 + ch] = 0.f;
       }
+      continue;
+    }
+#pragma unroll 1
+    for (int i = 0; i < TS; ++i) {
+      const int f = fb + i;
+      double vL = 0.0, vR = 0.0;
+      if (have && f >= sg.lo && f < f_hi) {
+        // ---- one step of a sounding ramp: Enveloped::step, then the imag() chain of the element (audioelement.h:1382-1384 -> 1126-1129 -> 227-231) ----
+        const double inc = ramp_advance(sg.r, p, lf, le, sg.j == 1);
+        const int j = sg.j;
+        const double env = (j <= sg.T) ? ((j < sg.A) ? (double)j * sg.inv_A : 1.0)                       // attack then sustain 1 (stepPressed :960-1000)
+                                       : fma(-sg.top, (double)(j - sg.T) * sg.inv_R, sg.top);         // release: top + (-top) m / R (:732-737)
+        const double osc = alias_gain(inc) * osc_imag(sg.r.theta);                                       // SineOscillatorAlgo::imag :2424
+        const double mix = 0.0 + (double)p.sine_gain * (sg.r.y * osc);                                   // Mix::imag :1867-1873 over LoudnessVolumeAdjusted
+        const double mono = sg.vol * (mix * env);                                                        // VolumeAdjusted over Enveloped
+        vL = sg.fL * mono; vR = sg.fR * mono;
+        ++sg.j;
+        if (f + 1 == sg.hi) { // the segment ends: the slot's next job may begin inside this tile
+          have = false;
+          ++jb;
+          if (jb < je) {
+            const RaVoiceJob J = jobs[jb];
+            if (J.begin < f_hi) { seg_open(sg, J, f_lo, f_hi, q, L, st_prev, st_cur); have = true; }
+          }
+        }
+      }
+      mine[i] = vL; mine[TS + i] = vR;
+    }
+    __syncthreads();
+    for (int t = l; t < n_out; t += nt) { // buffer[2 i + ch] += elem.imag(ch): the unit's slots in slot order, then the float cast of SimpleAudioOutContext::step
+      const int uu = t / (TS * 2), i = (t >> 1) % TS, ch = t & 1;
+      const long long un = unit0 + uu;
+      if (un >= n_units) continue;
+      const double *col = tile + (size_t)(uu << g_log2) * (2 * TS + 1) + ch * TS + i;
+      double acc = 0.0;
+      for (int k = 0; k < g; ++k) acc += col[(size_t)k * (2 * TS + 1)];
+      const int st2 = (int)(un / n_tiles), q2 = (int)(un % n_tiles);
+      const int f = q2 * L + base + i;
+      if (f < min(n, q2 * L + L)) out[((size_t)st2 * n + f) * 2 + ch] = (float)acc;
     }
     __syncthreads();
   }
-  if (have && q.store) slots_out[q.slot] = v; // (at most one note per channel goes on into the next block)
-}
-
-// the float cast of SimpleAudioOutContext::step, and the buffer is zero again for the next block
-__global__ void ra_voice_cast_kernel(double *__restrict__ accum, float *__restrict__ out, size_t count) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
-    out[i] = (float)accum[i];
-    accum[i] = 0.0;
-  }
-}
-
-// steps of the ramp's envelope from the note's first step until it is finished (EnvelopeDone2): what decides whether a channel is free again
-__global__ void ra_voice_probe_kernel(RaVoiceParams p, int *out) {
-  const RaEnvParams ep = {p.envA, 0, 0, p.envR, 0.f};
-  Chan c;
-  chan_init(c);
-  chan_forget_past_signals(c);
-  c.state = ENV_SOON;
-  const int time_to_release = (int)(.5f + p.n_frames) - p.xfade_len;
-  env_on_key_pressed(c, 0);
-  env_on_key_released(c, max(time_to_release, 0));
-  int k = 0;
-  while (c.state != ENV_DONE2 && k < (1 << 30)) { env_step(c, ep); ++k; }
-  *out = k;
 }
 
 } // namespace
 
-size_t ra_voice_state_bytes() { return sizeof(VoiceChan); }
-void ra_voice_launch_init(void *state, int count, hipStream_t st) {
-  hipLaunchKernelGGL(ra_voice_init_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, static_cast<VoiceChan *>(state), count);
-}
-void ra_voice_launch(const RaVoiceParams &p, void *state, const RaVoiceEv *ev, const int32_t *ev_begin, int32_t *dropped, int n_streams, int64_t t0, int64_t n,
-                     float *d_out, hipStream_t st) {
-  if (n <= 0) return;
-  const int Ppad = ((p.P + 63) / 64) * 64;
-  const size_t lds = (size_t)Ppad * (2 * VT + 1) * sizeof(double) + 16 + 58 * sizeof(float);
-  hipLaunchKernelGGL(ra_voice_kernel, dim3((unsigned)n_streams), dim3((unsigned)Ppad), lds, st, p, static_cast<VoiceChan *>(state), ev, ev_begin, dropped, t0, n, d_out);
+void ra_voice_launch_pre(const RaVoiceParams &p, const RaVoiceJob *jobs, const int32_t *order, int n_work, const RaVoiceState *st_prev, RaVoiceState *st_cur, int L,
+                         hipStream_t st) {
+  if (n_work <= 0) return;
+  hipLaunchKernelGGL(ra_voice_pre_kernel, dim3((unsigned)((n_work + 63) / 64)), dim3(64), 0, st, p, jobs, order, n_work, st_prev, st_cur, L);
 }
 
-size_t ra_voice_note_bytes() { return sizeof(RaVoiceNote); }
-int ra_voice_probe_done2(const RaVoiceParams &p, int *d_scratch) {
-  hipLaunchKernelGGL(ra_voice_probe_kernel, dim3(1), dim3(1), 0, nullptr, p, d_scratch);
-  int k = -1;
-  if (hipMemcpy(&k, d_scratch, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  return k;
-}
-void ra_voice_launch_notes(const RaVoiceParams &p, const void *slots_in, void *slots_out, const void *notes, int n_notes, int n_streams, int64_t t0, int64_t n, double *accum, float *d_out,
-                           hipStream_t st) {
-  if (n <= 0) return;
-  if (n_notes > 0) {
-    // notes per wavefront (tuning aid): measured on 256 synths x 10 s, 64: 71.5 ms, 32: 69.3 ms, 16: 94.9 ms per step
-    static const int per_wave = [] { const char *e = getenv("RA_VOICE_NOTES_PER_WAVE"); const int v = e ? atoi(e) : 32; return v == 64 ? 64 : 32; }();
-    hipLaunchKernelGGL(ra_voice_notes_kernel, dim3((unsigned)((n_notes + per_wave - 1) / per_wave)), dim3(per_wave), 0, st, p, static_cast<const VoiceChan *>(slots_in),
-                       static_cast<VoiceChan *>(slots_out), static_cast<const RaVoiceNote *>(notes), n_notes, t0, n, accum);
+size_t ra_voice_render_lds(int threads) { return (size_t)threads * (2 * TS + 1) * sizeof(double) + 58 * sizeof(float); }
+
+int ra_voice_launch_render(const RaVoiceParams &p, const RaVoiceJob *jobs, const int32_t *slot_begin, const RaVoiceState *st_prev, const RaVoiceState *st_cur, int n_streams,
+                           int64_t n, int L, int g_log2, float *d_out, hipStream_t st) {
+  if (n <= 0) return 0;
+  const int g = 1 << g_log2;
+  const int threads = std::max(64, g);
+  const int U = threads / g;
+  const int n_tiles = (int)((n + L - 1) / L);
+  const long long units = (long long)n_streams * n_tiles;
+  const size_t lds = ra_voice_render_lds(threads);
+  if (threads == 64) {
+    hipLaunchKernelGGL(ra_voice_render_kernel<64>, dim3((unsigned)((units + U - 1) / U)), dim3(64), lds, st, p, jobs, slot_begin, st_prev, st_cur, n_streams, (int)n, L, n_tiles, g_log2,
+                       d_out);
+    return 0;
   }
-  const size_t count = (size_t)n_streams * (size_t)n * 2;
-  hipLaunchKernelGGL(ra_voice_cast_kernel, dim3((unsigned)std::min<size_t>((count + 255) / 256, 65536)), dim3(256), 0, st, accum, d_out, count);
+  static bool attr_set = false; // more than 64 ramps of a stream at once (n_channels > 21): one unit per workgroup of g lanes
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voice_render_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ra_voice_render_lds(1024)) != hipSuccess) return -1;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(ra_voice_render_kernel<1024>, dim3((unsigned)((units + U - 1) / U)), dim3((unsigned)threads), lds, st, p, jobs, slot_begin, st_prev, st_cur, n_streams, (int)n, L,
+                     n_tiles, g_log2, d_out);
+  return 0;
 }
-

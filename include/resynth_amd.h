@@ -314,49 +314,105 @@ int ra_sqmag(const float *h_windows, int32_t n_windows, int32_t window_size, int
              int32_t *fft_length);
 
 /*
- * ---- gen.voice, first slice: the SWEEP voice -----------------------------------------------------------------
- * voice::Impl_<..., Mode::SWEEP, ...> (include/gen.voice.h:1087-1190): the same ImplCRTP compute / onEvent boundary as the sine bank, the
- * element being VolumeAdjusted<SoundEngine<SWEEP, 2, ...>> (include/soundengine.h:240-1127).  A context of its own: the voice is driven
- * by note events, not by the analysis.  Parameters are the SWEEP program's, de-normalised (gen.voice.h:186-208,474-529,560-580).
- * What SWEEP mode asks of the absent cpp.algorithms (a MarkovChain with one certain transition, two inert mersenne<> draws) is
- * restated exactly; interpolation is itp::LINEAR only (the reference's SWEEP programs use nothing else); a random pan uses the declared
- * counter hash.  BIRDS / ROBOTS / WIND (Markov chains with real draws, pink-noise buffers) are not built.
+ * ---- gen.voice: the SWEEP, BIRDS and ROBOTS voices ---------------------------------------------------------------
+ * voice::Impl_<..., MODE, ...> (include/gen.voice.h:1087-1190): the same ImplCRTP compute / onEvent boundary as the sine bank, the
+ * element being VolumeAdjusted<SoundEngine<MODE, 2, ...>> (include/soundengine.h:240-1127).  A context of its own: the voice is driven
+ * by note events, not by the analysis.  Parameters are the program's, de-normalised (gen.voice.h:55-208,474-529,533-621).
+ * At a note-on the engine's Markov chain (create_birds :565-595, create_robot :597-695, create_sweep :697-719; do_initialize :963-1003)
+ * writes up to 30 ramp specs; orchestrate_algos / playNextSpec (:744-803) then play them one after the other on the engine's three
+ * cross-fading ramps.  Here the chain and the orchestration — integer and PRNG work — run on the host at the note-on
+ * (ra_voice_expand_note shows the result), and every ramp becomes a job of the device kernels (csrc/ra_voice.hip).
+ * What the path takes from the absent cpp.algorithms is decided in DESIGN.md §5 (PARITY UNPINNED): MarkovChain restated from its call
+ * sites; mersenne<> draws = the declared counter hash (salt 5: the k-th draw after the per-note reseed; salt 3: SWEEP's random pan);
+ * itp::interpolate = Penner's easing equations (enum ra_itp: this build's numbering).  WIND (soundengine.h:721-735) is not built: its
+ * voices read pink-noise buffers of cpp.algorithms (RA_EINVAL at ra_voice_create).
  */
+enum { RA_VOICE_BIRDS = 0, RA_VOICE_ROBOTS = 1, RA_VOICE_SWEEP = 2, RA_VOICE_WIND = 3 }; /* SoundEngineMode, soundengine.h:31-40 */
+enum { RA_XFADE_FREQ_NO = 0, RA_XFADE_FREQ_NONTRIVIAL = 1, RA_XFADE_FREQ_ALL = 2 };     /* FreqXfade, soundengine.h:3-11 */
+enum ra_itp {
+  RA_ITP_LINEAR = 0, RA_ITP_PROPORTIONAL_VALUE_DERIVATIVE = 1,
+  RA_ITP_EASE_IN_QUAD, RA_ITP_EASE_OUT_QUAD, RA_ITP_EASE_INOUT_QUAD, RA_ITP_EASE_IN_CUBIC, RA_ITP_EASE_OUT_CUBIC, RA_ITP_EASE_INOUT_CUBIC,
+  RA_ITP_EASE_IN_QUART, RA_ITP_EASE_OUT_QUART, RA_ITP_EASE_INOUT_QUART, RA_ITP_EASE_IN_QUINT, RA_ITP_EASE_OUT_QUINT, RA_ITP_EASE_INOUT_QUINT,
+  RA_ITP_EASE_IN_SINE, RA_ITP_EASE_OUT_SINE, RA_ITP_EASE_INOUT_SINE, RA_ITP_EASE_IN_EXPO, RA_ITP_EASE_OUT_EXPO, RA_ITP_EASE_INOUT_EXPO,
+  RA_ITP_EASE_IN_CIRC, RA_ITP_EASE_OUT_CIRC, RA_ITP_EASE_INOUT_CIRC, RA_ITP_END
+};
 typedef struct ra_voice_config {
   int32_t sample_rate;
   int32_t n_channels;            /* 2 * nVoices (gen.crtp.h:225), <= 256 */
   float length_ms;               /* LENGTH (10 .. 500) */
-  float length_exponent;         /* LENGTH_EXPONENT (0 .. 7): the sweep lasts length_ms * 2^exponent */
-  float xfade_length_seconds;    /* XFADE_LENGTH (0.0023 .. 0.0454): attack and release of the ramp's envelope */
-  float low_freq, high_freq;     /* LOW_FREQ, HIGH_FREQ: the sweep's ends, Hz */
+  float length_exponent;         /* LENGTH_EXPONENT (0 .. 7): a ramp lasts length_ms * 2^exponent */
+  float xfade_length_seconds;    /* XFADE_LENGTH (0.0023 .. 0.0454): attack and release of a ramp's envelope */
+  float low_freq, high_freq;     /* LOW_FREQ, HIGH_FREQ: the sweep's ends, Hz (SWEEP) */
   float sine_gain;               /* SINE_GAIN */
   float loudness_level;          /* LOUDNESS_LEVEL, phons (20 .. 100) */
   float loudness_compensation_amount; /* LOUDNESS_COMPENSATION_AMOUNT (log_ratio, 0 .. 1) */
   int32_t loudness_ref_freq_index;    /* LOUDNESS_REF_FREQ_INDEX (0 .. 15) */
   float pan;                     /* PAN (-1 .. 1) */
   int32_t random_pan;            /* RANDOM_PAN as a boolean */
-  uint64_t seed;
+  uint64_t seed;                 /* key of the declared draws; stream s uses seed + s */
+  /* ---- BIRDS / ROBOTS ---- */
+  int32_t mode;                  /* RA_VOICE_* */
+  int32_t interpolation;         /* INTERPOLATION: the ramps' frequency law (ra_itp) */
+  int32_t markov_start_node;     /* MARKOV_START_NODE (0 .. 2) */
+  int32_t markov_pre_tries;      /* MARKOV_PRE_TRIES (0 .. 20): normalised steps without lambdas */
+  int32_t markov_min_path_length;/* MARKOV_MIN_PATH_LENGTH (0 .. 20): normalised steps with lambdas */
+  int32_t markov_additional_tries;/* MARKOV_ADDITIONAL_TRIES (0 .. 20): raw steps with lambdas */
+  float articulative_pause_seconds; /* MARKOV_ARTICULATIVE_PAUSE_LENGTH (0 .. 0.5) */
+  float freq_scatter;            /* FREQ_SCATTER (0 .. 1) */
+  float length_exponent_scatter; /* LENGTH_EXPONENT_SCATTER (0 .. 1): the exponent is drawn in exponent * (1 -+ scatter) */
+  float phase_ratio1, phase_ratio2; /* PHASE_RATIO1 / 2 (clamped to 0 .. 1; ratio2 is carried but unused, as in the reference) */
+  float d1, d2;                  /* D1, D2 (ROBOTS): halftones one of the two tones is raised by (0 .. 47) */
+  float harmonic_attenuation;    /* HARMONIC_ATTENUATION (ROBOTS; clamped to 0 .. 0.99) */
+  int32_t xfade_freq;            /* MARKOV_XFADE_FREQ (BIRDS; RA_XFADE_FREQ_*) */
+  float freq_transition_seconds; /* FREQ_TRANSITION_LENGTH (BIRDS; 0 .. 0.5) */
+  int32_t freq_interpolation;    /* FREQ_TRANSITION_INTERPOLATION (BIRDS; ra_itp) */
+  int32_t seed_param;            /* SEED (0 .. 257): 0 = the next of 1 .. 257 per note-on of a stream, else this seed for every note */
 } ra_voice_config;
 typedef struct ra_voice_event {
   int64_t sample;    /* frame of Impl_::doProcessing at which the event reaches onEvent (gen.voice.h:1159-1165) */
   int32_t stream;
   int32_t type;      /* 0 NoteOn, 1 NoteOff */
   int64_t noteid;    /* unique per note (events.h:55-107); a note-off names its note-on's id */
-  float frequency;   /* > 0 (SoundEngine::do_initialize refuses base_freq <= 0, soundengine.h:1012-1015); SWEEP ignores its value */
+  float frequency;   /* > 0 (SoundEngine::do_initialize refuses base_freq <= 0, soundengine.h:972-975); SWEEP ignores its value */
   float velocity;
 } ra_voice_event;
 typedef struct ra_voice ra_voice;
 int ra_voice_default_config(ra_voice_config *cfg); /* the "Sweep 1" program (gen.voice.h:752-754) with its sweep ends at 100 Hz / 20 kHz */
+/* the reference's own programs (ImplBase::getPrograms, gen.voice.h:700-761) with make_common's defaults (:474-531): mode RA_VOICE_BIRDS
+ * index 0 .. 8, RA_VOICE_ROBOTS 0 .. 1, RA_VOICE_SWEEP 0 .. 1; returns RA_EINVAL beyond.  `name` (may be NULL) receives the program's name. */
+int ra_voice_program(int32_t mode, int32_t index, ra_voice_config *cfg, const char **name);
 int ra_voice_create(const ra_voice_config *cfg, int32_t n_streams, int32_t device, ra_voice **out);
 void ra_voice_destroy(ra_voice *v);
 /* queue events (HOST pointer; per stream in non-decreasing sample order, not before the frames already processed) */
 int ra_voice_events(ra_voice *v, const ra_voice_event *h_events, int64_t n_events);
 /* Impl_::doProcessing over n_frames for every stream: h_out [n_streams][n_frames][2] float32 (HOST pointer); consecutive calls continue */
 int ra_voice_process_host(ra_voice *v, int64_t n_frames, float *h_out);
-/* the same with the output resident in HBM: d_out [n_streams][n_frames][2] float32 (DEVICE pointer); synchronous on the null stream */
+/* the same with the output resident in HBM: d_out [n_streams][n_frames][2] float32 (DEVICE pointer); returns when the block is done */
 int ra_voice_process_device(ra_voice *v, int64_t n_frames, float *d_out);
+/* hipStream_t on which every later call enqueues its work (NULL = the null stream) */
+int ra_voice_set_hip_stream(ra_voice *v, void *hip_stream);
+/* ra_voice_process_device without the wait: the block's bookkeeping runs on the host, its kernels and copies are enqueued on the
+ * object's stream and the call returns; d_out is complete when the stream has drained (hipStreamSynchronize / ra_voice_synchronize). */
+int ra_voice_process_device_async(ra_voice *v, int64_t n_frames, float *d_out);
+int ra_voice_synchronize(ra_voice *v);
 /* note-ons that found no channel (onDroppedNote), all streams; negative RA_E* on error */
 int64_t ra_voice_dropped_note_ons(ra_voice *v);
+/* device time of the two kernels of a block, accumulated since the last call with reset != 0 (HIP events on the object's stream):
+ * ms2 = {state pre-pass, render}, launches2 likewise; synchronises */
+int ra_voice_get_kernel_ms(ra_voice *v, double *ms2, int64_t *launches2, int32_t reset);
+
+/*
+ * Host-only (no device needed): what the engine makes of ONE note-on — setupAudioElement + initialize_<mode> + the orchestration's
+ * schedule.  `seed_value` is the value the per-note reseed takes (SEED, or the stream's running counter), `stream_seed` the key
+ * (cfg->seed + stream).  Outputs (each may be NULL; capacities in entries):
+ *   spec_d [.][4] = {from, to, duration in samples, start sample} (angle increments, LogRamp::setup), spec_i [.][3] = {ra_itp, silence
+ *   follows, 0}, spec_vol [.]: the ramp specs in build order;
+ *   played [.][4] = {element step (1-based) at which playNextSpec starts the spec, ramp 0 .. 2, spec, steps until the ramp's key release};
+ *   info [4] = {specs, plays, element steps until every ramp is finished and no spec is left, float bits of the left stereo gain}.
+ * Returns RA_OK, RA_EINVAL (bad config / frequency) or RA_EOVERFLOW (a capacity is too small; info is still filled).
+ */
+int ra_voice_expand_note(const ra_voice_config *cfg, float frequency, uint64_t stream_seed, int32_t seed_value, int64_t noteid, double *spec_d, int32_t *spec_i,
+                         float *spec_vol, int64_t spec_cap, int64_t *played, int64_t played_cap, int64_t *info);
 
 #ifdef __cplusplus
 }

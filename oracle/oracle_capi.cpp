@@ -215,7 +215,7 @@ int64_t ora_resynth_notes(const int32_t *start, const int32_t *end, const double
   return n;
 }
 
-// gen.voice, SWEEP mode (oracle_voice.hpp): Impl_::doProcessing (gen.voice.h:1128-1187) over n_frames for one stream — events reach the
+// gen.voice (oracle_voice.hpp): Impl_::doProcessing (gen.voice.h:1128-1187) over n_frames for one stream — events reach the
 // synth at their frame, then SimpleAudioOutContext::step renders.  ev: sample / type (0 on, 1 off) / noteid / frequency / velocity.
 // out [n_frames][2] float.  Returns the number of note-ons dropped.
 int32_t ora_voice_run(const ora_voice_params *p, const int64_t *ev_sample, const int32_t *ev_type, const int64_t *ev_noteid, const float *ev_freq,
@@ -237,6 +237,84 @@ int32_t ora_voice_run(const ora_voice_params *p, const int64_t *ev_sample, const
     stepper.step(out + 2 * k, 1);
   }
   return dropped;
+}
+
+// What the engine makes of consecutive note-ons of one synth (no note-off until the note has played out), for the tests of the product's
+// host-side note expansion: per note its ramp specs as the Markov chain built them — spec_d [.][4] = {from, to, duration, start sample},
+// spec_i [.][3] = {interpolation, silence follows, 0}, spec_vol [.] — and every playNextSpec as it happened while the element was stepped —
+// played [.][3] = {element step (1-based), ramp, spec} —, note_info [n_notes][4] = {specs, plays, steps until the element is finished (every
+// ramp EnvelopeDone2 and no spec left), pan as float bits}.  Returns 0, or -1 when a capacity is too small / a note does not end in max_steps.
+int32_t ora_voice_trace(const ora_voice_params *p, const float *freqs, int32_t n_notes, int64_t max_steps, double *spec_d, int32_t *spec_i, float *spec_vol,
+                        int64_t spec_cap, int64_t *played, int64_t played_cap, int64_t *note_info) {
+  Stepper stepper;
+  VoiceSynth synth(1);
+  synth.phase_policy = 1;
+  VoiceInitializer init;
+  init.p = *p;
+  std::vector<VoicePlayed> trace;
+  init.trace = &trace;
+  synth.initializer = init;
+  synth.initialize(stepper);
+  int64_t ns = 0, np = 0;
+  float out[2];
+  for (int32_t i = 0; i < n_notes; ++i) {
+    trace.clear();
+    Event on{EventType::NoteOn, i + 1, freqs[i], 1.f, 0};
+    if (synth.onEvent(p->sample_rate, on, stepper) != onEventResult::OK) return -1;
+    VoiceElement &e = synth.channels[0].elem;
+    if (!e.setup_ok) return -1;
+    int32_t const n_specs = e.ramp_specs.end;
+    if (ns + n_specs > spec_cap) return -1;
+    for (int32_t s = 0; s < n_specs; ++s, ++ns) {
+      auto const &sp = e.ramp_specs.a[s];
+      spec_d[4 * ns + 0] = sp.ctrl.from; spec_d[4 * ns + 1] = sp.ctrl.to; spec_d[4 * ns + 2] = sp.ctrl.duration_in_samples; spec_d[4 * ns + 3] = sp.ctrl.cur_sample;
+      spec_i[3 * ns + 0] = sp.ctrl.interp; spec_i[3 * ns + 1] = sp.silenceAfter ? 1 : 0; spec_i[3 * ns + 2] = 0;
+      spec_vol[ns] = sp.vol;
+    }
+    int64_t k = 0;
+    for (;;) {
+      stepper.step(out, 1);
+      ++k;
+      bool busy = !e.ramp_specs.done();
+      for (auto const &r : e.ramps) if (r.env.state != EnvelopeState::EnvelopeDone2) busy = true;
+      if (!busy) break;
+      if (k >= max_steps) return -1;
+    }
+    if (np + static_cast<int64_t>(trace.size()) > played_cap) return -1;
+    for (auto const &t : trace) { played[3 * np] = t.step; played[3 * np + 1] = t.ramp; played[3 * np + 2] = t.spec; ++np; }
+    float const pan_gain = static_cast<float>(e.ramps[0].gain_.gains[0]);
+    int32_t bits;
+    std::memcpy(&bits, &pan_gain, 4);
+    note_info[4 * i] = n_specs; note_info[4 * i + 1] = static_cast<int64_t>(trace.size()); note_info[4 * i + 2] = k; note_info[4 * i + 3] = bits;
+    Event off{EventType::NoteOff, i + 1, 0.f, 0.f, 0};
+    synth.onEvent(p->sample_rate, off, stepper);
+    stepper.step(out, 1);
+  }
+  return 0;
+}
+
+// the restated MarkovChain alone: visits of each node over n_steps raw / normalised steps of the BIRDS (which = 0) or ROBOTS (1) graph from
+// `start`, driven by the declared draws (tests: visit frequencies against the transition table)
+void ora_markov_visits(int32_t which, int32_t start, int32_t normalized, uint64_t seed, int64_t n_steps, int64_t *visits4) {
+  VoiceElement e;
+  VoiceRng rng;
+  rng.key = seed;
+  rng.seed(1);
+  e.rng = &rng;
+  e.sample_rate = 48000;
+  auto mc = which == 0 ? e.create_birds() : e.create_robot();
+  mc->initialize(start);
+  for (int i = 0; i < 4; ++i) visits4[i] = 0;
+  for (int64_t i = 0; i < n_steps; ++i) {
+    float const r = rng.uniform_real(0.f, 1.f);
+    if (normalized) mc->step_normalized<false>(r); else mc->step<false>(r);
+    ++visits4[mc->current];
+  }
+}
+
+// itp::interpolate as decided in oracle_voice.hpp, over arrays (tests: end points, monotony, symmetry)
+void ora_itp(int32_t kind, const double *t, int64_t n, double b, double c, double d, double *out) {
+  for (int64_t i = 0; i < n; ++i) out[i] = itp_interpolate(kind, t[i], b, c, d);
 }
 
 // deduceNotesSlow as decided in oracle_resynth.hpp; returns the number of notes, stores the first cap

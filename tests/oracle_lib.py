@@ -274,11 +274,26 @@ class OraVoiceParams(C.Structure):
     _fields_ = [("sample_rate", C.c_int32), ("n_channels", C.c_int32), ("length_ms", C.c_float), ("length_exponent", C.c_float),
                 ("xfade_length_seconds", C.c_float), ("low_freq", C.c_float), ("high_freq", C.c_float), ("sine_gain", C.c_float),
                 ("loudness_level", C.c_float), ("loudness_compensation", C.c_float), ("loudness_ref_freq_index", C.c_int32),
-                ("pan", C.c_float), ("random_pan", C.c_int32), ("seed", C.c_uint64)]
+                ("pan", C.c_float), ("random_pan", C.c_int32), ("seed", C.c_uint64),
+                ("mode", C.c_int32), ("interpolation", C.c_int32), ("markov_start_node", C.c_int32), ("markov_pre_tries", C.c_int32),
+                ("markov_min_path_length", C.c_int32), ("markov_additional_tries", C.c_int32), ("articulative_pause_seconds", C.c_float),
+                ("freq_scatter", C.c_float), ("length_exponent_scatter", C.c_float), ("phase_ratio1", C.c_float), ("phase_ratio2", C.c_float),
+                ("d1", C.c_float), ("d2", C.c_float), ("harmonic_attenuation", C.c_float), ("xfade_freq", C.c_int32),
+                ("freq_transition_seconds", C.c_float), ("freq_interpolation", C.c_int32), ("seed_param", C.c_int32)]
+
+
+def voice_params_from(cfg, seed):
+    """The oracle's parameters for a product ra_voice_config (same field meanings; `seed` = cfg.seed + stream)."""
+    p = OraVoiceParams()
+    for name, _ in OraVoiceParams._fields_:
+        src = "loudness_compensation_amount" if name == "loudness_compensation" else name
+        setattr(p, name, getattr(cfg, src))
+    p.seed = seed
+    return p
 
 
 def voice_run(params, rows, n_frames):
-    """gen.voice SWEEP on the oracle, one stream.  rows: (sample, type, noteid, frequency, velocity).  Returns (out [n, 2] float32, dropped)."""
+    """gen.voice on the oracle, one stream.  rows: (sample, type, noteid, frequency, velocity).  Returns (out [n, 2] float32, dropped)."""
     rows = sorted(rows, key=lambda r: r[0])
     es = np.array([r[0] for r in rows], np.int64)
     et = np.array([r[1] for r in rows], np.int32)
@@ -290,6 +305,43 @@ def voice_run(params, rows, n_frames):
     L.ora_voice_run.restype = C.c_int32
     d = L.ora_voice_run(C.byref(params), _p(es), _p(et), _p(ei), _p(ef), _p(ev), C.c_int64(len(rows)), C.c_int64(n_frames), _p(out))
     return out, d
+
+
+def voice_trace(params, freqs, max_steps=1 << 26, spec_cap=4096, play_cap=4096):
+    """Consecutive note-ons of one synth, each played out (ora_voice_trace).  Returns a list of dict(specs_d, specs_i, vol, played [m,3], done_step, gain_left)."""
+    freqs = np.ascontiguousarray(freqs, np.float32)
+    sd = np.zeros((spec_cap, 4), np.float64)
+    si = np.zeros((spec_cap, 3), np.int32)
+    sv = np.zeros(spec_cap, np.float32)
+    pl = np.zeros((play_cap, 3), np.int64)
+    info = np.zeros((len(freqs), 4), np.int64)
+    L = lib()
+    L.ora_voice_trace.restype = C.c_int32
+    r = L.ora_voice_trace(C.byref(params), _p(freqs), C.c_int32(len(freqs)), C.c_int64(max_steps), _p(sd), _p(si), _p(sv), C.c_int64(spec_cap), _p(pl),
+                          C.c_int64(play_cap), _p(info))
+    assert r == 0, "ora_voice_trace failed (capacity / a note that does not end)"
+    res, a, b = [], 0, 0
+    for i in range(len(freqs)):
+        ns, npl = int(info[i, 0]), int(info[i, 1])
+        gain = np.array([info[i, 3]], np.int64).astype(np.int32).view(np.float32)[0]
+        res.append(dict(specs_d=sd[a:a + ns].copy(), specs_i=si[a:a + ns].copy(), vol=sv[a:a + ns].copy(), played=pl[b:b + npl].copy(), done_step=int(info[i, 2]),
+                        gain_left=float(gain)))
+        a += ns
+        b += npl
+    return res
+
+
+def markov_visits(which, start, normalized, seed, n_steps):
+    v = np.zeros(4, np.int64)
+    lib().ora_markov_visits(C.c_int32(which), C.c_int32(start), C.c_int32(1 if normalized else 0), C.c_uint64(seed), C.c_int64(n_steps), _p(v))
+    return v
+
+
+def itp(kind, t, b, c, d):
+    t = np.ascontiguousarray(t, np.float64)
+    out = np.empty_like(t)
+    lib().ora_itp(C.c_int32(kind), _p(t), C.c_int64(t.size), C.c_double(b), C.c_double(c), C.c_double(d), _p(out))
+    return out
 
 
 def det_math(x, which):

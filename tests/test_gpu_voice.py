@@ -1,8 +1,12 @@
-"""GPU parity test for SURVEY.md §8 f4 (first slice): gen.voice in SWEEP mode (K9) against the CPU restatement (oracle_voice.hpp)."""
+"""GPU parity tests for SURVEY.md §8 f4: gen.voice — SWEEP, BIRDS, ROBOTS (K9) against the CPU restatement (oracle_voice.hpp)."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+# measured on MI355X: the worst stream of these 24 cases is 5.6e-9 RMS; the bar is ten times that
+RMS_BAR = 6e-8
+PEAK_BAR = 1e-6
 
 
 @pytest.fixture(scope="module")
@@ -16,44 +20,95 @@ def rms(a, b):
     return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
 
 
-def ora_params(oracle, cfg, seed):
-    return oracle.OraVoiceParams(cfg.sample_rate, cfg.n_channels, cfg.length_ms, cfg.length_exponent, cfg.xfade_length_seconds, cfg.low_freq, cfg.high_freq,
-                                 cfg.sine_gain, cfg.loudness_level, cfg.loudness_compensation_amount, cfg.loudness_ref_freq_index, cfg.pan, cfg.random_pan, seed)
+def note_rows(rng, S, count, gap, hold, freq=(100, 2000)):
+    rows, nid = [], 0
+    for s in range(S):
+        t = 0
+        for _ in range(count):
+            t += int(rng.integers(*gap))
+            nid += 1
+            rows.append((t, s, 0, nid, float(rng.uniform(*freq)), float(rng.uniform(0.2, 1.0))))
+            # some notes are released before they have played out (the element falls silent at once and its channel is lost), some after
+            rows.append((t + int(rng.integers(*hold)), s, 1, nid, 0.0, 0.0))
+    rows.sort(key=lambda r: (r[1], r[0]))
+    return rows
+
+
+def check_against_oracle(api, oracle, cfg, rows, S, n, cuts, seed, expect_sound=True):
+    with api.Voice(cfg, S, 0) as v:
+        v.events(rows)
+        parts = [v.process(m) for m in cuts]
+        dropped = v.dropped_note_ons()
+    out = np.concatenate(parts, axis=1)
+    assert out.shape[1] == n
+    ref_dropped, worst = 0, 0.0
+    for s in range(S):
+        ref, d = oracle.voice_run(oracle.voice_params_from(cfg, seed + s), [(r[0], r[2], r[3], r[4], r[5]) for r in rows if r[1] == s], n)
+        ref_dropped += d
+        if expect_sound:
+            assert np.sqrt(np.mean(ref.astype(np.float64) ** 2)) > 2e-4, "the oracle's voice is silent"
+        e = rms(out[s], ref)
+        worst = max(worst, e)
+        assert e <= RMS_BAR, f"stream {s}: rms {e:.3g}"
+        assert np.max(np.abs(out[s].astype(np.float64) - ref)) < PEAK_BAR
+    assert dropped == ref_dropped
+    print(f"worst stream rms vs oracle: {worst:.3g}")
+    return out, dropped, worst
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(length_ms=40.0, length_exponent=3.0, low_freq=8000.0, high_freq=60.0, pan=-0.6),
                                 dict(n_channels=3, random_pan=1, loudness_level=70.0, loudness_compensation_amount=0.5, loudness_ref_freq_index=11, sine_gain=0.5),
-                                dict(sample_rate=44100, length_ms=25.0, length_exponent=1.0, xfade_length_seconds=0.0023, low_freq=300.0, high_freq=300.0)])
+                                dict(sample_rate=44100, length_ms=25.0, length_exponent=1.0, xfade_length_seconds=0.0023, low_freq=300.0, high_freq=300.0),
+                                dict(interpolation=17, length_exponent=2.0, low_freq=200.0, high_freq=6000.0),   # EASE_IN_EXPO
+                                dict(interpolation=1, length_exponent=2.5, low_freq=5000.0, high_freq=50.0)])     # PROPORTIONAL_VALUE_DERIVATIVE
 def test_sweep_voice_matches_oracle(api, oracle, kw):
     cfg = api.voice_default_config(seed=11, **kw)
     S, n = 3, 80000
-    rng = np.random.default_rng(5)
-    rows = []
-    nid = 0
-    for s in range(S):
-        t = 0
-        for _ in range(9):
-            t += int(rng.integers(200, 9000))
-            nid += 1
-            rows.append((t, s, 0, nid, float(rng.uniform(100, 2000)), float(rng.uniform(0.2, 1.0))))
-            # some notes are released before their sweep ends (the element falls silent at once and its channel is lost), some after
-            rows.append((t + int(rng.integers(300, 60000)), s, 1, nid, 0.0, 0.0))
-    rows.sort(key=lambda r: (r[1], r[0]))
-    with api.Voice(cfg, S, 0) as v:
-        v.events(rows)
-        parts = [v.process(m) for m in (1, 7000, 33, n - 7034)]   # block cuts do not matter
-        dropped = v.dropped_note_ons()
-    out = np.concatenate(parts, axis=1)
-    ref_dropped = 0
-    for s in range(S):
-        ref, d = oracle.voice_run(ora_params(oracle, cfg, 11 + s), [(r[0], r[2], r[3], r[4], r[5]) for r in rows if r[1] == s], n)
-        ref_dropped += d
-        assert np.sqrt(np.mean(ref.astype(np.float64) ** 2)) > 1e-3, "the oracle's voice is silent"
-        assert rms(out[s], ref) <= 1e-5, f"stream {s}: {rms(out[s], ref):.3g}"
-        assert np.max(np.abs(out[s].astype(np.float64) - ref)) < 1e-5
-    assert dropped == ref_dropped
+    rows = note_rows(np.random.default_rng(5), S, 9, (200, 9000), (300, 60000))
+    _, dropped, _ = check_against_oracle(api, oracle, cfg, rows, S, n, (1, 7000, 33, n - 7034), 11)   # block cuts do not matter
     if cfg.n_channels == 3:
         assert dropped > 0, "three channels and lost channels: some note-ons must be dropped"
+
+
+@pytest.mark.parametrize("index", range(9))
+def test_birds_programs_match_oracle(api, oracle, index):
+    # the reference's nine BIRDS programs (gen.voice.h:702-735): Markov-drawn ramp lists, pauses, cross-fading ramps, frequency transitions
+    cfg, name = api.voice_program(api.VOICE_BIRDS, index, seed=1000 + index, n_channels=6)
+    S, n = 2, 240000
+    rows = note_rows(np.random.default_rng(100 + index), S, 7, (3000, 40000), (2000, 200000), freq=(150, 1200))
+    check_against_oracle(api, oracle, cfg, rows, S, n, (5, 100000, 1, n - 100006), 1000 + index)
+
+
+@pytest.mark.parametrize("index", range(2))
+def test_robots_programs_match_oracle(api, oracle, index):
+    cfg, name = api.voice_program(api.VOICE_ROBOTS, index, seed=2000 + index, n_channels=5)
+    S, n = 2, 200000
+    rows = note_rows(np.random.default_rng(200 + index), S, 8, (2000, 30000), (1500, 150000), freq=(150, 1500))
+    check_against_oracle(api, oracle, cfg, rows, S, n, (70000, 1, 64, n - 70065), 2000 + index)
+
+
+@pytest.mark.parametrize("kw", [dict(seed_param=48, markov_min_path_length=5, markov_additional_tries=20, xfade_freq=2, freq_transition_seconds=0.01, freq_interpolation=19,
+                                     length_ms=12.0, length_exponent=1.0, articulative_pause_seconds=0.0, interpolation=4, freq_scatter=0.3, random_pan=0, pan=0.4),
+                                dict(seed_param=0, markov_start_node=2, markov_pre_tries=3, markov_min_path_length=20, markov_additional_tries=20, length_ms=10.0,
+                                     length_exponent=0.0, length_exponent_scatter=1.0, xfade_length_seconds=0.0454, articulative_pause_seconds=0.5, interpolation=22),
+                                dict(sample_rate=44100, markov_min_path_length=4, xfade_freq=1, freq_transition_seconds=0.2, length_ms=30.0, length_exponent=2.0,
+                                     interpolation=16, freq_interpolation=9, sine_gain=0.7, loudness_level=80.0, loudness_compensation_amount=0.3)])
+def test_birds_variants(api, oracle, kw):
+    # corners: the 30-spec cap with frequency transitions (cancel_last_ramp), ramps shorter than their cross-fade (skipped at once), every
+    # ramp busy when the next spec is due, long pauses during which a note-off finds every ramp finished (the channel is not lost)
+    cfg, _ = api.voice_program(api.VOICE_BIRDS, 1, seed=31, n_channels=4, **kw)
+    S, n = 2, 160000
+    rows = note_rows(np.random.default_rng(7), S, 10, (1000, 20000), (500, 100000), freq=(200, 900))
+    check_against_oracle(api, oracle, cfg, rows, S, n, (n,), 31, expect_sound=(cfg.length_exponent > 0))
+
+
+def test_many_channels_take_the_wide_workgroups(api, oracle):
+    # more than 64 ramps of one stream at once: one (stream, tile) unit per workgroup of g > 64 lanes
+    cfg, _ = api.voice_program(api.VOICE_ROBOTS, 1, seed=9, n_channels=120)
+    n = 30000
+    rows = [(10 + 3 * k, 0, 0, k + 1, 200.0 + 7 * k, 0.05) for k in range(110)]
+    out, dropped, _ = check_against_oracle(api, oracle, cfg, rows, 1, n, (n,), 9)
+    assert dropped == 0
 
 
 def test_sweep_voice_is_a_sweep(api):
@@ -71,58 +126,49 @@ def test_sweep_voice_is_a_sweep(api):
     assert np.allclose(out[m, 1] / out[m, 0], g[1] / g[0], rtol=1e-4)
 
 
-def test_voice_output_resident_in_hbm_equals_host_output(api):
+def test_voice_is_bit_reproducible_and_hbm_resident_output_equals_host_output(api):
+    # every output sample is one fixed-order sum (no atomics): two runs agree bit for bit, on the host path, on the device path and on the
+    # asynchronous path over a caller's stream — with overlapping notes on every stream
     import torch
+    cfg, _ = api.voice_program(api.VOICE_BIRDS, 8, seed=5, n_channels=8)
     rows = [(100 * k + 37 * s, s, 0, 10 * s + k, 200.0 + 50 * k, 0.8) for s in range(3) for k in range(5)]
     rows.sort(key=lambda r: (r[1], r[0]))
-    cfg = api.voice_default_config(seed=5, random_pan=1)
-    with api.Voice(cfg, 3, 0) as v:
-        v.events(rows)
-        host = v.process(30000)
-    with api.Voice(cfg, 3, 0) as v:
-        v.events(rows)
-        out = torch.empty(3, 30000, 2, dtype=torch.float32, device="cuda:0")
-        v.process_device(30000, out.data_ptr())
-    assert np.any(host != 0) and np.array_equal(out.cpu().numpy(), host)
-
-
-def test_one_note_per_lane_equals_the_sample_serial_kernel(api, monkeypatch):
-    # the default renders every note of a block in a lane of its own and walks the channel bookkeeping on the host; RA_VOICE_SERIAL=1 (read
-    # when the object is created) keeps the one-wave-per-synth kernel.  Same samples (the sum over a frame's notes associates differently),
-    # same dropped note-ons — with three channels, early releases (lost channels) and long notes that span blocks.
-    rng = np.random.default_rng(17)
-    S, n = 4, 90000
-    rows, nid = [], 0
-    for s in range(S):
-        t = 0
-        for _ in range(30):
-            t += int(rng.integers(100, 4000))
-            nid += 1
-            rows.append((t, s, 0, nid, 440.0, float(rng.uniform(0.2, 1.0))))
-            rows.append((t + int(rng.integers(1, 30000)), s, 1, nid, 0.0, 0.0))
-    rows.sort(key=lambda r: (r[1], r[0]))
-    cfg = api.voice_default_config(seed=3, random_pan=1, n_channels=3, length_exponent=1.5)
-    res = []
-    for serial in (False, True):
-        if serial:
-            monkeypatch.setenv("RA_VOICE_SERIAL", "1")
-        else:
-            monkeypatch.delenv("RA_VOICE_SERIAL", raising=False)
-        with api.Voice(cfg, S, 0) as v:
+    n = 60000
+    runs = []
+    for _ in range(2):
+        with api.Voice(cfg, 3, 0) as v:
             v.events(rows)
-            out = np.concatenate([v.process(m) for m in (5, 20000, 1, 30000, n - 50006)], axis=1)
-            res.append((out.astype(np.float64), v.dropped_note_ons()))
-    monkeypatch.delenv("RA_VOICE_SERIAL", raising=False)
-    assert np.sqrt(np.mean(res[1][0] ** 2)) > 1e-3 and res[1][1] > 0
-    assert res[0][1] == res[1][1]
-    assert np.max(np.abs(res[0][0] - res[1][0])) < 2e-7
+            runs.append(v.process(n))
+    assert np.any(runs[0] != 0) and np.array_equal(runs[0], runs[1])
+    with api.Voice(cfg, 3, 0) as v:
+        v.events(rows)
+        out = torch.empty(3, n, 2, dtype=torch.float32, device="cuda:0")
+        v.process_device(n, out.data_ptr())
+        assert np.array_equal(out.cpu().numpy(), runs[0])
+    st = torch.cuda.Stream()
+    with api.Voice(cfg, 3, 0) as v:
+        v.set_hip_stream(st.cuda_stream)
+        v.events(rows)
+        halves = [torch.empty(3, n // 2, 2, dtype=torch.float32, device="cuda:0") for _ in range(2)]
+        for h in halves:
+            v.process_device_async(n // 2, h.data_ptr())   # both blocks are enqueued before either is waited for
+        v.synchronize()
+        got = torch.cat(halves, dim=1).cpu().numpy()
+    # (another block cut packs the ramps into other slots: the sums associate differently — a float ulp now and then)
+    assert np.max(np.abs(got.astype(np.float64) - runs[0])) < 1e-6
 
 
 def test_voice_argument_errors(api):
-    for kw in (dict(n_channels=0), dict(low_freq=0.0), dict(length_ms=0.0), dict(loudness_ref_freq_index=16), dict(length_ms=10.0, length_exponent=0.0, xfade_length_seconds=0.04)):
+    for kw in (dict(n_channels=0), dict(low_freq=0.0), dict(length_ms=0.0), dict(loudness_ref_freq_index=16), dict(length_ms=10.0, length_exponent=0.0, xfade_length_seconds=0.04),
+               dict(mode=3), dict(mode=7), dict(interpolation=23)):
         with pytest.raises(api.RaError) as e:
             api.Voice(api.voice_default_config(**kw), 1, 0)
         assert e.value.code == -1
+    for kw in (dict(markov_start_node=3), dict(markov_additional_tries=21), dict(articulative_pause_seconds=0.6), dict(seed_param=258), dict(xfade_freq=1, freq_transition_seconds=0.0)):
+        with pytest.raises(api.RaError):
+            api.Voice(api.voice_program(api.VOICE_BIRDS, 0, **kw)[0], 1, 0)
+    with pytest.raises(api.RaError):
+        api.voice_program(api.VOICE_WIND, 0)
     with api.Voice(api.voice_default_config(), 1, 0) as v:
         for bad in ([(0, 1, 0, 1, 440.0, 1.0)], [(0, 0, 2, 1, 440.0, 1.0)], [(0, 0, 0, 1, 0.0, 1.0)], [(0, 0, 0, 1, 440.0, 0.0)]):
             with pytest.raises(api.RaError):
