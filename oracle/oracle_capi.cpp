@@ -317,6 +317,61 @@ void ora_itp(int32_t kind, const double *t, int64_t n, double b, double c, doubl
   for (int64_t i = 0; i < n; ++i) out[i] = itp_interpolate(kind, t[i], b, c, d);
 }
 
+
+// ---- single objects, for the closed-form checks of tests/test_oracle_closed_forms_cpu.py ------------------------------------------------
+// One ResynthElement (with_ctrl = 1: rt.resynth's; 0: driver (A)'s) stepped alone for n samples.  Before step k the operations with
+// op_sample == k run in order: 0 setAngleIncrements(v), 1 setVolumeTarget(v), 2 the note-on preparations of ImplCRTP::onEvent and the
+// initializer (tryAcquire, forgetPastSignals, setAHDSR, setMaxFilterIncrement(2 / stride), ctrl.setup(stride), stereo(pan = v)),
+// 3 setStartAngle(v), 4 onKeyPressed(int(v)), 5 onKeyReleased(int(v)).  Per step: out [n][6] = {imag(0), envelope value, the oscillator's
+// angle increment, the volume, the phasor's angle / pi in (-1, 1], RT-active after the step}.
+void ora_elem_run(int32_t sample_rate, const int32_t *ahdsr4, float sustain, int32_t stride, int32_t with_ctrl, const int64_t *op_sample, const int32_t *op_type,
+                  const double *op_value, int64_t n_ops, int64_t n, double *out) {
+  ResynthElement e;
+  e.with_ctrl = with_ctrl != 0;
+  int64_t o = 0;
+  for (int64_t k = 0; k < n; ++k) {
+    for (; o < n_ops && op_sample[o] <= k; ++o) {
+      double const v = op_value[o];
+      switch (op_type[o]) {
+        case 0: e.setAngleIncrements(v); break;
+        case 1: e.setVolumeTarget(v); break;
+        case 2:
+          e.env.tryAcquire();
+          e.forgetPastSignals();
+          e.env.setAHDSR(AHDSR{ahdsr4[0], ahdsr4[1], ahdsr4[2], ahdsr4[3], sustain}, sample_rate);
+          e.setMaxFilterIncrement(2. / static_cast<double>(stride));
+          e.ctrl.setup(stride);
+          e.setStereoGain(stereo(v));
+          break;
+        case 3: e.setStartAngle(v); break;
+        case 4: e.env.onKeyPressed(static_cast<int32_t>(v)); break;
+        default: e.env.onKeyReleased(static_cast<int32_t>(v)); break;
+      }
+    }
+    e.step();
+    double *r = out + 6 * k;
+    r[0] = e.volume ? e.imag(0) : 0.0;
+    r[1] = e.env.value();
+    r[2] = e.osc.angleIncrements();
+    r[3] = e.volume ? *e.volume : 0.0;
+    r[4] = std::atan2(e.osc.cur.imag(), e.osc.cur.real()) / M_PI;
+    r[5] = e.env.isEnvelopeRTActive() ? 1.0 : 0.0;
+  }
+}
+
+// LogRamp<double> alone: the increments of n steps after setup(from, to, duration, start, interpolation)
+void ora_logramp_run(double from, double to, double duration, double start, int32_t interp, int64_t n, double *out_inc) {
+  LogRamp r;
+  r.setup(from, to, duration, start, interp);
+  for (int64_t k = 0; k < n; ++k) out_inc[k] = r.step();
+}
+
+// Limiter<double> as decided in oracle_dsp.hpp, in place over n stereo frames; target [n] receives getTargetCompressionLevel() per frame
+void ora_limiter_run(double *lr, int64_t n, double *target) {
+  Limiter lim;
+  for (int64_t k = 0; k < n; ++k) { lim.feedOneFrame(lr + 2 * k); if (target) target[k] = lim.getTargetCompressionLevel(); }
+}
+
 // deduceNotesSlow as decided in oracle_resynth.hpp; returns the number of notes, stores the first cap
 int64_t ora_deduce_notes(const float *x, int64_t n, int32_t sr, int32_t half_window_size, int32_t window_kind, int32_t stride, int32_t *start,
                          int32_t *end, double *freq, double *amp_db, int64_t cap) {

@@ -344,6 +344,34 @@ def itp(kind, t, b, c, d):
     return out
 
 
+def elem_run(ops, n, sample_rate=48000, ahdsr=(0, 0, 0, 0), sustain=1.0, stride=1024, with_ctrl=True):
+    """One ResynthElement stepped alone (ora_elem_run).  ops: (sample, op, value), op = 0 setAngleIncrements, 1 setVolumeTarget, 2 note-on
+    preparations (value = pan), 3 setStartAngle, 4 onKeyPressed(delay), 5 onKeyReleased(delay).  Returns [n, 6]: imag(0), envelope, increment,
+    volume, phasor angle / pi, RT-active."""
+    ops = sorted(ops, key=lambda r: r[0])
+    os_ = np.array([r[0] for r in ops], np.int64)
+    ot = np.array([r[1] for r in ops], np.int32)
+    ov = np.array([r[2] for r in ops], np.float64)
+    a4 = np.array(ahdsr, np.int32)
+    out = np.zeros((n, 6), np.float64)
+    lib().ora_elem_run(C.c_int32(sample_rate), _p(a4), C.c_float(sustain), C.c_int32(stride), C.c_int32(1 if with_ctrl else 0), _p(os_), _p(ot), _p(ov),
+                       C.c_int64(len(ops)), C.c_int64(n), _p(out))
+    return out
+
+
+def logramp_run(from_, to, duration, start, interp, n):
+    out = np.zeros(n, np.float64)
+    lib().ora_logramp_run(C.c_double(from_), C.c_double(to), C.c_double(duration), C.c_double(start), C.c_int32(interp), C.c_int64(n), _p(out))
+    return out
+
+
+def limiter_run(lr):
+    x = np.ascontiguousarray(lr, np.float64).copy()
+    tgt = np.zeros(len(x), np.float64)
+    lib().ora_limiter_run(_p(x), C.c_int64(len(x)), _p(tgt))
+    return x, tgt
+
+
 def det_math(x, which):
     """oracle_math.hpp: which = 'log2' | 'log10' | 'exp10' | 'pitch_to_freq' (440 * det_pow(2^(1/12), x - 69)) over a float64 array."""
     x = np.ascontiguousarray(x, np.float64)
