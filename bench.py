@@ -230,32 +230,60 @@ def time_compute_shim(api, calls=400):
             "us_per_call": dt * 1e6, "frames_per_call": 16, "x_realtime": 16 / SR / dt}
 
 
-def time_voice(api, torch, dev, S, seconds, steps):
-    """SURVEY.md section 8 (f4), first slice: gen.voice in SWEEP mode, S synths of 16 channels, a sweep note every 50 ms per synth, output in HBM."""
-    n = int(round(seconds * SR))
-    cfg = api.voice_default_config(seed=99, random_pan=1, length_exponent=2.0)
-    out = torch.empty(S, n, 2, dtype=torch.float32, device=dev)
+def voice_workload(api, which, S, seconds, blocks):
+    """The gen.voice workloads of the bench line: (config, rows, description).  16 channels per synth, a note every 50 ms per synth."""
+    # note-offs come after the note has played out (a note-off before that loses the channel for good, soundengine.h:345-353,470-480), and
+    # the note-ons are spaced so that the 16 channels suffice: nothing is dropped
+    if which == "sweep":
+        cfg = api.voice_default_config(seed=99, random_pan=1, length_exponent=2.0)
+        desc, every, hold = "SWEEP: a 292 ms sweep (100 Hz -> 20 kHz) every 50 ms", SR // 20, (SR * 4) // 10
+    elif which == "birds":
+        cfg, name = api.voice_program(api.VOICE_BIRDS, 8, seed=99)       # "Talkative bird": six Markov steps, frequency transitions, pauses: ~4 s of ~10 ramps
+        desc, every, hold = f"BIRDS program '{name}': a note-on every 350 ms, released after 5 s", (SR * 35) // 100, 5 * SR
+    else:
+        cfg, name = api.voice_program(api.VOICE_ROBOTS, 1, seed=99)      # "Communication": 16 + 14 Markov steps: ~2 s of ~20 tones
+        desc, every, hold = f"ROBOTS program '{name}': a note-on every 250 ms, released after 3.5 s", SR // 4, (7 * SR) // 2
     rows = []
     for s in range(S):
         per = []
-        for k in range(int((steps + 1) * seconds * 20)):
-            on = k * (SR // 20) + 7 * (s % 64)
-            per.append((on, s, 0, k, 440.0, 0.5))
-            per.append((on + (SR * 4) // 10, s, 1, k, 0.0, 0.0))   # released after the 292 ms sweep has ended: the channel is free again
+        for k in range(int(blocks * seconds * SR) // every):
+            on = k * every + 7 * (s % 64)
+            per.append((on, s, 0, k, 220.0 + 20.0 * (k % 23), 0.5))
+            per.append((on + hold, s, 1, k, 0.0, 0.0))
         rows += sorted(per, key=lambda r: r[0])
+    return cfg, rows, desc
+
+
+def time_voice(api, torch, dev, which, S, seconds, steps):
+    """gen.voice, S synths of 16 channels, output resident in HBM.  Blocks are issued asynchronously on a stream of
+    their own (ra_voice_process_device_async): the host's share of block k + 1 (events, Markov chains, schedules, job tables) runs while the
+    device renders block k, as the headline's blocks do.  `kernel_ms` = HIP events around the two kernels of a block."""
+    n = int(round(seconds * SR))
+    cfg, rows, desc = voice_workload(api, which, S, seconds, steps + 2)
+    out = torch.empty(S, n, 2, dtype=torch.float32, device=dev)
+    st = torch.cuda.Stream()
     with api.Voice(cfg, S, 0) as v:
+        v.set_hip_stream(st.cuda_stream)
         v.events(rows)
         v.process_device(n, out.data_ptr())   # warm-up block
-        torch.cuda.synchronize()
+        v.kernel_ms(reset=True)
         t0 = time.perf_counter()
         for _ in range(steps):
-            v.process_device(n, out.data_ptr())
-        torch.cuda.synchronize()
+            v.process_device_async(n, out.data_ptr())
+        t_host = (time.perf_counter() - t0) / steps
+        v.synchronize()
         dt = (time.perf_counter() - t0) / steps
+        kms, launches = v.kernel_ms()
         dropped = v.dropped_note_ons()
-    return {"config": f"gen.voice SWEEP (section 8 f4, first slice): {S} synths x 16 channels, a 292 ms sweep note every 50 ms, {seconds:g} s per step, output resident",
-            "streams": S, "seconds_per_step": seconds, "steps": steps, "ms_per_step": dt * 1e3, "frames_per_s": S * n / dt,
-            "dropped_note_on": int(dropped), "out_rms": float(out.double().pow(2).mean().sqrt().item())}
+        rms = float(out.double().pow(2).mean().sqrt().item())
+        # the same block twice more, one at a time: what a caller that waits for every block sees
+        t0 = time.perf_counter()
+        v.process_device(n, out.data_ptr())
+        dt_sync = time.perf_counter() - t0
+    return {"config": f"gen.voice {desc} on each of {S} synths x 16 channels, {seconds:g} s per step, output resident", "streams": S, "seconds_per_step": seconds,
+            "steps": steps, "ms_per_step": dt * 1e3, "ms_per_step_one_block_at_a_time": dt_sync * 1e3, "host_ms_per_step": t_host * 1e3,
+            "kernel_ms_per_step": {k: x / max(launches, 1) for k, x in kms.items()}, "frames_per_s": S * n / dt, "x_realtime": seconds / dt,
+            "dropped_note_on": int(dropped), "out_rms": rms}
 
 
 def time_config(api, torch, dev, name, cfg_kw, S, seconds, steps, carrier=None):
@@ -488,7 +516,8 @@ def main():
             others.append(time_config(api, torch, dev, "configs[3]: 1000 stereo = 2000 mono streams, N = 8192, H = 2048, P = 128, autotune major / C",
                                       dict(parity, window_size=8192, stride=2048, n_channels=128, use_autotune=1, autotune_type=0, autotune_scale_mode=0,
                                            autotune_root_note=0), 2000, 10.0, 2))
-            others.append(time_voice(api, torch, dev, 256, 10.0, 2))
+            for which in ("sweep", "birds", "robots"):
+                others.append(time_voice(api, torch, dev, which, 256, 10.0, 3))
             others.append(time_compute_shim(api))
         except Exception as e:  # a failure here must not cost the headline line
             others.append({"error": repr(e)})

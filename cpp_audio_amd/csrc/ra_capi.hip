@@ -9,7 +9,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -1614,6 +1621,43 @@ int64_t ra_resynth_notes(const ra_note *notes, int32_t n_notes, int32_t stride, 
 // SoundEngine::tryAcquire (soundengine.h:301-317, 470-480), the notes' ramps cut into the block's jobs, the jobs of a stream packed into
 // slots whose jobs never overlap, the state slots the two kernels exchange.  Everything a block uploads goes through one pinned staging
 // buffer of two (an event says when its copies have drained), so ra_voice_process_device_async returns without waiting for the device.
+// A handful of host threads that share a block's per-stream work (streams are independent synths): run(n, f) calls f(i) for i in 0 .. n - 1.
+// The partition is static — thread w always gets the same contiguous streams — so that what a stream allocates in one block is freed by
+// the same thread in a later one (with a dynamic hand-out the frees crossed threads and the allocator's arena locks ate the gain).
+struct VoicePool {
+  std::vector<std::thread> workers;
+  std::mutex m;
+  std::condition_variable cv_go, cv_done;
+  std::function<void(int)> job;
+  int n = 0, generation = 0, busy = 0;
+  bool quit = false;
+  explicit VoicePool(int threads) {
+    for (int i = 1; i < threads; ++i) workers.emplace_back([this, i] { loop(i); });
+  }
+  ~VoicePool() {
+    { std::lock_guard<std::mutex> g(m); quit = true; }
+    cv_go.notify_all();
+    for (auto &w : workers) w.join();
+  }
+  void share(int w) { const int T = (int)workers.size() + 1; for (int i = (int)((long long)n * w / T), e = (int)((long long)n * (w + 1) / T); i < e; ++i) job(i); }
+  void loop(int w) {
+    int seen = 0;
+    for (;;) {
+      { std::unique_lock<std::mutex> g(m); cv_go.wait(g, [&] { return quit || generation != seen; }); if (quit) return; seen = generation; }
+      share(w);
+      { std::lock_guard<std::mutex> g(m); if (--busy == 0) cv_done.notify_one(); }
+    }
+  }
+  void run(int count, std::function<void(int)> f) {
+    if (workers.empty() || count < 8) { for (int i = 0; i < count; ++i) f(i); return; }
+    { std::lock_guard<std::mutex> g(m); job = std::move(f); n = count; busy = (int)workers.size(); ++generation; }
+    cv_go.notify_all();
+    share(0);
+    std::unique_lock<std::mutex> g(m);
+    cv_done.wait(g, [&] { return busy == 0; });
+  }
+};
+
 struct ra_voice {
   ra_voice_config cfg;
   RaVoiceParams p;
@@ -1622,23 +1666,36 @@ struct ra_voice {
   hipStream_t stream = nullptr;
   float *out = nullptr;
   int64_t out_cap = 0;
-  std::vector<std::deque<ra_voice_event>> pending;
-  std::vector<int64_t> last_sample;
-  std::vector<int32_t> seed_counter;   // `thread_local int seed` of setupAudioElement (gen.voice.h:910): one per stream here
   // a channel is free iff no note is on and every ramp of its engine is finished; a note-off while a ramp is busy leaves that ramp
   // unfinished for good (nothing steps the element any more): the channel is lost (isEnvelopeFinished_internal, soundengine.h:470-480)
   struct Chan { bool odd = false, lost = false; int64_t noteid = -1, t_on = 0; int live = -1; std::vector<std::pair<int64_t, int64_t>> busy; /* element steps [k0, k1) */ };
   struct LiveRamp { rav::Spec spec; int64_t k; int32_t T; int32_t carry; };
-  struct Live { int32_t stream, chan; int64_t t_on, noteid, limit; double fL, fR; int32_t A, R; std::vector<LiveRamp> ramps; };
-  std::vector<Chan> chans;             // [n_streams][P]
-  std::vector<Live> live;              // notes that still have samples to render
-  int64_t dropped = 0;
-  rav::Note scratch;
+  struct Live { int32_t chan; bool done; int64_t t_on, noteid, limit; double fL, fR; int32_t A, R; std::vector<LiveRamp> ramps; };
+  struct JobRec { RaVoiceJob j; int32_t end, live, ramp; };
+  struct Synth { // one stream: everything a block's host work touches for it (so that streams can be handed to different threads)
+    std::vector<ra_voice_event> pending; // queued events from `head` on (consumed by index: a worker thread never frees what the caller's thread allocated)
+    size_t head = 0;
+    int64_t last_sample = 0;
+    int32_t seed_counter = 0;          // `thread_local int seed` of setupAudioElement (gen.voice.h:910): one per stream here
+    std::vector<Chan> chans;           // [P]
+    std::vector<Live> live;            // notes that still have samples to render
+    int64_t dropped = 0;
+    rav::Note scratch;
+    // per block
+    std::vector<JobRec> jobs;
+    std::vector<int32_t> slot_end;
+    int32_t n_states = 0, n_work = 0, slots_used = 0;
+    int64_t job_base = 0, state_base = 0, work_base = 0;
+  };
+  std::vector<Synth> synths;
+  std::unique_ptr<VoicePool> pool;
   // device side
   static constexpr int kTile = 256;
   RaVoiceJob *d_jobs = nullptr; int32_t *d_order = nullptr, *d_slot_begin = nullptr;
   int64_t jobs_cap = 0, slots_cap = 0, order_cap = 0;
   RaVoiceState *d_states[2] = {nullptr, nullptr};
+  RaVoiceSeg *d_seg = nullptr;
+  int64_t seg_cap = 0;
   int64_t states_cap[2] = {0, 0};
   int parity = 0;
   struct Staging { void *h = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool used = false; } staging[2];
@@ -1650,10 +1707,8 @@ struct ra_voice {
   bool profiling = false;
   double ms[2] = {0, 0};
   int64_t launches[2] = {0, 0};
-  // per-block scratch vectors (kept to avoid reallocation)
-  struct JobRec { RaVoiceJob j; int32_t end; };
-  std::vector<std::vector<JobRec>> by_stream;
-  std::vector<int64_t> slot_end;
+  double host_ms[6] = {0, 0, 0, 0, 0, 0}; // RA_VOICE_PROFILE: jobs, prefix, staging wait, emit, grow + copies, launches
+  int64_t host_blocks = 0;
 };
 
 namespace {
@@ -1776,6 +1831,7 @@ int ra_voice_create(const ra_voice_config *cfg, int32_t n_streams, int32_t devic
   p.sample_rate = c.sample_rate;
   p.sine_gain = c.sine_gain;
   p.log_ratio = c.loudness_compensation_amount;
+  p.db_to_log2 = c.loudness_compensation_amount / 20.f * 3.32192809488736f;
   { // include/loudness.h:199-229
     int li = static_cast<int>(c.loudness_level * .1f) - 2;
     li = std::max(0, li); li = std::min(8, li);
@@ -1788,11 +1844,13 @@ int ra_voice_create(const ra_voice_config *cfg, int32_t n_streams, int32_t devic
   HIP_TRY(hipSetDevice(device));
   ra_voice *v = new ra_voice();
   v->cfg = c; v->p = p; v->device = device; v->n_streams = n_streams;
-  v->pending.assign(n_streams, {});
-  v->last_sample.assign(n_streams, 0);
-  v->seed_counter.assign(n_streams, 0);
-  v->chans.assign((size_t)n_streams * c.n_channels, {});
-  v->by_stream.assign(n_streams, {});
+  v->synths.resize(n_streams);
+  for (auto &sy : v->synths) sy.chans.assign(c.n_channels, {});
+  {
+    int threads = std::min(8, std::max(1, (int)std::thread::hardware_concurrency() / 2));
+    if (const char *e = std::getenv("RA_VOICE_THREADS")) threads = std::max(1, std::min(64, std::atoi(e)));
+    v->pool.reset(new VoicePool(threads));
+  }
   v->profiling = std::getenv("RA_VOICE_PROFILE") != nullptr;
   hipError_t e = hipSuccess;
   for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&v->staging[i].done, hipEventDisableTiming);
@@ -1803,10 +1861,14 @@ int ra_voice_create(const ra_voice_config *cfg, int32_t n_streams, int32_t devic
 
 void ra_voice_destroy(ra_voice *v) {
   if (!v) return;
+  if (std::getenv("RA_VOICE_PROFILE") && v->host_blocks)
+    std::fprintf(stderr, "ra_voice host ms per block (%lld blocks): jobs %.3f prefix %.3f staging-wait %.3f emit %.3f grow+copies %.3f launches %.3f\n", (long long)v->host_blocks,
+                 v->host_ms[0] / v->host_blocks, v->host_ms[1] / v->host_blocks, v->host_ms[2] / v->host_blocks, v->host_ms[3] / v->host_blocks, v->host_ms[4] / v->host_blocks,
+                 v->host_ms[5] / v->host_blocks);
   (void)hipSetDevice(v->device);
   (void)hipDeviceSynchronize();
   (void)hipFree(v->out); (void)hipFree(v->d_jobs); (void)hipFree(v->d_order); (void)hipFree(v->d_slot_begin);
-  (void)hipFree(v->d_states[0]); (void)hipFree(v->d_states[1]);
+  (void)hipFree(v->d_states[0]); (void)hipFree(v->d_states[1]); (void)hipFree(v->d_seg);
   for (auto &s : v->staging) { if (s.h) (void)hipHostFree(s.h); if (s.done) (void)hipEventDestroy(s.done); }
   for (auto &t : v->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); (void)hipEventDestroy(t.c); }
   for (auto &e : v->ev_pool) (void)hipEventDestroy(e);
@@ -1837,11 +1899,14 @@ int ra_voice_events(ra_voice *v, const ra_voice_event *ev, int64_t n) {
     if (e.stream < 0 || e.stream >= v->n_streams) return fail(RA_EINVAL, at + "stream out of range");
     if (e.type != 0 && e.type != 1) return fail(RA_EINVAL, at + "type must be 0 (NoteOn) or 1 (NoteOff)");
     if (e.sample < v->t) return fail(RA_EINVAL, at + "its frame has already been processed");
-    if (e.sample < v->last_sample[e.stream]) return fail(RA_EINVAL, at + "samples of a stream must not decrease");
+    if (e.sample < v->synths[e.stream].last_sample) return fail(RA_EINVAL, at + "samples of a stream must not decrease");
     if (e.type == 0 && !(e.velocity > 0.f)) return fail(RA_EINVAL, at + "a note-on needs a velocity > 0 (gen.crtp.h:391)");
     if (e.type == 0 && !(e.frequency > 0.f)) return fail(RA_EINVAL, at + "a note-on needs a frequency > 0 (soundengine.h:972-975)");
-    v->pending[e.stream].push_back(e);
-    v->last_sample[e.stream] = e.sample;
+    ra_voice::Synth &sy = v->synths[e.stream];
+    if (sy.head == sy.pending.size()) { sy.pending.clear(); sy.head = 0; }
+    else if (sy.head > 4096 && sy.head * 2 > sy.pending.size()) { sy.pending.erase(sy.pending.begin(), sy.pending.begin() + (ptrdiff_t)sy.head); sy.head = 0; }
+    sy.pending.push_back(e);
+    sy.last_sample = e.sample;
   }
   return RA_OK;
 }
@@ -1858,61 +1923,141 @@ int voice_grow_bytes(void **ptr, int64_t &cap, int64_t need, size_t elem, hipStr
 }
 #define voice_grow(ptr, cap, need, st) voice_grow_bytes(reinterpret_cast<void **>(ptr), cap, need, sizeof(**(ptr)), st)
 
-// the block's events: ImplCRTP::onEvent (gen.crtp.h:389-449, 541-588) with the engine's acquisition rule
-void voice_block_events(ra_voice *v, int64_t t0, int64_t t1) {
-  const int S = v->n_streams, P = v->cfg.n_channels;
-  for (int s = 0; s < S; ++s) {
-    auto &q = v->pending[s];
-    ra_voice::Chan *ch = v->chans.data() + (size_t)s * P;
-    while (!q.empty() && q.front().sample < t1) {
-      const ra_voice_event e = q.front();
-      q.pop_front();
-      const int64_t te = std::max(e.sample, t0); // (events are not accepted before the frames already processed)
-      if (e.type == 0) { // NoteOn: the first channel whose engine is finished
-        int sel = -1;
-        for (int c = 0; c < P; ++c) if (!ch[c].odd && !ch[c].lost) { sel = c; break; }
-        if (sel < 0) { ++v->dropped; continue; }
-        // setupAudioElement: the reseed (gen.voice.h:910-925), the chain, the schedule
-        int32_t seed_value = 0;
-        if (v->cfg.mode != RA_VOICE_SWEEP) {
-          int32_t &sc = v->seed_counter[s];
-          if (v->cfg.seed_param) sc = v->cfg.seed_param;
-          else if (sc == 257) sc = 1;
-          else ++sc;
-          seed_value = sc;
-        }
-        rav::Note &note = v->scratch;
-        rav::expand_note(v->cfg, e.frequency, v->cfg.seed + (uint64_t)s, seed_value, e.noteid, note);
-        ra_voice::Chan &c = ch[sel];
-        c.odd = true; c.noteid = e.noteid; c.t_on = te;
-        c.busy.clear();
-        ra_voice::Live l;
-        l.stream = s; l.chan = sel; l.t_on = te; l.noteid = e.noteid; l.limit = INT64_MAX; l.A = note.A; l.R = note.R;
-        {
-          const double o_vol = ((static_cast<double>(0.1f) * 1.) / static_cast<double>(0.1f)) * (double)e.velocity; // Element::baseVolume * velocity (gen.crtp.h:425; audioelement.h:1279,2370)
-          double pan = (double)note.pan;
-          pan = std::min(pan, 1.); pan = std::max(pan, -1.);
-          const double ang = (0.25 * M_PI) * (pan + 1.); // stereo(), include/stereo.h:18-27
-          l.fL = o_vol * std::cos(ang); l.fR = o_vol * std::sin(ang);
-        }
-        for (const rav::Play &pl : note.plays) {
-          c.busy.emplace_back(pl.k, pl.T > 0 ? pl.k + pl.T + note.R + 16 : pl.k + 16);
-          if (pl.T > 0 && pl.T + note.R - 1 > 0) l.ramps.push_back({note.specs[pl.spec], pl.k, pl.T, -1});
-        }
-        if (!l.ramps.empty()) { c.live = (int)v->live.size(); v->live.push_back(std::move(l)); }
-        else c.live = -1;
-      } else { // NoteOff: the first channel that last played this note id; it reacts only while its note is on
-        int sel = -1;
-        for (int c = 0; c < P; ++c) if (ch[c].noteid == e.noteid) { sel = c; break; }
-        if (sel < 0 || !ch[sel].odd) continue;
-        const int64_t k = te - ch[sel].t_on; // steps the element took
-        ch[sel].odd = false;
-        for (const auto &b : ch[sel].busy) if (k >= b.first && k < b.second) { ch[sel].lost = true; break; }
-        if (ch[sel].live >= 0) { ra_voice::Live &l = v->live[ch[sel].live]; l.limit = std::min(l.limit, k); }
-        ch[sel].live = -1;
+// the block's events of one stream: ImplCRTP::onEvent (gen.crtp.h:389-449, 541-588) with the engine's acquisition rule
+void voice_stream_events(ra_voice *v, int s, int64_t t0, int64_t t1) {
+  ra_voice::Synth &sy = v->synths[s];
+  const int P = v->cfg.n_channels;
+  ra_voice::Chan *ch = sy.chans.data();
+  while (sy.head < sy.pending.size() && sy.pending[sy.head].sample < t1) {
+    const ra_voice_event e = sy.pending[sy.head++];
+    const int64_t te = std::max(e.sample, t0); // (events are not accepted before the frames already processed)
+    if (e.type == 0) { // NoteOn: the first channel whose engine is finished
+      int sel = -1;
+      for (int c = 0; c < P; ++c) if (!ch[c].odd && !ch[c].lost) { sel = c; break; }
+      if (sel < 0) { ++sy.dropped; continue; }
+      // setupAudioElement: the reseed (gen.voice.h:910-925), the chain, the schedule
+      int32_t seed_value = 0;
+      if (v->cfg.mode != RA_VOICE_SWEEP) {
+        int32_t &sc = sy.seed_counter;
+        if (v->cfg.seed_param) sc = v->cfg.seed_param;
+        else if (sc == 257) sc = 1;
+        else ++sc;
+        seed_value = sc;
       }
+      rav::Note &note = sy.scratch;
+      rav::expand_note(v->cfg, e.frequency, v->cfg.seed + (uint64_t)s, seed_value, e.noteid, note);
+      ra_voice::Chan &c = ch[sel];
+      c.odd = true; c.noteid = e.noteid; c.t_on = te;
+      c.busy.clear();
+      ra_voice::Live l;
+      l.chan = sel; l.done = false; l.t_on = te; l.noteid = e.noteid; l.limit = INT64_MAX; l.A = note.A; l.R = note.R;
+      {
+        const double o_vol = ((static_cast<double>(0.1f) * 1.) / static_cast<double>(0.1f)) * (double)e.velocity; // Element::baseVolume * velocity (gen.crtp.h:425; audioelement.h:1279,2370)
+        double pan = (double)note.pan;
+        pan = std::min(pan, 1.); pan = std::max(pan, -1.);
+        const double ang = (0.25 * M_PI) * (pan + 1.); // stereo(), include/stereo.h:18-27
+        l.fL = o_vol * std::cos(ang); l.fR = o_vol * std::sin(ang);
+      }
+      for (const rav::Play &pl : note.plays) {
+        c.busy.emplace_back(pl.k, pl.T > 0 ? pl.k + pl.T + note.R + 16 : pl.k + 16);
+        if (pl.T > 0 && pl.T + note.R - 1 > 0) l.ramps.push_back({note.specs[pl.spec], pl.k, pl.T, -1});
+      }
+      if (!l.ramps.empty()) { c.live = (int)sy.live.size(); sy.live.push_back(std::move(l)); }
+      else c.live = -1;
+    } else { // NoteOff: the first channel that last played this note id; it reacts only while its note is on
+      int sel = -1;
+      for (int c = 0; c < P; ++c) if (ch[c].noteid == e.noteid) { sel = c; break; }
+      if (sel < 0 || !ch[sel].odd) continue;
+      const int64_t k = te - ch[sel].t_on; // steps the element took
+      ch[sel].odd = false;
+      for (const auto &b : ch[sel].busy) if (k >= b.first && k < b.second) { ch[sel].lost = true; break; }
+      if (ch[sel].live >= 0) { ra_voice::Live &l = sy.live[ch[sel].live]; l.limit = std::min(l.limit, k); }
+      ch[sel].live = -1;
     }
   }
+}
+
+// one stream's share of a block, first half: events, the live notes' ramps cut into this block's jobs (state slots numbered within the
+// stream), the jobs packed into slots — a stream's jobs in begin order, each into the lowest slot that is free again (greedy interval colouring)
+void voice_stream_jobs(ra_voice *v, int s, int64_t t0, int64_t t1) {
+  ra_voice::Synth &sy = v->synths[s];
+  const int L = ra_voice::kTile;
+  voice_stream_events(v, s, t0, t1);
+  sy.jobs.clear();
+  sy.n_states = 0; sy.n_work = 0;
+  for (size_t li = 0; li < sy.live.size(); ++li) {
+    ra_voice::Live &l = sy.live[li];
+    bool more = false;
+    for (size_t ri = 0; ri < l.ramps.size(); ++ri) {
+      ra_voice::LiveRamp &r = l.ramps[ri];
+      const int64_t k_last = std::min(r.k + r.T + l.R - 2, l.limit); // the ramp's last sounding element step (1-based), cut by the note-off
+      const int64_t fa = std::max(l.t_on + r.k - 1, t0), fz = std::min(l.t_on + k_last - 1, t1 - 1);
+      const bool goes_on = l.t_on + k_last - 1 >= t1;
+      more |= goes_on;
+      if (fa > fz) continue;
+      ra_voice::JobRec jr;
+      RaVoiceJob &j = jr.j;
+      j.from = r.spec.from; j.to = r.spec.to; j.dur = r.spec.dur; j.cur0 = r.spec.start;
+      j.vol = (double)r.spec.vol; j.fL = l.fL; j.fR = l.fR;
+      j.C = (j.to == j.from) ? (double)1.f : -std::log(j.from / j.to) / (j.to - j.from);
+      j.l2r = (r.spec.interp == RA_ITP_PROPORTIONAL_VALUE_DERIVATIVE) ? std::log2(j.to / j.from) : 0.0;
+      j.begin = (int32_t)(fa - t0); j.n = (int32_t)(fz - fa + 1);
+      j.j0 = (int32_t)(fa - l.t_on - r.k + 2);
+      j.T = r.T; j.A = l.A; j.R = l.R; j.interp = r.spec.interp;
+      j.state_in = (j.j0 == 1) ? -1 : r.carry;
+      j.stream = s; j.slot = 0;
+      const int32_t tiles = (j.begin + j.n - 1) / L - j.begin / L;
+      j.state_tiles = sy.n_states;
+      sy.n_states += tiles;
+      j.state_out = goes_on ? sy.n_states++ : -1;
+      if (tiles > 0 || goes_on) ++sy.n_work;
+      jr.end = j.begin + j.n; jr.live = (int32_t)li; jr.ramp = (int32_t)ri;
+      sy.jobs.push_back(jr);
+    }
+    l.done = !more;
+  }
+  std::sort(sy.jobs.begin(), sy.jobs.end(), [](const ra_voice::JobRec &a, const ra_voice::JobRec &b) { return a.j.begin < b.j.begin; });
+  sy.slot_end.clear();
+  for (auto &jr : sy.jobs) {
+    int sl = -1;
+    for (size_t k = 0; k < sy.slot_end.size(); ++k) if (sy.slot_end[k] <= jr.j.begin) { sl = (int)k; break; }
+    if (sl < 0) { sl = (int)sy.slot_end.size(); sy.slot_end.push_back(0); }
+    sy.slot_end[sl] = jr.end;
+    jr.j.slot = sl;
+  }
+  sy.slots_used = (int32_t)sy.slot_end.size();
+}
+
+// second half, once the streams' offsets are known: the state slots become block-wide indices (and are remembered by the ramps that go
+// on), the jobs go to the staging image sorted by (slot, begin), finished notes are retired
+void voice_stream_emit(ra_voice *v, int s, int g, RaVoiceJob *hj, int32_t *hs, int32_t *ho) {
+  ra_voice::Synth &sy = v->synths[s];
+  const int L = ra_voice::kTile;
+  int32_t fill[1024];
+  for (int k = 0; k < g; ++k) fill[k] = 0;
+  for (auto &jr : sy.jobs) ++fill[jr.j.slot];
+  int64_t o = sy.job_base;
+  for (int k = 0; k < g; ++k) { hs[(size_t)s * g + k] = (int32_t)o; const int c = fill[k]; fill[k] = (int32_t)o; o += c; }
+  int64_t w = sy.work_base;
+  for (auto &jr : sy.jobs) { // (begin order within a slot is the order of `jobs`)
+    RaVoiceJob &j = jr.j;
+    j.state_tiles += (int32_t)sy.state_base;
+    if (j.state_out >= 0) j.state_out += (int32_t)sy.state_base;
+    sy.live[jr.live].ramps[jr.ramp].carry = j.state_out;
+    const int at = fill[j.slot]++;
+    hj[at] = j;
+    if (j.state_out >= 0 || (j.begin + j.n - 1) / L > j.begin / L) ho[w++] = at;
+  }
+  // retire the notes that have been rendered to their end (a channel stays taken until its note-off)
+  size_t keep = 0;
+  for (size_t li = 0; li < sy.live.size(); ++li) {
+    ra_voice::Live &l = sy.live[li];
+    ra_voice::Chan &c = sy.chans[l.chan];
+    const bool mine = c.live == (int)li;
+    if (!l.done) { if (mine) c.live = (int)keep; if (keep != li) sy.live[keep] = std::move(l); ++keep; }
+    else if (mine) c.live = -1;
+  }
+  sy.live.resize(keep);
 }
 
 void *voice_stage(ra_voice *v, size_t bytes, int &err) { // the pinned staging buffer of this block (waits for the block before last to have drained it)
@@ -1933,109 +2078,53 @@ int voice_block(ra_voice *v, int64_t n, float *d_out) {
   if (n > INT32_MAX / 4) return fail(RA_EINVAL, "a block must have fewer than 2^29 frames");
   const int S = v->n_streams, L = ra_voice::kTile;
   const int64_t t0 = v->t, t1 = v->t + n;
-  voice_block_events(v, t0, t1);
-  // ---- the live notes' ramps -> this block's jobs, per stream ----
-  for (auto &b : v->by_stream) b.clear();
-  int64_t n_states = 0, n_jobs = 0;
-  {
-    std::vector<ra_voice::Live> keep;
-    keep.reserve(v->live.size());
-    for (auto &l : v->live) {
-      bool more = false;
-      for (auto &r : l.ramps) {
-        if (r.T <= 0) continue;
-        const int64_t k_last = std::min(r.k + r.T + l.R - 2, l.limit); // the ramp's last sounding element step (1-based), cut by the note-off
-        const int64_t fa = std::max(l.t_on + r.k - 1, t0), fz = std::min(l.t_on + k_last - 1, t1 - 1);
-        if (l.t_on + k_last - 1 >= t1) more = true;
-        if (fa > fz) continue;
-        ra_voice::JobRec jr;
-        RaVoiceJob &j = jr.j;
-        j.from = r.spec.from; j.to = r.spec.to; j.dur = r.spec.dur; j.cur0 = r.spec.start;
-        j.vol = (double)r.spec.vol; j.fL = l.fL; j.fR = l.fR;
-        j.begin = (int32_t)(fa - t0); j.n = (int32_t)(fz - fa + 1);
-        j.j0 = (int32_t)(fa - l.t_on - r.k + 2);
-        j.T = r.T; j.A = l.A; j.R = l.R; j.interp = r.spec.interp;
-        j.state_in = (j.j0 == 1) ? -1 : r.carry;
-        j.stream = l.stream; j.slot = 0;
-        const bool goes_on = l.t_on + k_last - 1 >= t1;
-        const int32_t tiles = (j.begin + j.n - 1) / L - j.begin / L;
-        j.state_tiles = (int32_t)n_states;
-        n_states += tiles;
-        j.state_out = goes_on ? (int32_t)n_states++ : -1;
-        r.carry = j.state_out;
-        jr.end = j.begin + j.n;
-        v->by_stream[l.stream].push_back(jr);
-        ++n_jobs;
-      }
-      const bool mine_on = v->chans[(size_t)l.stream * v->cfg.n_channels + l.chan].live >= 0 &&
-                           v->live[v->chans[(size_t)l.stream * v->cfg.n_channels + l.chan].live].noteid == l.noteid &&
-                           v->live[v->chans[(size_t)l.stream * v->cfg.n_channels + l.chan].live].t_on == l.t_on;
-      if (more) { if (mine_on) v->chans[(size_t)l.stream * v->cfg.n_channels + l.chan].live = (int)keep.size(); keep.push_back(std::move(l)); }
-      else if (mine_on) v->chans[(size_t)l.stream * v->cfg.n_channels + l.chan].live = -1; // rendered to its end; the channel stays taken until the note-off
-    }
-    v->live.swap(keep);
-  }
-  // ---- slots: a stream's jobs in begin order, each into the lowest slot that is free again (greedy interval colouring) ----
+  auto clk = [] { return std::chrono::steady_clock::now(); };
+  auto lap = [v](std::chrono::steady_clock::time_point &a, int i) { const auto b = std::chrono::steady_clock::now(); v->host_ms[i] += std::chrono::duration<double, std::milli>(b - a).count(); a = b; };
+  auto tp = clk();
+  v->pool->run(S, [v, t0, t1](int s) { voice_stream_jobs(v, s, t0, t1); });
+  lap(tp, 0);
+  int64_t n_jobs = 0, n_states = 0, n_work = 0;
   int g_needed = 1;
-  for (int s = 0; s < S; ++s) {
-    auto &jobs = v->by_stream[s];
-    std::sort(jobs.begin(), jobs.end(), [](const ra_voice::JobRec &a, const ra_voice::JobRec &b) { return a.j.begin < b.j.begin; });
-    v->slot_end.clear();
-    for (auto &jr : jobs) {
-      int sl = -1;
-      for (size_t k = 0; k < v->slot_end.size(); ++k) if (v->slot_end[k] <= jr.j.begin) { sl = (int)k; break; }
-      if (sl < 0) { sl = (int)v->slot_end.size(); v->slot_end.push_back(0); }
-      v->slot_end[sl] = jr.end;
-      jr.j.slot = sl;
-    }
-    g_needed = std::max(g_needed, (int)v->slot_end.size());
+  for (auto &sy : v->synths) {
+    sy.job_base = n_jobs; sy.state_base = n_states; sy.work_base = n_work;
+    n_jobs += (int64_t)sy.jobs.size(); n_states += sy.n_states; n_work += sy.n_work;
+    g_needed = std::max(g_needed, (int)sy.slots_used);
   }
+  if (n_states > INT32_MAX - 2 || n_jobs > INT32_MAX - 2) return fail(RA_EINVAL, "the block has too many ramps: process it in shorter pieces");
   const int g_log2 = pow2_ceil_log2(g_needed), g = 1 << g_log2;
   if (g > 1024) return fail(RA_EINTERNAL, "more than 1024 overlapping ramps in a stream");
-  // ---- staging image: jobs sorted by (stream, slot, begin), the slots' offsets, the pre-pass order (longest first) ----
+  // ---- staging image: jobs sorted by (stream, slot, begin), the slots' offsets, the jobs the pre-pass works on ----
   const int64_t n_slots = (int64_t)S * g + 1;
-  const size_t bytes_jobs = sizeof(RaVoiceJob) * (size_t)n_jobs, bytes_slots = sizeof(int32_t) * (size_t)n_slots, bytes_order = sizeof(int32_t) * (size_t)n_jobs;
+  const size_t bytes_jobs = sizeof(RaVoiceJob) * (size_t)n_jobs, bytes_slots = sizeof(int32_t) * (size_t)n_slots, bytes_order = sizeof(int32_t) * (size_t)n_work;
   int err = RA_OK;
+  lap(tp, 1);
   char *h = static_cast<char *>(voice_stage(v, bytes_jobs + bytes_slots + bytes_order + 64, err));
   if (err) return err;
+  lap(tp, 2);
   RaVoiceJob *hj = reinterpret_cast<RaVoiceJob *>(h);
   int32_t *hs = reinterpret_cast<int32_t *>(h + bytes_jobs), *ho = hs + n_slots;
-  int64_t at = 0, n_work = 0;
-  {
-    std::vector<int32_t> fill(g);
-    for (int s = 0; s < S; ++s) {
-      auto &jobs = v->by_stream[s];
-      std::fill(fill.begin(), fill.end(), 0);
-      for (auto &jr : jobs) ++fill[jr.j.slot];
-      int64_t o = at;
-      for (int k = 0; k < g; ++k) { hs[(size_t)s * g + k] = (int32_t)o; const int c = fill[k]; fill[k] = (int32_t)o; o += c; }
-      for (auto &jr : jobs) hj[fill[jr.j.slot]++] = jr.j; // (begin order within a slot is the order of `jobs`)
-      at = o;
-    }
-    hs[(size_t)S * g] = (int32_t)at;
-    for (int64_t i = 0; i < n_jobs; ++i) {
-      const RaVoiceJob &j = hj[i];
-      if (j.state_out >= 0 || (j.begin + j.n - 1) / L > j.begin / L) ho[n_work++] = (int32_t)i;
-    }
-    std::sort(ho, ho + n_work, [hj](int32_t a, int32_t b) { return hj[a].n > hj[b].n; });
-  }
+  v->pool->run(S, [v, g, hj, hs, ho](int s) { voice_stream_emit(v, s, g, hj, hs, ho); });
+  hs[(size_t)S * g] = (int32_t)n_jobs;
+  lap(tp, 3);
   // ---- device buffers, copies, launches ----
+  static_assert(sizeof(RaVoiceJob) == 120, "layout of the job record");
   RA_TRY(voice_grow(&v->d_jobs, v->jobs_cap, n_jobs + 1, v->stream));
-  static_assert(sizeof(RaVoiceJob) == 104, "layout of the job record");
-  RA_TRY(voice_grow(&v->d_order, v->order_cap, n_jobs + 1, v->stream));
+  RA_TRY(voice_grow(&v->d_order, v->order_cap, n_work + 1, v->stream));
   RA_TRY(voice_grow(&v->d_slot_begin, v->slots_cap, n_slots, v->stream));
   const int cur = v->parity, prev = cur ^ 1;
   RA_TRY(voice_grow(&v->d_states[cur], v->states_cap[cur], n_states + 1, v->stream));
+  RA_TRY(voice_grow(&v->d_seg, v->seg_cap, n_states + 1, v->stream));
   if (!v->d_states[prev]) RA_TRY(voice_grow(&v->d_states[prev], v->states_cap[prev], 1, v->stream));
   if (n_jobs) HIP_TRY(hipMemcpyAsync(v->d_jobs, hj, bytes_jobs, hipMemcpyHostToDevice, v->stream));
   HIP_TRY(hipMemcpyAsync(v->d_slot_begin, hs, bytes_slots, hipMemcpyHostToDevice, v->stream));
-  if (n_work) HIP_TRY(hipMemcpyAsync(v->d_order, ho, sizeof(int32_t) * (size_t)n_work, hipMemcpyHostToDevice, v->stream));
+  if (n_work) HIP_TRY(hipMemcpyAsync(v->d_order, ho, bytes_order, hipMemcpyHostToDevice, v->stream));
   {
     ra_voice::Staging &sg = v->staging[v->stage_parity];
     HIP_TRY(hipEventRecord(sg.done, v->stream));
     sg.used = true;
     v->stage_parity ^= 1;
   }
+  lap(tp, 4);
   ra_voice::Timed tm{nullptr, nullptr, nullptr};
   if (v->profiling) {
     hipEvent_t *evs[3] = {&tm.a, &tm.b, &tm.c};
@@ -2045,13 +2134,15 @@ int voice_block(ra_voice *v, int64_t n, float *d_out) {
     }
     HIP_TRY(hipEventRecord(tm.a, v->stream));
   }
-  ra_voice_launch_pre(v->p, v->d_jobs, v->d_order, (int)n_work, v->d_states[prev], v->d_states[cur], L, v->stream);
+  ra_voice_launch_pre(v->p, v->d_jobs, v->d_order, (int)n_work, (int)n_states, v->d_states[prev], v->d_states[cur], v->d_seg, L, v->stream);
   HIP_TRY(hipGetLastError());
   if (v->profiling) HIP_TRY(hipEventRecord(tm.b, v->stream));
   if (ra_voice_launch_render(v->p, v->d_jobs, v->d_slot_begin, v->d_states[prev], v->d_states[cur], S, n, L, g_log2, d_out, v->stream) != 0)
-    return fail(RA_EHIP, "ra_voice: hipFuncSetAttribute(render)");
+    return fail(RA_EHIP, "ra_voice: the render launch was refused (too many (stream, tile) units, or hipFuncSetAttribute failed)");
   HIP_TRY(hipGetLastError());
   if (v->profiling) { HIP_TRY(hipEventRecord(tm.c, v->stream)); v->timed.push_back(tm); ++v->launches[0]; ++v->launches[1]; }
+  lap(tp, 5);
+  ++v->host_blocks;
   v->parity ^= 1;
   v->t += n;
   return RA_OK;
@@ -2092,7 +2183,9 @@ int ra_voice_process_host(ra_voice *v, int64_t n, float *h_out) {
 
 int64_t ra_voice_dropped_note_ons(ra_voice *v) {
   if (!v) return fail(RA_EINVAL, "null context");
-  return v->dropped;
+  int64_t d = 0;
+  for (const auto &sy : v->synths) d += sy.dropped;
+  return d;
 }
 
 int ra_voice_get_kernel_ms(ra_voice *v, double *ms2, int64_t *launches2, int32_t reset) {

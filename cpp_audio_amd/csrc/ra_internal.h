@@ -274,6 +274,7 @@ struct RaSpan {
 struct RaVoiceParams {
   int sample_rate;
   float sine_gain, log_ratio, max_db;
+  float db_to_log2;                   // log_ratio / 20 * log2(10): 10^(log_ratio dB / 20) = 2^(db_to_log2 dB)
   float loud_freqs[29], loud_elv[29]; // include/loudness.h:9-39 and the equal-loudness row of the configured level (:199-216)
 };
 // One ramp of one note inside one block (a job): the LogRamp spec, the output factors, the envelope's three integers, where its samples
@@ -281,6 +282,7 @@ struct RaVoiceParams {
 struct RaVoiceJob {
   double from, to, dur, cur0;   // LogRamp::setup(from, to, duration, start sample)
   double vol, fL, fR;           // the ramp's volume (spec volume); Element::baseVolume * velocity * the note's stereo gains
+  double C, l2r;                // LogRamp's proportionality constant (audioelement.h:2560-2571); log2(to / from) for PROPORTIONAL_VALUE_DERIVATIVE, else 0
   int32_t begin, n;             // block-relative frame of the first step taken in this block; steps taken in this block
   int32_t j0;                   // index (1-based) of that first step within the ramp
   int32_t T, A, R;              // steps until the key release; attack and release lengths
@@ -291,8 +293,9 @@ struct RaVoiceJob {
   int32_t stream, slot;
 };
 struct RaVoiceState { double cur, theta, y; int32_t swapped, loud_k; };
-void ra_voice_launch_pre(const RaVoiceParams &p, const RaVoiceJob *jobs, const int32_t *order, int n_work, const RaVoiceState *st_prev, RaVoiceState *st_cur, int L,
-                         hipStream_t st);
+struct RaVoiceSeg { double dtheta, a, b; int32_t job, loud_k; }; // pre-pass scratch, one per state slot: what the slot's segment adds
+void ra_voice_launch_pre(const RaVoiceParams &p, const RaVoiceJob *jobs, const int32_t *order, int n_work, int n_slots, const RaVoiceState *st_prev, RaVoiceState *st_cur,
+                         RaVoiceSeg *seg, int L, hipStream_t st);
 int ra_voice_launch_render(const RaVoiceParams &p, const RaVoiceJob *jobs, const int32_t *slot_begin, const RaVoiceState *st_prev, const RaVoiceState *st_cur, int n_streams,
                            int64_t n, int L, int g_log2, float *d_out, hipStream_t st);
 

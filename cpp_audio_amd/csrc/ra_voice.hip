@@ -36,37 +36,43 @@ constexpr int TS = 8; // samples a lane parks in LDS before the wave sums the sl
 struct Ramp { // the registers of a lane while it steps a job
   double cur, from, to, dur, inv_dur, C, l2r; // LogRamp; l2r = log2(to / from) (PROPORTIONAL_VALUE_DERIVATIVE only)
   double theta, y;                            // phase sum (units of pi, kept in [0, 2)); the loudness volume
+  float lo_f, hi_f, inv_w, lo_e, hi_e;        // the loudness table interval the ramp is in: its two frequencies, 1 / width, its two levels
   int interp, loud_k, swapped;
 };
 
 // loudness::equal_loudness_volume_from_freq, include/loudness.h:246-274 over :157-186 (float arithmetic).  The reference finds the table
-// interval by bisection on every call; a ramp moves through the 29 frequencies in order, so the interval of the previous sample is
-// carried in `k` (freqs[k] <= freq < freqs[k + 1], clamped to 0 .. 27) and walked: the same interval.  The final powf(10, x) runs as
-// exp2f(x log2 10): a float ulp or two from the reference's pow on a gain.
-__device__ inline float loudness_volume(const RaVoiceParams &p, const float *__restrict__ lf, const float *__restrict__ le, float freq, int &k) {
-  k = min(max(k, 0), 27);
+// interval by bisection on every call; a ramp moves through the 29 frequencies in order, so the interval it is in — freqs[k] <= freq <
+// freqs[k + 1], k clamped to 0 .. 27 — is kept in registers and walked when the frequency leaves it (28 times per sweep, not per sample):
+// the same interval, the same interpolation ratio * elv[k + 1] + (1 - ratio) * elv[k] (at the interval's ends and outside the table the
+// ratio is 0 or 1: the reference's three cases).  The final powf(10, log_ratio (db - max_db) / 20) runs as one exp2f: float ulps on a gain.
+__device__ inline void loudness_seek(Ramp &r, const float *__restrict__ lf, const float *__restrict__ le, float freq) {
+  int k = min(max(r.loud_k, 0), 27);
   while (k < 27 && freq >= lf[k + 1]) ++k;
   while (k > 0 && freq < lf[k]) --k;
-  const int min_ = k, max_ = k + 1; // what the bisection of loudness.h:231-244 ends with
-  int kk; float ratio;
-  if (freq <= lf[min_]) { kk = min_; ratio = 1.f; }
-  else if (freq >= lf[max_]) { kk = max_; ratio = 1.f; }
-  else { kk = max_; ratio = (freq - lf[min_]) / (lf[max_] - lf[min_]); }
-  const float db = (ratio == 1.f) ? le[kk] : ratio * le[kk] + (1.f - ratio) * le[kk - 1];
+  r.loud_k = k;
+  r.lo_f = lf[k]; r.hi_f = lf[k + 1]; r.inv_w = 1.f / (r.hi_f - r.lo_f); r.lo_e = le[k]; r.hi_e = le[k + 1];
+}
+__device__ inline float loudness_volume(Ramp &r, const RaVoiceParams &p, const float *__restrict__ lf, const float *__restrict__ le, float freq) {
+  if ((freq < r.lo_f && r.loud_k > 0) || (freq >= r.hi_f && r.loud_k < 27)) loudness_seek(r, lf, le, freq);
+  const float ratio = fminf(fmaxf((freq - r.lo_f) * r.inv_w, 0.f), 1.f);
+  const float db = ratio * r.hi_e + (1.f - ratio) * r.lo_e;
   if (db > p.max_db) return 1.f;
-  return exp2f((p.log_ratio * (db - p.max_db) / 20.f) * 3.32192809488736f);
+  return exp2f(p.db_to_log2 * (db - p.max_db));
 }
 
-__device__ inline double one_pole_k(double inc_abs) { // a / (1 + a), a = pi inc (Filter<LOW_PASS>): v_rcp_f64 and two Newton steps (an ulp)
-  const double a = M_PI * inc_abs, d = 1.0 + a;
+__device__ inline double rcp_newton(double d) { // 1 / d: v_rcp_f64 and two Newton steps instead of the IEEE division (an ulp)
   double r = __builtin_amdgcn_rcp(d);
   r = r * fma(-d, r, 2.0);
   r = r * fma(-d, r, 2.0);
-  return a * r;
+  return r;
+}
+__device__ inline double one_pole_k(double inc_abs) { // a / (1 + a), a = pi inc (Filter<LOW_PASS>)
+  const double a = M_PI * inc_abs;
+  return a * rcp_newton(1.0 + a);
 }
 
 // itp::interpolate(kind, t, b, c, d) as decided (Penner's equations): every one of them is b + c g(t / d)
-__device__ inline double ease01(int kind, double u, double l2r) {
+__device__ __noinline__ double ease01(int kind, double u) {
   switch (kind) {
     case RA_ITP_EASE_IN_QUAD: return u * u;
     case RA_ITP_EASE_OUT_QUAD: return -u * (u - 2.0);
@@ -99,45 +105,51 @@ __device__ inline double ease01(int kind, double u, double l2r) {
   }
 }
 
-// LogRamp::do_step (audioelement.h:2522-2542): the increment of this step; `cur` moves on by C times the increment half a sample later.
-// The two divisions by the ramp's constant duration are multiplications by its reciprocal (an ulp on the increment).
-__device__ inline double ramp_inc(Ramp &r) {
+// LogRamp::do_step (audioelement.h:2522-2542) in two halves.  ramp_tick: the wrap at the ramp's end, then `cur` moves on by C times the
+// increment half a sample later; it returns the time of this step.  ramp_value: the increment at that time.  The two divisions by the
+// ramp's constant duration are multiplications by its reciprocal (an ulp on the increment).
+__device__ inline double ramp_tick(Ramp &r) {
   if (r.cur + 0.5 > r.dur) { r.cur = 0.0; const double t = r.from; r.from = r.to; r.to = t; r.l2r = -r.l2r; r.swapped ^= 1; }
-  const double d = r.to - r.from, u = r.cur * r.inv_dur;
-  double inc;
-  if (r.interp == RA_ITP_LINEAR) inc = fma(d, u, r.from);
-  else if (r.interp == RA_ITP_PROPORTIONAL_VALUE_DERIVATIVE) inc = r.from * exp2(u * r.l2r);
-  else inc = fma(d, ease01(r.interp, u, r.l2r), r.from);
-  const double f = fma(d, (r.cur + 0.5) * r.inv_dur, r.from);
-  r.cur = fma(r.C, f, r.cur);
-  return inc;
+  const double c0 = r.cur;
+  const double f = fma(r.to - r.from, (c0 + 0.5) * r.inv_dur, r.from);
+  r.cur = fma(r.C, f, c0);
+  return c0;
+}
+__device__ inline double ramp_value(const Ramp &r, double c0) {
+  const double d = r.to - r.from, u = c0 * r.inv_dur;
+  if (r.interp == RA_ITP_LINEAR) return fma(d, u, r.from);
+  if (r.interp == RA_ITP_PROPORTIONAL_VALUE_DERIVATIVE) return r.from * exp2(u * r.l2r);
+  return fma(d, ease01(r.interp, u), r.from);
 }
 
-// One step of what carries state: the increment, the phase sum, the loudness volume (LoudnessVolumeAdjusted::setAngleIncrements
+// One step of what carries state besides `cur`: the phase sum and the loudness volume (LoudnessVolumeAdjusted::setAngleIncrements
 // :1291-1298, BaseVolumeAdjusted::step :1195-1216: the filter starts at its first target; its coefficient is re-derived from the
 // increment whenever the volume still differs from the target — when it does not, the coefficient does not matter).
-__device__ inline double ramp_advance(Ramp &r, const RaVoiceParams &p, const float *__restrict__ lf, const float *__restrict__ le, bool first) {
-  const double inc = ramp_inc(r);
-  double th = r.theta + inc;
-  th -= 2.0 * floor(th * 0.5);
-  r.theta = th;
-  const double tgt = (double)loudness_volume(p, lf, le, (float)(inc * 0.5 * (double)p.sample_rate), r.loud_k);
-  r.y = first ? tgt : fma(one_pole_k(fabs(inc)), tgt - r.y, r.y);
+// k_out / tgt_out: the step as the affine map y -> (1 - k) y + k tgt, for the pre-pass' composition.
+__device__ inline double ramp_advance(Ramp &r, const RaVoiceParams &p, const float *__restrict__ lf, const float *__restrict__ le, bool first, double &k_out, double &tgt_out) {
+  const double inc = ramp_value(r, ramp_tick(r));
+  const double tgt = (double)loudness_volume(r, p, lf, le, (float)(inc * 0.5 * (double)p.sample_rate));
+  const double k = first ? 1.0 : one_pole_k(fabs(inc));
+  k_out = k; tgt_out = tgt;
   return inc;
 }
+__device__ inline double wrap2(double th) { return th - 2.0 * floor(th * 0.5); }
 
-__device__ inline void ramp_load(Ramp &r, const RaVoiceJob &J, const RaVoiceState *st) { // st == nullptr: the job's first step is next
-  r.from = J.from; r.to = J.to; r.dur = J.dur; r.inv_dur = 1.0 / J.dur;
-  r.C = (J.to == J.from) ? (double)1.f : -log(J.from / J.to) / (J.to - J.from); // get_linear_proportionality_constant :2560-2571 (symmetric in from / to)
+__device__ inline void ramp_setup(Ramp &r, const RaVoiceJob &J) {
+  r.from = J.from; r.to = J.to; r.dur = J.dur; r.inv_dur = rcp_newton(J.dur);
+  r.C = J.C;       // get_linear_proportionality_constant :2560-2571, from the host (symmetric in from / to: a swap keeps it)
   r.interp = J.interp;
-  r.l2r = (J.interp == RA_ITP_PROPORTIONAL_VALUE_DERIVATIVE) ? log2(J.to / J.from) : 0.0;
-  if (st) {
-    r.cur = st->cur; r.theta = st->theta; r.y = st->y; r.loud_k = st->loud_k; r.swapped = st->swapped;
-    if (r.swapped) { const double t = r.from; r.from = r.to; r.to = t; r.l2r = -r.l2r; }
-  } else { r.cur = J.cur0; r.theta = 0.0; r.y = 0.0; r.loud_k = 14; r.swapped = 0; }
+  r.l2r = J.l2r;
+  r.cur = J.cur0; r.theta = 0.0; r.y = 0.0; r.loud_k = 14; r.swapped = 0;
 }
-__device__ inline void ramp_store(const Ramp &r, RaVoiceState *st) {
-  st->cur = r.cur; st->theta = r.theta; st->y = r.y; st->loud_k = r.loud_k; st->swapped = r.swapped;
+__device__ inline void ramp_swap_if(Ramp &r, int swapped) {
+  if (swapped != r.swapped) { const double t = r.from; r.from = r.to; r.to = t; r.l2r = -r.l2r; r.swapped = swapped; }
+}
+__device__ inline void ramp_load(Ramp &r, const RaVoiceJob &J, const RaVoiceState *st, const float *__restrict__ lf, const float *__restrict__ le) { // st == nullptr: the job's first step is next
+  ramp_setup(r, J);
+  if (st) { r.cur = st->cur; r.theta = st->theta; r.y = st->y; r.loud_k = st->loud_k; ramp_swap_if(r, st->swapped); }
+  r.lo_f = 1.f; r.hi_f = 0.f; r.inv_w = 0.f; r.lo_e = 0.f; r.hi_e = 0.f; // (an empty interval: the first step seeks)
+  loudness_seek(r, lf, le, lf[min(max(r.loud_k, 0), 27)]);
 }
 
 __device__ inline void load_tables(const RaVoiceParams &p, float *lf, float *le) { // (a dynamically indexed kernel-argument array would live in scratch)
@@ -145,37 +157,104 @@ __device__ inline void load_tables(const RaVoiceParams &p, float *lf, float *le)
   __syncthreads();
 }
 
-// ---- pre-pass: the states a block's render needs -------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) ra_voice_pre_kernel(RaVoiceParams p, const RaVoiceJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_work,
-                                                           const RaVoiceState *__restrict__ st_prev, RaVoiceState *__restrict__ st_cur, int L) {
+// ---- pre-pass: the states a block's render needs, in three launches -------------------------------------------------------------------
+// A job's states sit in consecutive slots: one per tile boundary it crosses, then one for the block's end if it goes on.  Slot i closes
+// the job's i-th SEGMENT (from the previous slot's frame — or the job's first frame of the block — to its own).
+//   A  one lane per job, samples in order: LogRamp's time alone (two dependent FMAs per sample) -> `cur` and the swap flag of every slot,
+//      and which job a slot belongs to;
+//   B  one lane per slot: its segment's samples from the segment's start time — the phase the segment adds, and the loudness volume's
+//      one-pole over the segment as ONE affine map y -> a y + b (each sample is one: y + k (tgt - y));
+//   C  one lane per job: the running phase and volume through its slots.
+// B is where the work is (the increment, the loudness gain and the coefficient of every sample), and it is as parallel as the render.
+__global__ void __launch_bounds__(64) ra_voice_pre_a_kernel(const RaVoiceJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_work, const RaVoiceState *__restrict__ st_prev,
+                                                             RaVoiceState *__restrict__ st_cur, RaVoiceSeg *__restrict__ seg, int L) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_work) return;
+  const int ji = order[w];
+  const RaVoiceJob J = jobs[ji];
+  Ramp r;
+  ramp_setup(r, J);
+  if (J.state_in >= 0) { r.cur = st_prev[J.state_in].cur; ramp_swap_if(r, st_prev[J.state_in].swapped); }
+  const int last = J.begin + J.n; // (exclusive)
+  const int steps = (J.state_out >= 0) ? J.n : ((last - 1) / L) * L - J.begin; // up to the last state somebody reads
+  int next_b = (J.begin / L + 1) * L, slot = J.state_tiles;
+  for (int i = 0; i < steps; ++i) {
+    if (J.begin + i == next_b) { st_cur[slot].cur = r.cur; st_cur[slot].swapped = r.swapped; seg[slot].job = ji; ++slot; next_b += L; }
+    ramp_tick(r);
+  }
+  if (J.begin + steps == next_b && J.begin + steps < last) { st_cur[slot].cur = r.cur; st_cur[slot].swapped = r.swapped; seg[slot].job = ji; }
+  if (J.state_out >= 0) { st_cur[J.state_out].cur = r.cur; st_cur[J.state_out].swapped = r.swapped; seg[J.state_out].job = ji; }
+}
+
+__global__ void __launch_bounds__(256) ra_voice_pre_b_kernel(RaVoiceParams p, const RaVoiceJob *__restrict__ jobs, int n_slots, const RaVoiceState *__restrict__ st_prev,
+                                                              const RaVoiceState *__restrict__ st_cur, RaVoiceSeg *__restrict__ seg, int L) {
   __shared__ float lf[29], le[29];
   load_tables(p, lf, le);
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= n_slots) return;
+  const RaVoiceJob J = jobs[seg[slot].job];
+  const int s = slot - J.state_tiles;                       // the segment's index within the job
+  const int first_b = (J.begin / L + 1) * L;                // the job's first tile boundary
+  const int f0 = (s == 0) ? J.begin : first_b + (s - 1) * L;
+  const int f1 = (slot == J.state_out) ? J.begin + J.n : first_b + s * L;
+  Ramp r;
+  ramp_setup(r, J);
+  if (s == 0) { if (J.state_in >= 0) { r.cur = st_prev[J.state_in].cur; r.loud_k = st_prev[J.state_in].loud_k; ramp_swap_if(r, st_prev[J.state_in].swapped); } }
+  else { r.cur = st_cur[slot - 1].cur; ramp_swap_if(r, st_cur[slot - 1].swapped); }
+  r.lo_f = 1.f; r.hi_f = 0.f; r.inv_w = 0.f; r.lo_e = 0.f; r.hi_e = 0.f;
+  r.loud_k = 14;
+  loudness_seek(r, lf, le, lf[14]);
+  double dth = 0.0, a = 1.0, b = 0.0;
+  int j = J.j0 + (f0 - J.begin);
+  for (int f = f0; f < f1; ++f, ++j) {
+    double k, tgt;
+    dth += ramp_advance(r, p, lf, le, j == 1, k, tgt);
+    a = a - k * a;             // (1 - k) a
+    b = fma(k, tgt - b, b);    // (1 - k) b + k tgt
+  }
+  seg[slot].dtheta = dth; seg[slot].a = a; seg[slot].b = b; seg[slot].loud_k = r.loud_k;
+}
+
+__global__ void __launch_bounds__(64) ra_voice_pre_c_kernel(const RaVoiceJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_work, const RaVoiceState *__restrict__ st_prev,
+                                                             RaVoiceState *__restrict__ st_cur, const RaVoiceSeg *__restrict__ seg, int L) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= n_work) return;
   const RaVoiceJob J = jobs[order[w]];
-  Ramp r;
-  ramp_load(r, J, J.state_in >= 0 ? st_prev + J.state_in : nullptr);
-  // steps up to the last state somebody reads: the block's end if the job goes on, else the last tile boundary it crosses
-  const int last = J.begin + J.n; // (exclusive)
-  const int steps = (J.state_out >= 0) ? J.n : ((last - 1) / L) * L - J.begin;
-  int next_b = (J.begin / L + 1) * L; // the next tile boundary
-  int slot = J.state_tiles;
-  int j = J.j0;
-  for (int i = 0; i < steps; ++i, ++j) {
-    if (J.begin + i == next_b) { ramp_store(r, st_cur + slot); ++slot; next_b += L; }
-    ramp_advance(r, p, lf, le, j == 1);
+  double th = 0.0, y = 0.0;
+  if (J.state_in >= 0) { th = st_prev[J.state_in].theta; y = st_prev[J.state_in].y; }
+  const int tiles = (J.begin + J.n - 1) / L - J.begin / L;
+  const int n_slots = tiles + (J.state_out >= 0 ? 1 : 0);
+  for (int i = 0; i < n_slots; ++i) {
+    const int slot = J.state_tiles + i;
+    th = wrap2(th + seg[slot].dtheta);
+    y = fma(seg[slot].a, y, seg[slot].b);
+    st_cur[slot].theta = th; st_cur[slot].y = y; st_cur[slot].loud_k = seg[slot].loud_k;
   }
-  if (J.begin + steps == next_b && J.begin + steps < last) { ramp_store(r, st_cur + slot); } // the boundary the loop ended on
-  if (J.state_out >= 0) ramp_store(r, st_cur + J.state_out);
 }
 
 // ---- render --------------------------------------------------------------------------------------------------------------------------
-// sin(pi x) for x in [0, 2): the device library's sinpi does its own reduction; x is already small
-__device__ inline double osc_imag(double theta) { return sinpi(theta); }
+// sin(pi x), x in [0, 2): reduced to |r| <= 1/2 (sin(pi (1 + r)) = -sin(pi r), sin(pi (+-1 - r)) = sin(pi r)), then the odd series to
+// r^19 (the next term is below 3e-16 at r = 1/2)
+__device__ inline double osc_imag(double theta) {
+  double r = theta - 1.0;                     // [-1, 1): the value is -sin(pi r)
+  r = (r > 0.5) ? 1.0 - r : ((r < -0.5) ? -1.0 - r : r);
+  const double z = r * r;
+  double v = -2.2948428997269856e-08;                              // (-1)^k pi^(2k+1) / (2k+1)!, k = 9 .. 0
+  v = fma(v, z, 7.952054001475508e-07);
+  v = fma(v, z, -2.1915353447830204e-05);
+  v = fma(v, z, 0.00046630280576761234);
+  v = fma(v, z, -0.007370430945714348);
+  v = fma(v, z, 0.08214588661112819);
+  v = fma(v, z, -0.5992645293207919);
+  v = fma(v, z, 2.550164039877345);
+  v = fma(v, z, -5.167712780049969);
+  v = fma(v, z, 3.141592653589793);
+  return -(v * r);
+}
 __device__ inline double alias_gain(double inc) { // freqAliasingMultiplicator, audioelement.h:466-483
-  if (inc == 0.0) return 1.0;
   if (inc > 0.0 && inc <= 0.25) return 1.0;
-  const double half_n = 1.0 / inc;
+  if (inc == 0.0) return 1.0;
+  const double half_n = rcp_newton(inc);
   if (half_n < 1.0) return 0.0;
   if (half_n > 4.0) return 1.0;
   return (half_n - 1.0) * (1.0 / 3.0);
@@ -187,16 +266,17 @@ struct Seg { // the piece of a job a lane renders inside its tile
   int lo, hi, j, T, A;
 };
 
-__device__ inline void seg_open(Seg &g, const RaVoiceJob &J, int f_lo, int f_hi, int q, int L, const RaVoiceState *__restrict__ st_prev, const RaVoiceState *__restrict__ st_cur) {
+__device__ inline void seg_open(Seg &g, const RaVoiceJob &J, int f_lo, int f_hi, int q, int L, const RaVoiceState *__restrict__ st_prev, const RaVoiceState *__restrict__ st_cur,
+                                const float *__restrict__ lf, const float *__restrict__ le) {
   g.lo = max(J.begin, f_lo);
   g.hi = min(J.begin + J.n, f_hi);
   const RaVoiceState *st;
   if (g.lo == J.begin) st = (J.state_in >= 0) ? st_prev + J.state_in : nullptr;
   else st = st_cur + J.state_tiles + (q - (J.begin / L + 1));
-  ramp_load(g.r, J, st);
+  ramp_load(g.r, J, st, lf, le);
   g.j = J.j0 + (g.lo - J.begin);
   g.T = J.T; g.A = J.A;
-  g.inv_A = 1.0 / (double)J.A; g.inv_R = 1.0 / (double)J.R;
+  g.inv_A = rcp_newton((double)J.A); g.inv_R = rcp_newton((double)J.R);
   g.top = (J.T < J.A) ? (double)J.T * g.inv_A : 1.0; // the envelope's value when the key is released (startReleased, audioelement.h:836-841)
   g.vol = J.vol; g.fL = J.fL; g.fR = J.fR;
 }
@@ -210,11 +290,11 @@ __global__ void __launch_bounds__(MAXT) ra_voice_render_kernel(RaVoiceParams p, 
   float *lf = reinterpret_cast<float *>(tile + (size_t)nt * (2 * TS + 1)), *le = lf + 29;
   load_tables(p, lf, le);
   const int U = nt >> g_log2;                       // (stream, tile) units of this workgroup
-  const long long unit0 = (long long)blockIdx.x * U, n_units = (long long)n_streams * n_tiles;
+  const int unit0 = (int)blockIdx.x * U, n_units = n_streams * n_tiles; // (the launcher refuses more than 2^31 - 1 units)
   const int u = l >> g_log2, s = l & (g - 1);
-  const long long unit = unit0 + u;
+  const int unit = unit0 + u;
   const bool valid = unit < n_units;
-  const int stream = valid ? (int)(unit / n_tiles) : 0, q = valid ? (int)(unit % n_tiles) : 0;
+  const int stream = valid ? unit / n_tiles : 0, q = valid ? unit - stream * n_tiles : 0;
   const int f_lo = q * L, f_hi = min(n, f_lo + L);
   // the slot's jobs are disjoint and in time order: the first one that ends after the tile's begin
   int jb = 0, je = 0;
@@ -230,21 +310,20 @@ __global__ void __launch_bounds__(MAXT) ra_voice_render_kernel(RaVoiceParams p, 
   }
   Seg sg;
   bool have = false;
-  if (jb < je) {
-    const RaVoiceJob J = jobs[jb];
-    if (J.begin < f_hi) { seg_open(sg, J, f_lo, f_hi, q, L, st_prev, st_cur); have = true; }
-  }
+  constexpr int kNever = 0x7fffffff;
+  int next_lo = kNever; // the frame at which the slot's next job starts to sound inside this tile
+  if (jb < je) { const int b = jobs[jb].begin; if (b < f_hi) next_lo = max(b, f_lo); }
   double *mine = tile + (size_t)l * (2 * TS + 1);
   const int n_out = U * TS * 2;
   for (int base = 0; base < L; base += TS) { // (every unit of the workgroup has the same tile length but the block's last tile may be cut: f_hi)
     const int fb = f_lo + base;
-    const bool work = have && sg.lo < fb + TS && fb < f_hi; // (sg.hi > fb holds: finished segments are replaced at once)
+    const bool work = (have || next_lo < fb + TS) && fb < f_hi;
     if (!__syncthreads_or(work ? 1 : 0)) {
       for (int t = l; t < n_out; t += nt) {
         const int uu = t / (TS * 2), i = (t >> 1) % TS, ch = t & 1;
-        const long long un = unit0 + uu;
+        const int un = unit0 + uu;
         if (un >= n_units) continue;
-        const int st2 = (int)(un / n_tiles), q2 = (int)(un % n_tiles);
+        const int st2 = un / n_tiles, q2 = un - st2 * n_tiles;
         const int f = q2 * L + base + i;
         if (f < min(n, q2 * L + L)) out[((size_t)st2 * n + f) * 2 + ch] = 0.f;
       }
@@ -254,9 +333,17 @@ __global__ void __launch_bounds__(MAXT) ra_voice_render_kernel(RaVoiceParams p, 
     for (int i = 0; i < TS; ++i) {
       const int f = fb + i;
       double vL = 0.0, vR = 0.0;
-      if (have && f >= sg.lo && f < f_hi) {
+      if (f == next_lo) { // (the one place a job is opened: at the tile's first frame if it is already sounding, else where it begins)
+        seg_open(sg, jobs[jb], f_lo, f_hi, q, L, st_prev, st_cur, lf, le);
+        have = true;
+        next_lo = kNever;
+      }
+      if (have) {
         // ---- one step of a sounding ramp: Enveloped::step, then the imag() chain of the element (audioelement.h:1382-1384 -> 1126-1129 -> 227-231) ----
-        const double inc = ramp_advance(sg.r, p, lf, le, sg.j == 1);
+        double k, tgt;
+        const double inc = ramp_advance(sg.r, p, lf, le, sg.j == 1, k, tgt);
+        sg.r.theta = wrap2(sg.r.theta + inc);
+        sg.r.y = fma(k, tgt - sg.r.y, sg.r.y);
         const int j = sg.j;
         const double env = (j <= sg.T) ? ((j < sg.A) ? (double)j * sg.inv_A : 1.0)                       // attack then sustain 1 (stepPressed :960-1000)
                                        : fma(-sg.top, (double)(j - sg.T) * sg.inv_R, sg.top);         // release: top + (-top) m / R (:732-737)
@@ -268,10 +355,7 @@ __global__ void __launch_bounds__(MAXT) ra_voice_render_kernel(RaVoiceParams p, 
         if (f + 1 == sg.hi) { // the segment ends: the slot's next job may begin inside this tile
           have = false;
           ++jb;
-          if (jb < je) {
-            const RaVoiceJob J = jobs[jb];
-            if (J.begin < f_hi) { seg_open(sg, J, f_lo, f_hi, q, L, st_prev, st_cur); have = true; }
-          }
+          if (jb < je) { const int b = jobs[jb].begin; if (b < f_hi) next_lo = b; }
         }
       }
       mine[i] = vL; mine[TS + i] = vR;
@@ -279,12 +363,12 @@ __global__ void __launch_bounds__(MAXT) ra_voice_render_kernel(RaVoiceParams p, 
     __syncthreads();
     for (int t = l; t < n_out; t += nt) { // buffer[2 i + ch] += elem.imag(ch): the unit's slots in slot order, then the float cast of SimpleAudioOutContext::step
       const int uu = t / (TS * 2), i = (t >> 1) % TS, ch = t & 1;
-      const long long un = unit0 + uu;
+      const int un = unit0 + uu;
       if (un >= n_units) continue;
       const double *col = tile + (size_t)(uu << g_log2) * (2 * TS + 1) + ch * TS + i;
       double acc = 0.0;
       for (int k = 0; k < g; ++k) acc += col[(size_t)k * (2 * TS + 1)];
-      const int st2 = (int)(un / n_tiles), q2 = (int)(un % n_tiles);
+      const int st2 = un / n_tiles, q2 = un - st2 * n_tiles;
       const int f = q2 * L + base + i;
       if (f < min(n, q2 * L + L)) out[((size_t)st2 * n + f) * 2 + ch] = (float)acc;
     }
@@ -294,10 +378,12 @@ __global__ void __launch_bounds__(MAXT) ra_voice_render_kernel(RaVoiceParams p, 
 
 } // namespace
 
-void ra_voice_launch_pre(const RaVoiceParams &p, const RaVoiceJob *jobs, const int32_t *order, int n_work, const RaVoiceState *st_prev, RaVoiceState *st_cur, int L,
-                         hipStream_t st) {
-  if (n_work <= 0) return;
-  hipLaunchKernelGGL(ra_voice_pre_kernel, dim3((unsigned)((n_work + 63) / 64)), dim3(64), 0, st, p, jobs, order, n_work, st_prev, st_cur, L);
+void ra_voice_launch_pre(const RaVoiceParams &p, const RaVoiceJob *jobs, const int32_t *order, int n_work, int n_slots, const RaVoiceState *st_prev, RaVoiceState *st_cur,
+                         RaVoiceSeg *seg, int L, hipStream_t st) {
+  if (n_work <= 0 || n_slots <= 0) return;
+  hipLaunchKernelGGL(ra_voice_pre_a_kernel, dim3((unsigned)((n_work + 63) / 64)), dim3(64), 0, st, jobs, order, n_work, st_prev, st_cur, seg, L);
+  hipLaunchKernelGGL(ra_voice_pre_b_kernel, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, st, p, jobs, n_slots, st_prev, st_cur, seg, L);
+  hipLaunchKernelGGL(ra_voice_pre_c_kernel, dim3((unsigned)((n_work + 63) / 64)), dim3(64), 0, st, jobs, order, n_work, st_prev, st_cur, seg, L);
 }
 
 size_t ra_voice_render_lds(int threads) { return (size_t)threads * (2 * TS + 1) * sizeof(double) + 58 * sizeof(float); }
@@ -310,6 +396,7 @@ int ra_voice_launch_render(const RaVoiceParams &p, const RaVoiceJob *jobs, const
   const int U = threads / g;
   const int n_tiles = (int)((n + L - 1) / L);
   const long long units = (long long)n_streams * n_tiles;
+  if (units > 0x7fffffffll - 1024) return -2;
   const size_t lds = ra_voice_render_lds(threads);
   if (threads == 64) {
     hipLaunchKernelGGL(ra_voice_render_kernel<64>, dim3((unsigned)((units + U - 1) / U)), dim3(64), lds, st, p, jobs, slot_begin, st_prev, st_cur, n_streams, (int)n, L, n_tiles, g_log2,
