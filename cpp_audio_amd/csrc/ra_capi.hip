@@ -44,7 +44,25 @@ struct ra_context {
   float *st_voice = nullptr, *st_carrier = nullptr, *st_out = nullptr;
   double *st_out_d = nullptr;
   int64_t st_cap = 0;
-  std::vector<float> pending_voice, pending_carrier; // ra_feed -> ra_compute
+  // ---- the ComputeFunc shim (ra_feed / ra_compute): per stream the input fed but not yet rolled into the window history, and the output
+  // rendered but not yet served.  A synth-only context renders AHEAD: between two analysis fires nothing can change the output (events
+  // apply where their frame fires, simple_audio_context.h:74-76), so when a compute reaches a fire sample the whole hop up to the next one is
+  // rendered by one launch sequence for all streams and the following computes are served from the ring.  The hop's input is still being
+  // fed while it is served: its window-history roll is deferred until the hop's input is complete.
+  struct Shim {
+    std::vector<std::vector<float>> in_voice, in_carrier; // [stream]: samples from frame in_base on
+    std::vector<char> carrier_given;                      // [stream]: ra_feed was given a carrier since in_base
+    std::vector<std::vector<double>> ring;                // [stream]: interleaved output frames; those from ring_head[stream] on are frames served[stream] .. rendered
+    std::vector<size_t> ring_head;                        // [stream]: doubles of ring[stream] already handed out
+    int32_t *h_flags = nullptr;                           // pinned: the device error flags, fetched with each block's output
+    std::vector<int64_t> served;                          // [stream]: frames handed out by ra_compute
+    int64_t in_base = 0, rendered = 0;
+    bool deferred = false;                                // the block [def_t0, def_t0 + def_n) has been rendered; its history roll is still owed
+    int64_t def_t0 = 0, def_n = 0;
+    double *h_out = nullptr; int64_t h_out_cap = 0;       // pinned
+    float *h_in = nullptr; int64_t h_in_cap = 0;          // pinned
+    bool active = false;
+  } shim;
   double *dbg_sqmag = nullptr;
   unsigned long long *dbg_clk = nullptr;
   // optional per-kernel timing with HIP events on the launch stream (ra_set_profiling)
@@ -540,8 +558,11 @@ int init_state(ra_context *c) {
   c->t = 0;
   c->frames_fired = 0;
   c->last_f_lo = c->last_nfb = c->last_n = c->last_t0 = 0;
-  c->pending_voice.clear();
-  c->pending_carrier.clear();
+  {
+    ra_context::Shim &sh = c->shim;
+    sh.in_voice.clear(); sh.in_carrier.clear(); sh.carrier_given.clear(); sh.ring.clear(); sh.ring_head.clear(); sh.served.clear();
+    sh.in_base = sh.rendered = 0; sh.deferred = false; sh.active = false;
+  }
   return RA_OK;
 }
 
@@ -734,7 +755,7 @@ int stage_carrier_events(ra_context *c, int64_t t0, int64_t n) {
 // wavefronts; cutting the block lets the throughput kernels (analysis of later chunks, render of earlier ones) fill the
 // rest of the chip meanwhile.  Results do not depend on the cut (each chunk continues the carried state exactly).
 int process_block_impl(ra_context *c, const float *d_voice, const float *d_carrier, int64_t n, float *d_out_final, double *d_out_d_caller, bool async, bool &started,
-                       bool apply_post) {
+                       bool apply_post, bool defer_history) {
   if (n <= 0) return RA_OK;
   HIP_TRY(hipSetDevice(c->device));
   RaParams &p = c->p;
@@ -948,7 +969,8 @@ int process_block_impl(ra_context *c, const float *d_voice, const float *d_carri
     c->pending_join = true;
     if (!async && (r = join_streams(c))) return r;
   }
-  if (n_chunks == 1) RA_TRY(timed_launch(c, ST_HISTORY, user, [&] { ra_launch_roll_history(p, b, d_voice, n, user); }));
+  // (the shim's render-ahead blocks roll the window history later, when the block's input is complete: shim_roll)
+  if (n_chunks == 1 && !defer_history) RA_TRY(timed_launch(c, ST_HISTORY, user, [&] { ra_launch_roll_history(p, b, d_voice, n, user); }));
   HIP_TRY(hipGetLastError());
   if (c->profiling) ++c->kernel_calls;
   c->last_f_lo = f_lo; c->last_nfb = nfb; c->last_n = n; c->last_t0 = t0;
@@ -959,10 +981,12 @@ int process_block_impl(ra_context *c, const float *d_voice, const float *d_carri
 
 // A block either completes, or fails before it touched any stream state (bad argument, allocation failure: the call can be retried), or
 // fails midway: then the context is poisoned until ra_reset (include/resynth_amd.h).
-int process_block(ra_context *c, const float *d_voice, const float *d_carrier, int64_t n, float *d_out, double *d_out_d, bool async = false, bool apply_post = true) {
+int process_block(ra_context *c, const float *d_voice, const float *d_carrier, int64_t n, float *d_out, double *d_out_d, bool async = false, bool apply_post = true,
+                  bool defer_history = false) {
   if (c->poisoned) return fail(RA_EINTERNAL, "an earlier block failed midway: the streams are in an undefined state until ra_reset");
+  if (c->shim.active && !defer_history && c->shim.deferred) return fail(RA_EINVAL, "ra_process_* in the middle of a hop served through ra_feed / ra_compute (feed and compute the hop to its end first)");
   bool started = false;
-  const int r = process_block_impl(c, d_voice, d_carrier, n, d_out, d_out_d, async, started, apply_post);
+  const int r = process_block_impl(c, d_voice, d_carrier, n, d_out, d_out_d, async, started, apply_post, defer_history);
   if (r && started) c->poisoned = true;
   return r;
 }
@@ -1089,6 +1113,9 @@ void ra_destroy(ra_context *c) {
     }
   }
   for (void *p : c->allocs) (void)hipFree(p);
+  if (c->shim.h_in) (void)hipHostFree(c->shim.h_in);
+  if (c->shim.h_out) (void)hipHostFree(c->shim.h_out);
+  if (c->shim.h_flags) (void)hipHostFree(c->shim.h_flags);
   for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->pipe_ready) {
@@ -1255,37 +1282,162 @@ int ra_get_carrier(ra_context *c, int32_t stream, double *h_carrier, int64_t cap
   return RA_OK;
 }
 
+namespace {
+void shim_init(ra_context *c) {
+  ra_context::Shim &sh = c->shim;
+  if (sh.active) return;
+  const int S = c->p.n_streams;
+  sh.in_voice.assign(S, {}); sh.in_carrier.assign(S, {}); sh.carrier_given.assign(S, 0); sh.ring.assign(S, {}); sh.ring_head.assign(S, 0); sh.served.assign(S, c->t);
+  sh.in_base = sh.rendered = c->t;
+  sh.deferred = false;
+  sh.active = true;
+}
+int shim_pinned(ra_context *c, int64_t floats_in, int64_t doubles_out) {
+  ra_context::Shim &sh = c->shim;
+  if (floats_in > sh.h_in_cap) {
+    if (sh.h_in) (void)hipHostFree(sh.h_in);
+    sh.h_in = nullptr; sh.h_in_cap = 0;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sh.h_in), sizeof(float) * (size_t)(floats_in + floats_in / 2), hipHostMallocDefault));
+    sh.h_in_cap = floats_in + floats_in / 2;
+  }
+  if (doubles_out > sh.h_out_cap) {
+    if (sh.h_out) (void)hipHostFree(sh.h_out);
+    sh.h_out = nullptr; sh.h_out_cap = 0;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sh.h_out), sizeof(double) * (size_t)(doubles_out + doubles_out / 2), hipHostMallocDefault));
+    sh.h_out_cap = doubles_out + doubles_out / 2;
+  }
+  return RA_OK;
+}
+// the history roll a render-ahead block owes, once every stream has fed the block's input
+int shim_roll(ra_context *c) {
+  ra_context::Shim &sh = c->shim;
+  if (!sh.deferred) return RA_OK;
+  const int S = c->p.n_streams;
+  const int64_t n = sh.def_n;
+  for (int s = 0; s < S; ++s)
+    if ((int64_t)sh.in_voice[s].size() < n) return fail(RA_EINVAL, "ra_compute: stream " + std::to_string(s) + " has not been fed up to the frames the others are computing");
+  RA_TRY(ensure_staging(c, n));
+  RA_TRY(shim_pinned(c, 3 * (int64_t)S * n, 0));
+  // (the roll's image has its own third of the pinned buffer and of the device staging — st_out is idle on this path — so nothing waits for it)
+  float *hr = sh.h_in + 2 * (size_t)S * n;
+  for (int s = 0; s < S; ++s) std::memcpy(hr + (size_t)s * n, sh.in_voice[s].data(), sizeof(float) * (size_t)n);
+  HIP_TRY(hipMemcpyAsync(c->st_out, hr, sizeof(float) * (size_t)S * n, hipMemcpyHostToDevice, c->stream));
+  ra_launch_roll_history(c->p, c->b, c->st_out, n, c->stream);
+  HIP_TRY(hipGetLastError());
+  for (int s = 0; s < S; ++s) {
+    sh.in_voice[s].erase(sh.in_voice[s].begin(), sh.in_voice[s].begin() + n);
+    sh.in_carrier[s].erase(sh.in_carrier[s].begin(), sh.in_carrier[s].begin() + std::min<size_t>(n, sh.in_carrier[s].size()));
+    sh.carrier_given[s] = 0;
+  }
+  sh.in_base += n;
+  sh.deferred = false;
+  return RA_OK;
+}
+// renders the next block for every stream: at least up to frame `upto` (exclusive) of the caller's compute
+int shim_render(ra_context *c, int64_t upto) {
+  ra_context::Shim &sh = c->shim;
+  const RaParams &p = c->p;
+  const int S = p.n_streams;
+  RA_TRY(shim_roll(c));
+  const int64_t R = sh.rendered;
+  const bool ahead = !p.voc_enabled && p.fb_gain == 0.f; // nothing but the analysis' events reaches the output
+  int64_t X, need_in;
+  if (ahead) {
+    const int64_t k0 = ra_fire_sample(p.N, p.H, 0);
+    if (R < k0) { X = k0; need_in = 0; }                        // before the first frame fires: silence up to it
+    else {                                                       // R is a fire sample: up to the next one; the frame needs input sample R itself
+      const int64_t f = (R - k0) / p.H;
+      X = ra_fire_sample(p.N, p.H, f + 1);
+      need_in = (ra_fire_sample(p.N, p.H, f) == R) ? 1 : 0;
+      if (ra_fire_sample(p.N, p.H, f) != R) { X = upto; need_in = X - R; } // (not aligned: a context that was driven by ra_process_* before)
+    }
+    X = std::min<int64_t>(X, R + ((int64_t)1 << 20));
+  } else { X = upto; need_in = X - R; }                          // a vocoder or a feedback loop needs every input sample: block by block as requested
+  const int64_t n = X - R;
+  for (int s = 0; s < S; ++s)
+    if ((int64_t)sh.in_voice[s].size() < need_in) return fail(RA_EINVAL, "ra_compute: stream " + std::to_string(s) + " has not been fed up to the frames the others are computing");
+  RA_TRY(ensure_staging(c, n));
+  RA_TRY(shim_pinned(c, 3 * (int64_t)S * n, 2 * (int64_t)S * n));
+  bool any_carrier = false, all_carrier = true;
+  for (int s = 0; s < S; ++s) { any_carrier |= sh.carrier_given[s] != 0; all_carrier &= sh.carrier_given[s] != 0; }
+  const bool synth_carrier = p.car_P > 0 && !any_carrier; // no carrier was fed: the carrier synth supplies it (ra_carrier_events)
+  if (p.car_P > 0 && any_carrier && !all_carrier) return fail(RA_EINVAL, "ra_feed: a block's carrier must be given for every stream or for none (none = the carrier synth plays)");
+  float *hv = sh.h_in, *hc = sh.h_in + (size_t)S * n;
+  for (int s = 0; s < S; ++s) {
+    const int64_t have = std::min<int64_t>(n, (int64_t)sh.in_voice[s].size());
+    std::memcpy(hv + (size_t)s * n, sh.in_voice[s].data(), sizeof(float) * (size_t)have);
+    std::memset(hv + (size_t)s * n + have, 0, sizeof(float) * (size_t)(n - have));
+    const int64_t hcn = std::min<int64_t>(n, (int64_t)sh.in_carrier[s].size());
+    std::memcpy(hc + (size_t)s * n, sh.in_carrier[s].data(), sizeof(float) * (size_t)hcn);
+    std::memset(hc + (size_t)s * n + hcn, 0, sizeof(float) * (size_t)(n - hcn));
+  }
+  HIP_TRY(hipMemcpyAsync(c->st_voice, hv, sizeof(float) * (size_t)S * n, hipMemcpyHostToDevice, c->stream));
+  if (!synth_carrier) HIP_TRY(hipMemcpyAsync(c->st_carrier, hc, sizeof(float) * (size_t)S * n, hipMemcpyHostToDevice, c->stream));
+  const bool defer = ahead && need_in < n;
+  // a compute's contribution: not post-processed (the post-processors run in SimpleAudioOutContext::step, after every compute)
+  RA_TRY(process_block(c, c->st_voice, synth_carrier ? nullptr : c->st_carrier, n, nullptr, c->st_out_d, false, false, defer));
+  HIP_TRY(hipMemcpyAsync(sh.h_out, c->st_out_d, sizeof(double) * 2 * (size_t)S * n, hipMemcpyDeviceToHost, c->stream));
+  if (!sh.h_flags) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sh.h_flags), 64, hipHostMallocDefault));
+  HIP_TRY(hipMemcpyAsync(sh.h_flags, c->b.error_flags, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  { int jr = join_streams(c); if (jr) return jr; }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (*sh.h_flags & RA_ERR_OVERFLOW) return fail(RA_EOVERFLOW, "a per-frame pitch list exceeded max_pitches_per_frame");
+  if (*sh.h_flags & RA_ERR_BOOKKEEPING) return fail(RA_EINTERNAL, "channel bookkeeping mismatch between tracking and synthesis");
+  for (int s = 0; s < S; ++s) {
+    std::vector<double> &ring = sh.ring[s];
+    ring.erase(ring.begin(), ring.begin() + (ptrdiff_t)sh.ring_head[s]); // (what is left is at most one tile: the streams are served in step)
+    sh.ring_head[s] = 0;
+    ring.insert(ring.end(), sh.h_out + 2 * (size_t)s * n, sh.h_out + 2 * (size_t)(s + 1) * n);
+  }
+  sh.rendered = X;
+  if (defer) { sh.deferred = true; sh.def_t0 = R; sh.def_n = n; }
+  else {
+    for (int s = 0; s < S; ++s) {
+      sh.in_voice[s].erase(sh.in_voice[s].begin(), sh.in_voice[s].begin() + std::min<size_t>(n, sh.in_voice[s].size()));
+      sh.in_carrier[s].erase(sh.in_carrier[s].begin(), sh.in_carrier[s].begin() + std::min<size_t>(n, sh.in_carrier[s].size()));
+      sh.carrier_given[s] = 0;
+    }
+    sh.in_base = X;
+  }
+  return RA_OK;
+}
+} // namespace
+
 int ra_feed(ra_context *c, int32_t stream, const float *h_voice, const float *h_carrier, int32_t n) {
   if (!c) return fail(RA_EINVAL, "null context");
-  if (c->p.n_streams != 1 || stream != 0) return fail(RA_EINVAL, "ra_feed/ra_compute drive a single-stream context (one RtResynth = one context)");
+  if (stream < 0 || stream >= c->p.n_streams) return fail(RA_EINVAL, "ra_feed: stream out of range");
   if (n < 0) return fail(RA_EINVAL, "n_frames < 0");
-  for (int i = 0; i < n; ++i) {
-    c->pending_voice.push_back(h_voice ? h_voice[i] : 0.f);
-    c->pending_carrier.push_back(h_carrier ? h_carrier[i] : 0.f);
+  if (c->poisoned) return fail(RA_EINTERNAL, "an earlier block failed midway: the streams are in an undefined state until ra_reset");
+  shim_init(c);
+  ra_context::Shim &sh = c->shim;
+  if (h_carrier && n > 0) {
+    // (a carrier given from some frame of a block on: the frames before count as silence, as with the reference's queue)
+    sh.in_carrier[stream].resize(sh.in_voice[stream].size(), 0.f);
+    sh.carrier_given[stream] = 1;
   }
+  for (int i = 0; i < n; ++i) sh.in_voice[stream].push_back(h_voice ? h_voice[i] : 0.f);
+  if (h_carrier) for (int i = 0; i < n; ++i) sh.in_carrier[stream].push_back(h_carrier[i]);
   return RA_OK;
 }
 
 int ra_compute(ra_context *c, int32_t stream, double *h_buffer, int32_t n) {
   if (!c) return fail(RA_EINVAL, "null context");
-  if (c->p.n_streams != 1 || stream != 0) return fail(RA_EINVAL, "ra_feed/ra_compute drive a single-stream context (one RtResynth = one context)");
+  if (stream < 0 || stream >= c->p.n_streams) return fail(RA_EINVAL, "ra_compute: stream out of range");
   if (n < 1 || n > RA_N_FRAMES_PER_BUFFER) return fail(RA_EINVAL, "nFrames must be in 1..16 (max_n_frames_per_loop)");
   if (!h_buffer) return fail(RA_EINVAL, "null buffer");
-  if (static_cast<int>(c->pending_voice.size()) < n) return fail(RA_EINVAL, "ra_compute: fewer frames fed than requested");
+  if (c->p.post_limit && c->p.fb_gain != 0.f)
+    return fail(RA_EINVAL, "ra_compute with post = limit and an output feedback: the loop feeds back what was PLAYED, i.e. the limited signal, which only the caller of the "
+                           "computes has (SimpleAudioOutContext::step runs the post-processors after them, lib.cpp:1245-1275) — use ra_process_*");
   HIP_TRY(hipSetDevice(c->device));
-  int r = ensure_staging(c, n);
-  if (r) return r;
-  HIP_TRY(hipMemcpyAsync(c->st_voice, c->pending_voice.data(), n * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->st_carrier, c->pending_carrier.data(), n * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  r = process_block(c, c->st_voice, c->st_carrier, n, nullptr, c->st_out_d, false, false); // a compute's contribution: not post-processed
-  if (r) return r;
-  double tmp[RA_N_FRAMES_PER_BUFFER * 2];
-  HIP_TRY(hipMemcpyAsync(tmp, c->st_out_d, n * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  r = ra_synchronize(c);
-  if (r) return r;
-  for (int i = 0; i < 2 * n; ++i) h_buffer[i] += tmp[i]; // the reference computes accumulate (gen.crtp.h:364-369)
-  c->pending_voice.erase(c->pending_voice.begin(), c->pending_voice.begin() + n);
-  c->pending_carrier.erase(c->pending_carrier.begin(), c->pending_carrier.begin() + n);
+  shim_init(c);
+  ra_context::Shim &sh = c->shim;
+  const int64_t t = sh.served[stream];
+  if (sh.in_base + (int64_t)sh.in_voice[stream].size() < t + n) return fail(RA_EINVAL, "ra_compute: fewer frames fed than requested");
+  while (sh.rendered < t + n) RA_TRY(shim_render(c, t + n));
+  const double *ring = sh.ring[stream].data() + sh.ring_head[stream];
+  for (int i = 0; i < 2 * n; ++i) h_buffer[i] += ring[i]; // the reference computes accumulate (gen.crtp.h:364-369)
+  sh.ring_head[stream] += 2 * (size_t)n;
+  sh.served[stream] = t + n;
   return 1;
 }
 

@@ -65,15 +65,19 @@ private:
 
 // ---- the two callables of the reference's audio thread --------------------------------------------------------------------
 // Holds a raw pointer only (the reference rejects functors that own heap memory, simple_audio_context.h:95-97).
+// `stream`: which of the context's streams this callable belongs to — one context serves the RecordF / ComputeFunc pairs of many
+// RtResynth instances; per tile every stream is fed before the first compute runs (the order of the reference's audio callback).
 struct InputShim {
   ra_context *ctx;
   const float *carrier = nullptr; // optional carrier block delivered together with the voice (job.read_carrier, lib.cpp:1412)
-  void operator()(const float *buf, int nFrames) const { check(ra_feed(ctx, 0, buf, carrier, nFrames)); }
+  int stream = 0;
+  void operator()(const float *buf, int nFrames) const { check(ra_feed(ctx, stream, buf, carrier, nFrames)); }
 };
 struct ComputeShim {
   ra_context *ctx;
+  int stream = 0;
   // accumulates nFrames (1..16) interleaved stereo doubles, like ImplCRTP::compute + the vocoder compute together
-  bool operator()(double *buffer, int nFrames) const { return check(ra_compute(ctx, 0, buffer, nFrames)) != 0; }
+  bool operator()(double *buffer, int nFrames) const { return check(ra_compute(ctx, stream, buffer, nFrames)) != 0; }
 };
 
 // ---- RtResynth in offline-job mode ------------------------------------------------------------------------------------------

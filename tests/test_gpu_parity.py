@@ -266,28 +266,96 @@ def test_streams_are_independent(api, sig):
         assert np.array_equal(np.concatenate(outs, axis=0), full)
 
 
+def drive_shim(ctx, x, rng, carrier=None, slices=None):
+    """The reference's audio callback: per tile of 1 .. 16 frames every stream is fed, then every stream's ComputeFunc runs (simple_audio_context.h:80-102)."""
+    S, n = x.shape
+    got = np.zeros((S, n, 2), np.float64)
+    pos = 0
+    while pos < n:
+        m = int(min(n - pos, rng.integers(1, 17))) if slices is None else int(min(n - pos, slices))
+        for s in range(S):
+            ctx.feed(x[s, pos:pos + m], None if carrier is None else carrier[s, pos:pos + m], stream=s)
+        for s in range(S):
+            buf = np.full((m, 2), 0.25, np.float64)   # pre-existing content must be preserved (+=)
+            assert ctx.compute(buf, m, stream=s) == 1
+            got[s, pos:pos + m] = buf - 0.25
+        pos += m
+    return got
+
+
 def test_compute_func_boundary_accumulates(api, oracle, sig):
-    # ra_feed + ra_compute = the reference's ComputeFunc contract: += into a caller-owned interleaved double buffer, 1..16 frames
+    # ra_feed + ra_compute = the reference's ComputeFunc contract: += into a caller-owned interleaved double buffer, 1..16 frames.
+    # A synth-only context renders ahead to the next analysis fire and serves the slices from a ring (one launch sequence per hop)
     x = sig.make_streams(1, 12000)
     cfg = api.default_config(**PARITY_KW)
     ref, _, _ = oracle.run_offline(oracle.default_config(**PARITY_KW), x[0])
     with api.Context(cfg, 1, 0) as ctx:
-        got = np.zeros((12000, 2), np.float64)
-        pos = 0
-        rng = np.random.default_rng(0)
-        while pos < 12000:
-            m = int(min(12000 - pos, rng.integers(1, 17)))
-            ctx.feed(x[0, pos:pos + m])
-            buf = np.full((m, 2), 0.25, np.float64)   # pre-existing content must be preserved (+=)
-            assert ctx.compute(buf, m) == 1
-            got[pos:pos + m] = buf - 0.25
-            pos += m
-        assert rms(got.astype(np.float32), ref) <= RMS_TOL
+        got = drive_shim(ctx, x, np.random.default_rng(0))
+        assert rms(got[0].astype(np.float32), ref) <= RMS_TOL
         with pytest.raises(api.RaError):
             ctx.compute(np.zeros((17, 2)), 17)        # max_n_frames_per_loop = 16
-    with api.Context(cfg, 2, 0) as ctx2:
         with pytest.raises(api.RaError):
-            ctx2.feed(x[0, :4])
+            ctx.compute(np.zeros((4, 2)), 4)          # nothing fed
+        with pytest.raises(api.RaError):
+            ctx.feed(x[0, :4], stream=1)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(window_size=800, stride=400, n_channels=16), dict(window_size=1024, stride=7, n_channels=8), dict(stereo_spread=1.0)])
+def test_compute_func_serves_four_streams_from_one_context(api, oracle, sig, kw):
+    # an S-stream context behind S ComputeFuncs: random 1 .. 16 frame tiles, every stream within 1e-5 RMS of its own oracle run (VERDICT r02 item 7)
+    S, n = 4, 9000
+    x = sig.make_streams(S, n)
+    pk = dict(PARITY_KW, **kw)
+    cfg = api.default_config(**pk)
+    with api.Context(cfg, S, 0) as ctx:
+        got = drive_shim(ctx, x, np.random.default_rng(1))
+        st = ctx.stats()
+    assert st.error_flags == 0
+    for s in range(S):
+        ref, _, _ = oracle.run_offline(oracle.default_config(**dict(pk, seed=pk["seed"] + s)), x[s])
+        assert np.sqrt(np.mean(ref.astype(np.float64) ** 2)) > 1e-3
+        assert rms(got[s].astype(np.float32), ref) <= RMS_TOL, s
+    # and the same frames as the block entry point gives (the ring changes when a launch happens, not what it computes)
+    with api.Context(cfg, S, 0) as ctx:
+        blk = ctx.process_host(x)
+    assert np.max(np.abs(got.astype(np.float32) - blk)) <= 1e-6
+
+
+def test_compute_func_with_a_vocoder_or_a_feedback_falls_back_to_a_block_per_tile(api, oracle, sig):
+    n = 6000
+    x = sig.make_streams(2, n, kind="speech")
+    car = np.stack([sig.carrier_stream(n, freq=110.0 * (1 + 0.1 * s)) for s in range(2)]).astype(np.float32)
+    vk = dict(PARITY_KW, analysis_volume=0.3, voice_volume=0.1, carrier_volume=0.05, vocoder_volume=1.0, vocoder_count_bands=8, vocoder_min_freq=150.0, vocoder_max_freq=8000.0,
+              vocoder_modulator_window_size_seconds=0.02, vocoder_stride_seconds=0.004)
+    with api.Context(api.default_config(**vk), 2, 0) as ctx:
+        got = drive_shim(ctx, x, np.random.default_rng(2), carrier=car)
+    for s in range(2):
+        ref, _, _ = oracle.run_offline(oracle.default_config(**dict(vk, seed=vk["seed"] + s)), x[s], car[s])
+        assert rms(got[s].astype(np.float32), ref) <= RMS_TOL, s
+    fk = dict(PARITY_KW, analysis_output_feedback_gain=0.05, output_delay_seconds=0.02, window_size=1024, stride=256, reference_order=1)
+    with api.Context(api.default_config(**fk), 1, 0) as ctx:
+        got = drive_shim(ctx, x[:1], np.random.default_rng(3))
+    ref, _, _ = oracle.run_offline(oracle.default_config(**{k: v for k, v in fk.items() if k != "reference_order"}), x[0])
+    assert rms(got[0].astype(np.float32), ref) <= RMS_TOL
+    # post = limit with a feedback loop: the loop feeds back what was played — the limited signal, which a compute never sees: refused (ADVICE r02)
+    with api.Context(api.default_config(**dict(fk, post=1)), 1, 0) as ctx:
+        ctx.feed(x[0, :16])
+        with pytest.raises(api.RaError) as e:
+            ctx.compute(np.zeros((16, 2)), 16)
+        assert "limit" in str(e.value)
+
+
+def test_compute_func_reaches_the_carrier_synth(api, oracle):
+    # no carrier is fed: the context's carrier synth plays the queued notes for the vocoder (ADVICE r02: it used to be fed zeros)
+    n = 5000
+    kw = dict(PARITY_KW, analysis_volume=0.0, voice_volume=0.0, carrier_volume=1.0, vocoder_volume=0.0, carrier_n_channels=4, phase_policy=1)
+    rows = [(10, 0, 0, 69, 0, 0.0, 0.5), (3000, 0, 1, 69)]
+    with api.Context(api.default_config(**kw), 1, 0) as ctx:
+        ctx.carrier_events(rows)
+        got = drive_shim(ctx, np.zeros((1, n), np.float32), np.random.default_rng(4))
+    ref, _, _, dr = oracle.run_offline_ex(oracle.default_config(**kw), None, None, oracle.carrier_events([(10, 0, 69, 0, 0.0, 0.5), (3000, 1, 69)]), n_frames=n)
+    assert dr == (0, 0) and np.sqrt(np.mean(ref.astype(np.float64) ** 2)) > 1e-2
+    assert rms(got[0].astype(np.float32), ref) <= RMS_TOL
 
 
 VOC_KW = dict(analysis_volume=0.0, voice_volume=0.0, carrier_volume=0.0, vocoder_volume=1.0, vocoder_count_bands=32,
