@@ -210,24 +210,24 @@ class Runner:
         self.torch.cuda.empty_cache()
 
 
-def time_compute_shim(api, calls=400):
-    """The reference's real-time seam, `ComputeFunc = bool(double*, int nFrames)` with nFrames <= 16 (simple_audio_context.h:24-26), through
-    ra_feed + ra_compute on a single-stream context: two copies, one block's launches and a synchronisation per call.  A correctness shim
-    (INTEGRATION.md section 2), timed here so that its cost is on record: 16 frames are 333 us of audio at 48 kHz."""
-    import numpy as np
-    cfg = api.default_config(analysis_volume=1.0, stereo_spread=0.0, carrier_volume=0.0, seed=1)
-    rng = np.random.default_rng(0)
-    x = (0.1 * rng.standard_normal(16 * (calls + 50))).astype(np.float32)
-    buf = np.zeros((16, 2), np.float64)
-    with api.Context(cfg, 1, 0) as ctx:
-        for k in range(50):   # warm-up (allocations, first frames)
-            ctx.feed(x[16 * k:16 * k + 16]); ctx.compute(buf, 16)
-        t0 = time.perf_counter()
-        for k in range(50, 50 + calls):
-            ctx.feed(x[16 * k:16 * k + 16]); ctx.compute(buf, 16)
-        dt = (time.perf_counter() - t0) / calls
-    return {"config": "ComputeFunc shim: one stream, ra_feed(16) + ra_compute(16) per call (window 4096, stride 1024, 64 partials)",
-            "us_per_call": dt * 1e6, "frames_per_call": 16, "x_realtime": 16 / SR / dt}
+def run_shim_bench():
+    """The reference's real drop-in seam (RecordF + ComputeFunc, simple_audio_context.h:24-26) through the C ABI, driven from compiled C++ the way
+    SimpleAudioOutContext::step drives its computes (tests/host/shim_bench.cpp): 1, 64 and 256 streams on one context, 16-frame tiles.  Runs as a
+    child process BEFORE this process touches the GPU (a process that has initialised HIP must not fork + exec)."""
+    import subprocess
+    import tempfile
+    lib_dir = os.path.join(ROOT, "cpp_audio_amd")
+    exe = os.path.join(tempfile.mkdtemp(prefix="ra_shim_"), "shim_bench")
+    try:
+        subprocess.run(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "host", "shim_bench.cpp"), "-o", exe, "-L", lib_dir, "-lresynth_amd", f"-Wl,-rpath,{lib_dir}",
+                        "-Wl,-rpath,/opt/rocm/lib"], check=True, capture_output=True, timeout=300)
+        r = subprocess.run([exe, "1", "10", "64", "5", "256", "3"], check=True, capture_output=True, timeout=300, text=True)
+        runs = [json.loads(line) for line in r.stdout.splitlines() if line.startswith("{")]
+        return {"config": "ComputeFunc shim from C++ (tests/host/shim_bench.cpp): per 16-frame tile every stream is fed, then every stream's compute runs; window 4096, "
+                          "stride 1024, 64 partials; a synth-only context renders one hop ahead per launch sequence and serves the tiles from a ring",
+                "runs": runs, "x_realtime_1_stream": runs[0]["x_realtime"], "x_realtime_64_streams": runs[1]["x_realtime"], "x_realtime_256_streams": runs[2]["x_realtime"]}
+    except Exception as e:  # (no compiler on the box, ...)
+        return {"config": "ComputeFunc shim from C++ (tests/host/shim_bench.cpp)", "error": repr(e)}
 
 
 def voice_workload(api, which, S, seconds, blocks):
@@ -340,6 +340,15 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    # child processes (the C++ shim harness, the oracle's build) run here, before anything in this process initialises the GPU
+    shim_result = None
+    if rank == 0 and world == 1:
+        if not args.no_other_configs:
+            shim_result = run_shim_bench()
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib
+            oracle_lib.lib()
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -518,7 +527,8 @@ def main():
                                            autotune_root_note=0), 2000, 10.0, 2))
             for which in ("sweep", "birds", "robots"):
                 others.append(time_voice(api, torch, dev, which, 256, 10.0, 3))
-            others.append(time_compute_shim(api))
+            if shim_result is not None:
+                others.append(shim_result)
         except Exception as e:  # a failure here must not cost the headline line
             others.append({"error": repr(e)})
         result["other_configs"] = others
