@@ -322,8 +322,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=256, help="streams per GPU (configs[1]: 256)")
-    ap.add_argument("--streams-total", type=int, default=0, help="total streams, sharded over the ranks (configs[4]: 8000 over 8 GPUs); overrides --streams")
+    ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: configs[1]'s 256; with --gpus 8 and no stream option: configs[4], see below)")
+    ap.add_argument("--streams-total", type=int, default=0, help="total streams, sharded over the ranks; overrides --streams.  `--gpus 8` without a stream option "
+                    "runs BASELINE configs[4]: 8000 streams over the 8 GPUs = 1000 per rank")
     ap.add_argument("--seconds", type=float, default=10.0, help="audio seconds per stream per step")
     ap.add_argument("--window", type=int, default=4096)
     ap.add_argument("--stride", type=int, default=1024)
@@ -364,11 +365,15 @@ def main():
 
     from cpp_audio_amd import api, sharding
 
+    configs4 = args.gpus == 8 and not args.streams and not args.streams_total   # BASELINE configs[4]: "8000 independent streams sharded per GPU"
+    if configs4:
+        args.streams_total = 8000
     if args.streams_total:
         lo, hi = sharding.shard_streams(args.streams_total, world, rank)
         S, first_stream = hi - lo, lo
     else:
-        S, first_stream = args.streams, rank * args.streams
+        per = args.streams or 256
+        S, first_stream = per, rank * per
     n = int(round(args.seconds * SR))
     N, H, P = args.window, args.stride, args.partials
     head_kw = dict(window_size=N, stride=H, n_channels=P, analysis_volume=1.0, stereo_spread=0.0, carrier_volume=0.0, seed=1234 + first_stream)
@@ -461,9 +466,11 @@ def main():
         result = {
             "metric": "audio frames/sec (48 kHz, 4096-pt FFT, 64 partials) per GPU; CPU ref x",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if not args.streams_total else "strong", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True,
+            # configs[4] fixes 1000 streams per GPU: the per-GPU work is what the config names, whatever N would be
+            "scaling": "weak" if (not args.streams_total or configs4) else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic", "issue": "stream-ordered" if args.stream_ordered else "overlapped blocks (ra_process_device_async)",
-            "config": {"workload": f"configs[1]: {S} mono streams/GPU x {args.seconds:g} s @ 48 kHz, window {N} (Gaussian 4 sigma) / FFT {N}, "
+            "config": {"workload": f"{'configs[4]: 8000 streams over 8 GPUs, ' if configs4 else 'configs[1]: '}{S} mono streams/GPU x {args.seconds:g} s @ 48 kHz, window {N} (Gaussian 4 sigma) / FFT {N}, "
                                    f"stride {H} (75% overlap), {P} partials, analysis_volume 1, stereo_spread 0, post none",
                        "streams_per_gpu": S, "streams_total": total_streams, "frames_per_stream_per_step": n, "sharding": f"streams x{world}, no collective"},
             "x_realtime_per_stream": value / (SR * total_streams),
@@ -515,6 +522,10 @@ def main():
                    vocoder_max_freq=20000.0, vocoder_modulator_window_size_seconds=0.10, vocoder_stride_seconds=0.005)
         others = []
         try:
+            ns = time_config(api, torch, dev, "north_star operating point: 1000 concurrent 48 kHz mono streams, 4096-pt window, 75 % overlap, 64 partials, on one MI355X "
+                             "(= one rank of configs[4])", dict(parity, window_size=N, stride=H, n_channels=P), 1000, 10.0, 3)
+            ns["target"] = ">= 10 x real time for each of the 1000 streams (BASELINE.json north_star)"
+            others.append(ns)
             others.append(time_config(api, torch, dev, "configs[1] with stereo_spread = 1 (the reference default): 256 streams, N 4096, H 1024, P 64",
                                       dict(parity, window_size=N, stride=H, n_channels=P, stereo_spread=1.0), 256, 10.0, 3))
             others.append(time_config(api, torch, dev, "configs[2] FFT vocoder: 256 streams, 32 bands, S = 241, modulator FFT 8192, carrier FFT 512, carrier from a file",

@@ -456,7 +456,10 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
       ++pos;
       clk.lap<1>();
     }
-    if (Ppad > 64) __syncthreads(); // one wave: its LDS operations execute in order, no barrier needed
+    // one wave: its LDS operations execute in order in hardware; the fence and the wave barrier cost no instruction and keep the compiler
+    // from moving a lane's `mine[pos] = v` below the other lanes' column reads
+    if (Ppad > 64) __syncthreads();
+    else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
     if (l < 64 && !(RA_ABL & 2)) { // NOUT outputs x NPART channel groups
       double acc = 0.0, accR = 0.0; // mono: the sum; stereo: left and right
       if (fr < m) {
@@ -719,7 +722,8 @@ __device__ inline void render_pair(const RaParams &p, const RaBuffers &b, const 
     if (pack) {
       if (l >= 64) return; // the other waves of the workgroup have nothing to do (no barrier follows on this path)
       const int h = l >> 5;
-      if ((l & 31) < cnt[h]) src = reinterpret_cast<int *>(tile)[l]; // (one wave: its LDS operations execute in order)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if ((l & 31) < cnt[h]) src = reinterpret_cast<int *>(tile)[l]; // (one wave: its LDS operations execute in order; the fence pins the compiler's order)
     }
   }
   if (pack && second) return; // rendered by the workgroup of the pair's first hop

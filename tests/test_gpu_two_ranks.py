@@ -45,7 +45,7 @@ def test_two_ranks_drive_the_product_on_their_shards(run_program, tmp_path):
     assert np.array_equal(got, ref), "a stream's result does not depend on which rank ran it (per-stream seeds = seed + global index)"
 
 
-@pytest.mark.parametrize("extra", [["--streams", "8"], ["--streams-total", "11"]])
+@pytest.mark.parametrize("extra", [["--streams", "8"], ["--streams-total", "11"], ["--streams-total", "2000"]])   # 2000 = configs[4]'s 1000 streams per rank
 def test_bench_runs_with_two_ranks(run_program, extra):
     rc, so, se = run_program(_torchrun(2, os.path.join(ROOT, "bench.py"), "--gpus", 2, "--steps", 2, "--warmup", 1, "--seconds", 1, *extra),
                              timeout=900, env=ENV, cwd=ROOT)
@@ -54,7 +54,7 @@ def test_bench_runs_with_two_ranks(run_program, extra):
     assert len(line) == 1, so[-2000:]
     d = json.loads(line[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["checks"]["error_flags"] == 0
-    total = 16 if extra[0] == "--streams" else 11
+    total = 16 if extra[0] == "--streams" else int(extra[1])
     assert d["config"]["streams_total"] == total
     assert abs(d["value"] - total * 48000 * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3)) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d and "other_configs" not in d   # N = 1 only

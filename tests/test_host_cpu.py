@@ -18,7 +18,8 @@ def wav_dump(tmp_path_factory):
     return str(exe)
 
 
-@pytest.mark.parametrize("name,scale", [("saw_pcm_24_signed_mono.wav", 2.0 ** 31), ("saw_pcm_16_signed_stereo.wav", 2.0 ** 15)])
+@pytest.mark.parametrize("name,scale", [("saw_pcm_24_signed_mono.wav", 2.0 ** 31), ("saw_pcm_16_signed_stereo.wav", 2.0 ** 15), ("saw_pcm_24_signed_stereo.wav", 2.0 ** 31),
+                                        ("saw_pcm_32_signed_mono.wav", 2.0 ** 31), ("saw_pcm_32_signed_stereo.wav", 2.0 ** 31), ("saw_pcm_32_float_stereo.wav", 1.0)])
 def test_wav_reader_matches_reference_fixtures(wav_dump, tmp_path, name, scale):
     src = os.path.join(GOLD, name)
     raw, rt = tmp_path / "raw.bin", tmp_path / "rt.wav"
@@ -32,7 +33,7 @@ def test_wav_reader_matches_reference_fixtures(wav_dump, tmp_path, name, scale):
     # the fixture is a 1 Hz saw ramp (the 16-bit file is dithered): at most one wrap, otherwise rising by 2/44100 per frame
     d = np.diff(got[0])
     assert np.sum(d < -0.5) <= 1
-    if bits == 24:
+    if bits >= 24:
         assert np.all(d[d > -0.5] > 0)
     assert abs(np.median(d) - 2.0 / 44100) < 2.0 / 32768 and np.max(np.abs(d[d > -0.5] - 2.0 / 44100)) < 8.0 / 32768
     # float64 writer round trip (the format resynth.hpp writes, :29-35)
