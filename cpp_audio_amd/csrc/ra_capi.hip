@@ -75,8 +75,8 @@ struct ra_context {
   int64_t kernel_launches[6] = {0, 0, 0, 0, 0, 0};
   // chunk pipeline: analysis / tracking / propagation / render streams and the events chaining them
   bool pipe_ready = false;
-  hipStream_t pipe_stream[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // analysis, tracking, propagation, render, vocoder
-  hipEvent_t ev_fork = nullptr, ev_voc = nullptr, ev_join[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipStream_t pipe_stream[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // analysis, tracking, propagation, render, vocoder, carrier synth
+  hipEvent_t ev_fork = nullptr, ev_voc = nullptr, ev_car = nullptr, ev_join[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_chunk[3][12] = {};
   // Per-block scratch (pitch lists, commands, hop states) exists twice: block k + 1 may run its analysis / tracking / propagation while
   // block k is still rendering (ra_process_device_async).  A set is reused two blocks later; the events say when its last readers are done.
@@ -86,7 +86,8 @@ struct ra_context {
     RaCmd *cmd = nullptr; int32_t *cmd_non = nullptr;
     double *seg_sd = nullptr; int32_t *seg_si = nullptr;
     double *voc_mix = nullptr; int64_t mix_cap = 0; // [n_streams][n] the vocoder's mix of the block (added by the render)
-    hipEvent_t ev_track_done = nullptr, ev_prop_done = nullptr, ev_render_done = nullptr;
+    double *car_gen_d = nullptr; float *car_gen_f = nullptr; int64_t car_gen_cap = 0; // [n_streams][n] the carrier synth's output for the block (read by the vocoder)
+    hipEvent_t ev_track_done = nullptr, ev_prop_done = nullptr, ev_render_done = nullptr, ev_voc_done = nullptr;
     bool used = false;
   } scr[2];
   int parity = 0;
@@ -623,12 +624,17 @@ int ensure_scratch(ra_context *c, int64_t nfb, int64_t n, int n_chunks) {
       }
     }
     b.voc_mix = c->scr[c->parity].voc_mix; b.mix_cap = c->scr[c->parity].mix_cap;
-    if (p.car_P > 0 && n > b.car_gen_cap) {
-      HIP_TRY(hipDeviceSynchronize()); // an earlier block may still use the old buffer on the render stream
-      dev_free(c, b.car_gen_d); dev_free(c, b.car_gen_f);
-      b.car_gen_cap = n;
-      if ((r = dev_alloc(c, &b.car_gen_d, S * n, false))) return r;
-      if ((r = dev_alloc(c, &b.car_gen_f, S * n, false))) return r;
+    if (p.car_P > 0) { // the generated carrier exists per scratch set: block k + 1's synth writes one while block k's vocoder reads the other
+      for (ra_context::Scratch &sc2 : c->scr) {
+        if (n > sc2.car_gen_cap) {
+          HIP_TRY(hipDeviceSynchronize()); // an earlier block may still use the old buffer
+          dev_free(c, sc2.car_gen_d); dev_free(c, sc2.car_gen_f);
+          sc2.car_gen_cap = n;
+          if ((r = dev_alloc(c, &sc2.car_gen_d, S * n, false))) return r;
+          if ((r = dev_alloc(c, &sc2.car_gen_f, S * n, false))) return r;
+        }
+      }
+      b.car_gen_d = c->scr[c->parity].car_gen_d; b.car_gen_f = c->scr[c->parity].car_gen_f; b.car_gen_cap = c->scr[c->parity].car_gen_cap;
     }
     RaFrameRange mod = ra_frames_firing(p.voc_Wm, p.voc_S, c->t, n), car = ra_frames_firing(2 * p.voc_S, p.voc_S, c->t, n);
     if (p.voc_kind != RA_VOCODER_FFT) { mod.count = 0; car.count = 0; }
@@ -702,7 +708,7 @@ int timed_launch(ra_context *c, int stage, hipStream_t st, F &&launch) {
 // makes the caller's stream wait for everything the internal streams still hold (asynchronous blocks); no host synchronisation
 int join_streams(ra_context *c) {
   if (!c->pending_join || !c->pipe_ready) { c->pending_join = false; return RA_OK; }
-  for (int i = 0; i < 5; ++i) {
+  for (int i = 0; i < 6; ++i) {
     HIP_TRY(hipEventRecord(c->ev_join[i], c->pipe_stream[i]));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join[i], 0));
   }
@@ -792,14 +798,15 @@ int process_block_impl(ra_context *c, const float *d_voice, const float *d_carri
   const bool limit = p.post_limit && apply_post && d_out_final;
   float *d_out = limit ? nullptr : d_out_final;
   double *d_out_d = limit ? b.post_d : d_out_d_caller;
-  auto launch_vocoder = [&](hipStream_t st) { // K6 (when the synth supplies the carrier) then K4 / K7
-    if (car_gen) {
-      const std::vector<RaCarEv> &flat = c->car_upload[c->parity];
-      const std::vector<int32_t> &begin = c->car_upload_begin[c->parity];
-      if (!flat.empty()) (void)hipMemcpyAsync(b.car_ev, flat.data(), flat.size() * sizeof(RaCarEv), hipMemcpyHostToDevice, st);
-      (void)hipMemcpyAsync(b.car_ev_begin, begin.data(), begin.size() * sizeof(int32_t), hipMemcpyHostToDevice, st);
-      ra_launch_carrier_synth(p, b, t0, n, c->car_total_segs, st);
-    }
+  auto launch_carrier = [&](hipStream_t st) { // K6: the carrier synth (when it supplies the carrier)
+    const std::vector<RaCarEv> &flat = c->car_upload[c->parity];
+    const std::vector<int32_t> &begin = c->car_upload_begin[c->parity];
+    if (!flat.empty()) (void)hipMemcpyAsync(b.car_ev, flat.data(), flat.size() * sizeof(RaCarEv), hipMemcpyHostToDevice, st);
+    (void)hipMemcpyAsync(b.car_ev_begin, begin.data(), begin.size() * sizeof(int32_t), hipMemcpyHostToDevice, st);
+    ra_launch_carrier_synth(p, b, t0, n, c->car_total_segs, st);
+  };
+  auto launch_vocoder = [&](hipStream_t st) { // K6 then K4 / K7 on one queue
+    if (car_gen) launch_carrier(st);
     ra_launch_vocoder(p, b, d_voice, car_f, car_d, t0, n, st);
   };
 
@@ -851,45 +858,56 @@ int process_block_impl(ra_context *c, const float *d_voice, const float *d_carri
       // fills whatever the chain leaves free: the chain's queues get dispatch priority over the render queue.
       int prio_least = 0, prio_greatest = 0;
       HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-      for (int i = 0; i < 5; ++i) {
+      for (int i = 0; i < 6; ++i) {
         // RA_PIPELINE_PRIO (tuning aid): 0 = flat, 1 = chain high / render and vocoder low, 2 = tracking and propagation high, the others normal
         const int prio = prio_mode == 0 ? 0 : prio_mode == 2 ? ((i == 1 || i == 2) ? prio_greatest : 0) : (i >= 3 ? prio_least : prio_greatest);
         HIP_TRY(hipStreamCreateWithPriority(&c->pipe_stream[i], hipStreamNonBlocking, prio));
       }
       HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&c->ev_voc, hipEventDisableTiming));
-      for (int i = 0; i < 5; ++i) HIP_TRY(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&c->ev_car, hipEventDisableTiming));
+      for (int i = 0; i < 6; ++i) HIP_TRY(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
       for (int i = 0; i < kMaxChunks; ++i)
         for (int k = 0; k < 3; ++k) HIP_TRY(hipEventCreateWithFlags(&c->ev_chunk[k][i], hipEventDisableTiming));
       c->pipe_ready = true;
     }
     // every stage has a queue of its own (on a shared queue propagate(i+1) would wait for render(i)); the caller's stream only
     // forks into them and joins them at the end of the block
-    hipStream_t sA = c->pipe_stream[0], sT = c->pipe_stream[1], sP = c->pipe_stream[2], sR = c->pipe_stream[3], sV = c->pipe_stream[4];
+    hipStream_t sA = c->pipe_stream[0], sT = c->pipe_stream[1], sP = c->pipe_stream[2], sR = c->pipe_stream[3], sV = c->pipe_stream[4], sC = c->pipe_stream[5];
     // streams of one priority share ROCm's 4 hardware queues; with flat priorities the analysis rides on the caller's stream instead so that
     // no two stages end up behind each other on one queue
     if (prio_mode == 0) sA = user;
     static const bool one_queue_env = std::getenv("RA_PIPELINE_SERIAL") != nullptr; // tuning aid: same chunks, no overlap
     const bool one_queue = one_queue_env || c->pipeline_serial;
-    if (one_queue) sA = sT = sP = sR = sV = user;
+    if (one_queue) sA = sT = sP = sR = sV = sC = user;
     if (sA == user) { if ((r = join_streams(c))) return r; async = false; } // tuning modes that use the caller's stream cannot overlap blocks
     HIP_TRY(hipEventRecord(c->ev_fork, user));
-    for (int i = 0; i < 5; ++i) HIP_TRY(hipStreamWaitEvent(c->pipe_stream[i], c->ev_fork, 0));
+    for (int i = 0; i < 6; ++i) HIP_TRY(hipStreamWaitEvent(c->pipe_stream[i], c->ev_fork, 0));
     // this scratch set was last used two blocks ago: its writers here wait for its readers there (normally long done)
     if (!sc.ev_track_done) {
       HIP_TRY(hipEventCreateWithFlags(&sc.ev_track_done, hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&sc.ev_prop_done, hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&sc.ev_render_done, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&sc.ev_voc_done, hipEventDisableTiming));
     }
     if (sc.used) {
       HIP_TRY(hipStreamWaitEvent(sA, sc.ev_track_done, 0));  // analysis rewrites the pitch lists tracking read
       HIP_TRY(hipStreamWaitEvent(sT, sc.ev_prop_done, 0));   // tracking rewrites the commands propagation read
       HIP_TRY(hipStreamWaitEvent(sP, sc.ev_render_done, 0)); // propagation rewrites the hop states the render read
       if (p.voc_enabled) HIP_TRY(hipStreamWaitEvent(sV, sc.ev_render_done, 0)); // the vocoder rewrites this set's mix, which that render added
+      if (p.voc_enabled && car_gen) HIP_TRY(hipStreamWaitEvent(sC, sc.ev_voc_done, 0)); // the carrier synth rewrites this set's carrier, which that vocoder read
     }
     if (p.voc_enabled) { // independent of the analysis chain, on a queue of its own: block k + 1's vocoder runs while block k renders (the
-      // mix exists per scratch set; the vocoder's own scratch and the generated carrier are only touched on this queue, in block order)
-      RA_TRY(timed_launch(c, ST_VOCODER, sV, [&] { launch_vocoder(sV); }));
+      // mix exists per scratch set; the vocoder's own scratch is only touched on this queue, in block order).  The carrier synth — two chains
+      // a few hundred waves wide that only FEED the vocoder — has a queue of its own too (r03): block k + 1's walk and render run beside
+      // block k's filter bank (the generated carrier exists per scratch set; the synth's segment tables are only touched on its queue)
+      if (car_gen && sC != sV) {
+        RA_TRY(timed_launch(c, ST_VOCODER, sC, [&] { launch_carrier(sC); }));
+        HIP_TRY(hipEventRecord(c->ev_car, sC));
+        HIP_TRY(hipStreamWaitEvent(sV, c->ev_car, 0));
+        RA_TRY(timed_launch(c, ST_VOCODER, sV, [&] { ra_launch_vocoder(p, b, d_voice, car_f, car_d, t0, n, sV); }));
+      } else RA_TRY(timed_launch(c, ST_VOCODER, sV, [&] { launch_vocoder(sV); }));
+      HIP_TRY(hipEventRecord(sc.ev_voc_done, sV));
       HIP_TRY(hipEventRecord(c->ev_voc, sV));
       if (sR != sV) HIP_TRY(hipStreamWaitEvent(sR, c->ev_voc, 0));
     }
@@ -1119,12 +1137,12 @@ void ra_destroy(ra_context *c) {
   for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->pipe_ready) {
-    for (int i = 0; i < 5; ++i) { (void)hipStreamSynchronize(c->pipe_stream[i]); (void)hipStreamDestroy(c->pipe_stream[i]); }
-    (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_voc);
+    for (int i = 0; i < 6; ++i) { (void)hipStreamSynchronize(c->pipe_stream[i]); (void)hipStreamDestroy(c->pipe_stream[i]); }
+    (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_voc); (void)hipEventDestroy(c->ev_car);
     for (auto e : c->ev_join) (void)hipEventDestroy(e);
     for (auto &row : c->ev_chunk) for (auto e : row) if (e) (void)hipEventDestroy(e);
   }
-  for (auto &sc : c->scr) for (hipEvent_t e : {sc.ev_track_done, sc.ev_prop_done, sc.ev_render_done}) if (e) (void)hipEventDestroy(e);
+  for (auto &sc : c->scr) for (hipEvent_t e : {sc.ev_track_done, sc.ev_prop_done, sc.ev_render_done, sc.ev_voc_done}) if (e) (void)hipEventDestroy(e);
   delete c;
 }
 
