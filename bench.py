@@ -162,7 +162,7 @@ def carrier_chords(S, n_steps_total, n):
 class Runner:
     """One context on one GPU, its inputs resident in HBM; step() issues one block the way an offline job does."""
 
-    def __init__(self, api, torch, dev, local_rank, cfg_kw, S, n, seed, carrier=None, stream_ordered=False, total_steps=0):
+    def __init__(self, api, torch, dev, local_rank, cfg_kw, S, n, seed, carrier=None, stream_ordered=False, total_steps=0, setup_block=True):
         self.api, self.torch, self.S, self.n = api, torch, S, n
         self.voice = synth_inputs_torch(S, n, SR, seed, dev)
         self.carrier = carrier_saw_torch(S, n, SR, dev) if carrier == "wav" else None
@@ -175,9 +175,11 @@ class Runner:
         self.total_steps = total_steps
         # set-up, not a step: a 2 s block makes HIP load the code objects and creates the context's internal streams and events, then
         # the streams are put back to their initial state; the per-block scratch (GBs) is still allocated by the first warm-up step
-        self.ctx.process_device(self.voice.data_ptr(), self.carrier.data_ptr() if self.carrier is not None else 0, min(n, 2 * SR), self.out.data_ptr())
-        self.ctx.synchronize()
-        self.ctx.reset()
+        # (scripts/profile_workload.py leaves it out: under rocprofv3 every launch of the run should belong to one of its equal steps)
+        if setup_block:
+            self.ctx.process_device(self.voice.data_ptr(), self.carrier.data_ptr() if self.carrier is not None else 0, min(n, 2 * SR), self.out.data_ptr())
+            self.ctx.synchronize()
+            self.ctx.reset()
         if self.chords:
             self.ctx.carrier_events(carrier_chords(S, total_steps, n))
 
@@ -284,6 +286,28 @@ def time_voice(api, torch, dev, which, S, seconds, steps):
             "steps": steps, "ms_per_step": dt * 1e3, "ms_per_step_one_block_at_a_time": dt_sync * 1e3, "host_ms_per_step": t_host * 1e3,
             "kernel_ms_per_step": {k: x / max(launches, 1) for k, x in kms.items()}, "frames_per_s": S * n / dt, "x_realtime": seconds / dt,
             "dropped_note_on": int(dropped), "out_rms": rms}
+
+
+def workloads(N=4096, H=1024, P=64):
+    """The single-GPU workloads of the bench line besides the headline, by the name their profiles are kept under (profiles/rNN/<name>/).
+    Resynthesis workloads: (description, config, streams, carrier source); gen.voice workloads: (which, synths)."""
+    parity = dict(analysis_volume=1.0, stereo_spread=0.0, carrier_volume=0.0, seed=1234)
+    voc = dict(parity, analysis_volume=0.0, voice_volume=0.0, carrier_volume=0.0, vocoder_volume=1.0, vocoder_count_bands=32, vocoder_min_freq=100.0,
+               vocoder_max_freq=20000.0, vocoder_modulator_window_size_seconds=0.10, vocoder_stride_seconds=0.005)
+    return {
+        "configs1": ("configs[1] (the headline shape): 256 mono streams, N 4096, H 1024, P 64", dict(parity, window_size=N, stride=H, n_channels=P), 256, None),
+        "north_star": ("north_star operating point: 1000 concurrent 48 kHz mono streams, 4096-pt window, 75 % overlap, 64 partials, on one MI355X (= one rank of configs[4])",
+                       dict(parity, window_size=N, stride=H, n_channels=P), 1000, None),
+        "stereo": ("configs[1] with stereo_spread = 1 (the reference default): 256 streams, N 4096, H 1024, P 64",
+                   dict(parity, window_size=N, stride=H, n_channels=P, stereo_spread=1.0), 256, None),
+        "voc_fft": ("configs[2] FFT vocoder: 256 streams, 32 bands, S = 241, modulator FFT 8192, carrier FFT 512, carrier from a file", voc, 256, "wav"),
+        "voc_bank": ("configs[2] band-pass bank (vocoder_kind 1): 256 streams, 32 bands, carrier from the carrier synth (sine + saw voices, 16 channels)",
+                     dict(voc, vocoder_kind=1, carrier_n_channels=16, vocoder_carrier_square_volume=0.0, vocoder_carrier_sine_volume=0.7, vocoder_carrier_saw_volume=0.3),
+                     256, "synth"),
+        "configs3": ("configs[3]: 1000 stereo = 2000 mono streams, N = 8192, H = 2048, P = 128, autotune major / C",
+                     dict(parity, window_size=8192, stride=2048, n_channels=128, use_autotune=1, autotune_type=0, autotune_scale_mode=0, autotune_root_note=0), 2000, None),
+        "voice_sweep": ("sweep", 256), "voice_birds": ("birds", 256), "voice_robots": ("robots", 256),
+    }
 
 
 def time_config(api, torch, dev, name, cfg_kw, S, seconds, steps, carrier=None):

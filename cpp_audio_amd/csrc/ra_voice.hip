@@ -34,7 +34,8 @@ namespace {
 constexpr int TS = 8; // samples a lane parks in LDS before the wave sums the slots
 
 struct Ramp { // the registers of a lane while it steps a job
-  double cur, from, to, dur, inv_dur, C, l2r; // LogRamp; l2r = log2(to / from) (PROPORTIONAL_VALUE_DERIVATIVE only)
+  double cur, from, to, dur, inv_dur, l2r;    // LogRamp; l2r = log2(to / from) (PROPORTIONAL_VALUE_DERIVATIVE only)
+  double al, be, be_o;                        // its time step as one multiply-add, cur' = al cur + be; when the ramp turns: al' = 2 - al, be' = be_o
   double theta, y;                            // phase sum (units of pi, kept in [0, 2)); the loudness volume
   float lo_f, hi_f, inv_w, lo_e, hi_e;        // the loudness table interval the ramp is in: its two frequencies, 1 / width, its two levels
   int interp, loud_k, swapped;
@@ -106,13 +107,28 @@ __device__ __noinline__ double ease01(int kind, double u) {
 }
 
 // LogRamp::do_step (audioelement.h:2522-2542) in two halves.  ramp_tick: the wrap at the ramp's end, then `cur` moves on by C times the
-// increment half a sample later; it returns the time of this step.  ramp_value: the increment at that time.  The two divisions by the
-// ramp's constant duration are multiplications by its reciprocal (an ulp on the increment).
+// increment half a sample later; it returns the time of this step.  ramp_value: the increment at that time.
+// The time step cur + C (from + (to - from) (cur + 1/2) / dur) is affine in cur: it runs as ONE multiply-add with the two constants formed
+// once per ramp (al = 1 + C (to - from) / dur, be = C (from + (to - from) / (2 dur)); swapped ends: 2 - al (exact for al >= 1) and
+// C (to - (to - from) / (2 dur))).
+// All three kernels step time with this very code, so their states agree bit for bit; against the reference's operation order the
+// trajectory differs by rounding (1e-16 relative per step, a few 1e-12 of the duration after the longest ramp).
+__device__ inline bool ramp_turn(Ramp &r) { // the ramp has reached its end: it restarts from the other end (periodic ramp)
+  const bool w = r.cur + 0.5 > r.dur;
+  if (__builtin_amdgcn_ballot_w64(w) == 0) return false; // (a wave-uniform branch: the turn is one step of a ramp's thousands — without it the selects below run every step)
+  if (w) {
+    r.cur = 0.0;
+    double t = r.from; r.from = r.to; r.to = t;
+    r.al = 2.0 - r.al;
+    t = r.be; r.be = r.be_o; r.be_o = t;
+    r.l2r = -r.l2r; r.swapped ^= 1;
+  }
+  return w;
+}
 __device__ inline double ramp_tick(Ramp &r) {
-  if (r.cur + 0.5 > r.dur) { r.cur = 0.0; const double t = r.from; r.from = r.to; r.to = t; r.l2r = -r.l2r; r.swapped ^= 1; }
+  ramp_turn(r);
   const double c0 = r.cur;
-  const double f = fma(r.to - r.from, (c0 + 0.5) * r.inv_dur, r.from);
-  r.cur = fma(r.C, f, c0);
+  r.cur = fma(r.al, c0, r.be);
   return c0;
 }
 __device__ inline double ramp_value(const Ramp &r, double c0) {
@@ -137,13 +153,22 @@ __device__ inline double wrap2(double th) { return th - 2.0 * floor(th * 0.5); }
 
 __device__ inline void ramp_setup(Ramp &r, const RaVoiceJob &J) {
   r.from = J.from; r.to = J.to; r.dur = J.dur; r.inv_dur = rcp_newton(J.dur);
-  r.C = J.C;       // get_linear_proportionality_constant :2560-2571, from the host (symmetric in from / to: a swap keeps it)
+  { // J.C: get_linear_proportionality_constant :2560-2571, from the host (symmetric in from / to: a swap keeps it)
+    const double g = (J.to - J.from) * r.inv_dur;
+    r.al = fma(J.C, g, 1.0); r.be = J.C * fma(0.5, g, J.from);
+    r.be_o = J.C * fma(-0.5, g, J.to);
+  }
   r.interp = J.interp;
   r.l2r = J.l2r;
   r.cur = J.cur0; r.theta = 0.0; r.y = 0.0; r.loud_k = 14; r.swapped = 0;
 }
 __device__ inline void ramp_swap_if(Ramp &r, int swapped) {
-  if (swapped != r.swapped) { const double t = r.from; r.from = r.to; r.to = t; r.l2r = -r.l2r; r.swapped = swapped; }
+  if (swapped != r.swapped) {
+    double t = r.from; r.from = r.to; r.to = t;
+    r.al = 2.0 - r.al;
+    t = r.be; r.be = r.be_o; r.be_o = t;
+    r.l2r = -r.l2r; r.swapped = swapped;
+  }
 }
 __device__ inline void ramp_load(Ramp &r, const RaVoiceJob &J, const RaVoiceState *st, const float *__restrict__ lf, const float *__restrict__ le) { // st == nullptr: the job's first step is next
   ramp_setup(r, J);
@@ -178,12 +203,25 @@ __global__ void __launch_bounds__(64) ra_voice_pre_a_kernel(const RaVoiceJob *__
   const int last = J.begin + J.n; // (exclusive)
   const int steps = (J.state_out >= 0) ? J.n : ((last - 1) / L) * L - J.begin; // up to the last state somebody reads
   int next_b = (J.begin / L + 1) * L, slot = J.state_tiles;
+  // only time and the turn flag are carried here (ramp_tick without the ends): the chain per step is one multiply-add and a select
+  double cur = r.cur, al = r.al, be = r.be, be_o = r.be_o;
+  const double dur = r.dur;
+  int sw = r.swapped;
   for (int i = 0; i < steps; ++i) {
-    if (J.begin + i == next_b) { st_cur[slot].cur = r.cur; st_cur[slot].swapped = r.swapped; seg[slot].job = ji; ++slot; next_b += L; }
-    ramp_tick(r);
+    if (J.begin + i == next_b) { st_cur[slot].cur = cur; st_cur[slot].swapped = sw; seg[slot].job = ji; ++slot; next_b += L; }
+    const bool w = cur + 0.5 > dur;
+    if (__builtin_amdgcn_ballot_w64(w) != 0) { // (wave-uniform branch around the turn, see ramp_turn)
+      const double b2 = w ? be_o : be;
+      be_o = w ? be : be_o;
+      be = b2;
+      al = w ? 2.0 - al : al;
+      sw ^= w ? 1 : 0;
+      cur = w ? 0.0 : cur;
+    }
+    cur = fma(al, cur, be);
   }
-  if (J.begin + steps == next_b && J.begin + steps < last) { st_cur[slot].cur = r.cur; st_cur[slot].swapped = r.swapped; seg[slot].job = ji; }
-  if (J.state_out >= 0) { st_cur[J.state_out].cur = r.cur; st_cur[J.state_out].swapped = r.swapped; seg[J.state_out].job = ji; }
+  if (J.begin + steps == next_b && J.begin + steps < last) { st_cur[slot].cur = cur; st_cur[slot].swapped = sw; seg[slot].job = ji; }
+  if (J.state_out >= 0) { st_cur[J.state_out].cur = cur; st_cur[J.state_out].swapped = sw; seg[J.state_out].job = ji; }
 }
 
 __global__ void __launch_bounds__(256) ra_voice_pre_b_kernel(RaVoiceParams p, const RaVoiceJob *__restrict__ jobs, int n_slots, const RaVoiceState *__restrict__ st_prev,
@@ -233,23 +271,29 @@ __global__ void __launch_bounds__(64) ra_voice_pre_c_kernel(const RaVoiceJob *__
 }
 
 // ---- render --------------------------------------------------------------------------------------------------------------------------
-// sin(pi x), x in [0, 2): reduced to |r| <= 1/2 (sin(pi (1 + r)) = -sin(pi r), sin(pi (+-1 - r)) = sin(pi r)), then the odd series to
-// r^19 (the next term is below 3e-16 at r = 1/2)
+// d = a b + c as the three-address instruction.  (The compiler turns a Horner chain whose coefficients live in VGPRs into v_mov_b64 + v_fmac_f64
+// pairs — two issue slots per term; the chain below is a fifth of the render's instructions.)
+__device__ inline double fma3(double a, double b, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+// sin(pi x), x in [0, 2]: k = the nearest integer, r = x - k in [-1/2, 1/2], sin(pi x) = (-1)^k sin(pi r); sin(pi r) / r as a polynomial of
+// degree 6 in r^2 (a Chebyshev fit on [0, 1/4]: within 8e-14 of the function — the output is a float — against 4e-16 for degree 7; every
+// coefficient is a VGPR pair held through the loop), the sign as a flip of the sign bit
 __device__ inline double osc_imag(double theta) {
-  double r = theta - 1.0;                     // [-1, 1): the value is -sin(pi r)
-  r = (r > 0.5) ? 1.0 - r : ((r < -0.5) ? -1.0 - r : r);
+  const double kf = rint(theta), r = theta - kf;
   const double z = r * r;
-  double v = -2.2948428997269856e-08;                              // (-1)^k pi^(2k+1) / (2k+1)!, k = 9 .. 0
-  v = fma(v, z, 7.952054001475508e-07);
-  v = fma(v, z, -2.1915353447830204e-05);
-  v = fma(v, z, 0.00046630280576761234);
-  v = fma(v, z, -0.007370430945714348);
-  v = fma(v, z, 0.08214588661112819);
-  v = fma(v, z, -0.5992645293207919);
-  v = fma(v, z, 2.550164039877345);
-  v = fma(v, z, -5.167712780049969);
-  v = fma(v, z, 3.141592653589793);
-  return -(v * r);
+  double v = 0.00044749586935114105;
+  v = fma3(v, z, -0.007364008149410389);
+  v = fma3(v, z, 0.08214479537170938);
+  v = fma3(v, z, -0.5992644340182135);
+  v = fma3(v, z, 2.55016403591087);
+  v = fma3(v, z, -5.167712779988022);
+  v = fma3(v, z, 3.141592653589636);
+  v *= r;
+  const unsigned flip = ((unsigned)(int)kf & 1u) << 31;
+  return __hiloint2double(__double2hiint(v) ^ (int)flip, __double2loint(v));
 }
 __device__ inline double alias_gain(double inc) { // freqAliasingMultiplicator, audioelement.h:466-483
   if (inc > 0.0 && inc <= 0.25) return 1.0;
@@ -262,12 +306,12 @@ __device__ inline double alias_gain(double inc) { // freqAliasingMultiplicator, 
 
 struct Seg { // the piece of a job a lane renders inside its tile
   Ramp r;
-  double vol, fL, fR, inv_A, inv_R, top;
+  double cL, cR, inv_A, inv_R, top; // cL / cR = the job's output factor times the ramp's volume times the Mix gain (constants of the job)
   int lo, hi, j, T, A;
 };
 
 __device__ inline void seg_open(Seg &g, const RaVoiceJob &J, int f_lo, int f_hi, int q, int L, const RaVoiceState *__restrict__ st_prev, const RaVoiceState *__restrict__ st_cur,
-                                const float *__restrict__ lf, const float *__restrict__ le) {
+                                const float *__restrict__ lf, const float *__restrict__ le, float sine_gain) {
   g.lo = max(J.begin, f_lo);
   g.hi = min(J.begin + J.n, f_hi);
   const RaVoiceState *st;
@@ -278,7 +322,7 @@ __device__ inline void seg_open(Seg &g, const RaVoiceJob &J, int f_lo, int f_hi,
   g.T = J.T; g.A = J.A;
   g.inv_A = rcp_newton((double)J.A); g.inv_R = rcp_newton((double)J.R);
   g.top = (J.T < J.A) ? (double)J.T * g.inv_A : 1.0; // the envelope's value when the key is released (startReleased, audioelement.h:836-841)
-  g.vol = J.vol; g.fL = J.fL; g.fR = J.fR;
+  g.cL = J.fL * (J.vol * (double)sine_gain); g.cR = J.fR * (J.vol * (double)sine_gain);
 }
 
 template <int MAXT>
@@ -334,7 +378,7 @@ __global__ void __launch_bounds__(MAXT) ra_voice_render_kernel(RaVoiceParams p, 
       const int f = fb + i;
       double vL = 0.0, vR = 0.0;
       if (f == next_lo) { // (the one place a job is opened: at the tile's first frame if it is already sounding, else where it begins)
-        seg_open(sg, jobs[jb], f_lo, f_hi, q, L, st_prev, st_cur, lf, le);
+        seg_open(sg, jobs[jb], f_lo, f_hi, q, L, st_prev, st_cur, lf, le, p.sine_gain);
         have = true;
         next_lo = kNever;
       }
@@ -348,9 +392,10 @@ __global__ void __launch_bounds__(MAXT) ra_voice_render_kernel(RaVoiceParams p, 
         const double env = (j <= sg.T) ? ((j < sg.A) ? (double)j * sg.inv_A : 1.0)                       // attack then sustain 1 (stepPressed :960-1000)
                                        : fma(-sg.top, (double)(j - sg.T) * sg.inv_R, sg.top);         // release: top + (-top) m / R (:732-737)
         const double osc = alias_gain(inc) * osc_imag(sg.r.theta);                                       // SineOscillatorAlgo::imag :2424
-        const double mix = 0.0 + (double)p.sine_gain * (sg.r.y * osc);                                   // Mix::imag :1867-1873 over LoudnessVolumeAdjusted
-        const double mono = sg.vol * (mix * env);                                                        // VolumeAdjusted over Enveloped
-        vL = sg.fL * mono; vR = sg.fR * mono;
+        // Mix::imag (gain * (loudness volume * osc), :1867-1873) under the envelope, the ramp's volume, the stereo gain and the element's
+        // volume: the constant factors are folded into cL / cR (an ulp from the reference's order of the multiplications)
+        const double mono = (sg.r.y * osc) * env;
+        vL = sg.cL * mono; vR = sg.cR * mono;
         ++sg.j;
         if (f + 1 == sg.hi) { // the segment ends: the slot's next job may begin inside this tile
           have = false;

@@ -1,32 +1,52 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (gpurun): GPU pytest log, bench line, rocprofv3 kernel stats of the same bench command, and the PMC passes
-# (one counter per run, --pmc never combined with a trace domain other than --kernel-trace) that profiles/rNN/traffic.json is built
-# from.  Output goes to gpurun_out/prof_<tag>/ ; copy what should be judged into profiles/rNN/.
-#   gpurun --timeout 1200 -- 'scripts/collect_profiles.sh c_pipeline'
-# SKIP_PYTEST=1 skips the test run; COUNTERS="..." overrides the counter list.
+# Runs ON THE GPU BOX (gpurun).  Two parts, both into gpurun_out/prof_<tag>/ :
+#   headline   the bench line, rocprofv3 kernel stats of the same bench command and the PMC passes profiles/rNN/traffic.json is built from
+#              (scripts/pmc_aggregate.py) — as in r02;
+#   workloads  for every other workload of the bench line (bench.workloads(): north_star, stereo, voc_fft, voc_bank, configs3, voice_*) and
+#              for configs1 itself: `rocprofv3 --kernel-trace --stats` and three `--pmc` passes (the six SQ counters fit one pass: 8 SQ slots;
+#              FETCH_SIZE and WRITE_SIZE need a pass each: MI355X_MICROARCH.md, PMC slots) of scripts/profile_workload.py <name> 3.
+# --pmc is never combined with a trace domain other than --kernel-trace; the program goes directly after `--`.
+#   gpurun --timeout 1200 -- 'scripts/collect_profiles.sh r03 headline'      gpurun --timeout 1200 -- 'scripts/collect_profiles.sh r03 workloads voc_fft voc_bank'
+# then: python scripts/pmc_aggregate.py gpurun_out/prof_r03 ; python scripts/profile_aggregate.py gpurun_out/prof_r03/workloads profiles/r03
 set -o pipefail
 TAG=${1:-run}
+PART=${2:-headline}
+shift 2
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/prof_$TAG
-COUNTERS=${COUNTERS:-FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE}
+SQ="SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 mkdir -p $OUT
 cd $ROOT
-if [ -z "$SKIP_PYTEST" ]; then
-  python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1 || { tail -5 $OUT/pytest_gpu.log; exit 1; }
+if [ "$PART" = headline ]; then
+  if [ -z "$SKIP_BENCH" ]; then
+    python bench.py --steps 5 --warmup 1 > $OUT/bench_full.log 2>&1 || { tail -5 $OUT/bench_full.log; exit 1; }
+    grep '^{"metric"' $OUT/bench_full.log > $OUT/bench.json
+  fi
+  cd /tmp && export TMPDIR=/tmp
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > $OUT/stats_run.log 2>&1 || { tail -5 $OUT/stats_run.log; exit 1; }
+  for ctr in FETCH_SIZE WRITE_SIZE $SQ; do
+    rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/pmc_$ctr -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-other-configs > $OUT/pmc_$ctr.log 2>&1 || { tail -5 $OUT/pmc_$ctr.log; exit 1; }
+    echo "pmc $ctr done"
+  done
+  cd $ROOT
+  python scripts/pmc_aggregate.py $OUT > $OUT/aggregate.log 2>&1
+  tail -3 $OUT/aggregate.log
+else
+  NAMES=${@:-configs1 north_star stereo voc_fft voc_bank configs3 voice_sweep voice_birds voice_robots}
+  cd /tmp && export TMPDIR=/tmp
+  for w in $NAMES; do
+    W=$OUT/workloads/$w
+    mkdir -p $W
+    rocprofv3 --kernel-trace --stats --output-format csv -d $W/stats -- python3 $ROOT/scripts/profile_workload.py $w 3 > $W/stats_run.log 2>&1 || { tail -5 $W/stats_run.log; exit 1; }
+    rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $W/pmc_SQ -- python3 $ROOT/scripts/profile_workload.py $w 3 > $W/pmc_SQ.log 2>&1 || { tail -5 $W/pmc_SQ.log; exit 1; }
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $W/pmc_FETCH -- python3 $ROOT/scripts/profile_workload.py $w 3 > $W/pmc_FETCH.log 2>&1 || { tail -5 $W/pmc_FETCH.log; exit 1; }
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $W/pmc_WRITE -- python3 $ROOT/scripts/profile_workload.py $w 3 > $W/pmc_WRITE.log 2>&1 || { tail -5 $W/pmc_WRITE.log; exit 1; }
+    grep '^{"workload"' $W/stats_run.log | tail -1 | cut -c1-200
+  done
+  cd $ROOT
 fi
-python bench.py --steps 5 --warmup 1 > $OUT/bench_full.log 2>&1 || { tail -5 $OUT/bench_full.log; exit 1; }
-grep '^{"metric"' $OUT/bench_full.log > $OUT/bench.json
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > $OUT/stats_run.log 2>&1 || { tail -5 $OUT/stats_run.log; exit 1; }
-for ctr in $COUNTERS; do
-  rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/pmc_$ctr -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-other-configs > $OUT/pmc_$ctr.log 2>&1 || { tail -5 $OUT/pmc_$ctr.log; exit 1; }
-  echo "pmc $ctr done"
-done
-cd $ROOT
-python scripts/pmc_aggregate.py $OUT > $OUT/aggregate.log 2>&1
-tail -3 $OUT/aggregate.log
-# keep the merge-back small: drop the raw per-dispatch CSVs, keep the summaries
+# keep the merge-back small: drop the raw per-dispatch CSVs that are not needed, keep the summaries
 find $OUT -name "*_agent_info.csv" -delete
-find $OUT -name "*counter_collection.csv" -size +8M -delete
-find $OUT/stats -name "*kernel_trace.csv" -delete 2>/dev/null
-ls $OUT
+find $OUT -name "*kernel_trace.csv" -delete 2>/dev/null
+find $OUT -name "*counter_collection.csv" -size +12M -delete
+du -sh $OUT
