@@ -401,6 +401,8 @@ def main():
     n = int(round(args.seconds * SR))
     N, H, P = args.window, args.stride, args.partials
     head_kw = dict(window_size=N, stride=H, n_channels=P, analysis_volume=1.0, stereo_spread=0.0, carrier_volume=0.0, seed=1234 + first_stream)
+    if os.environ.get("RA_BENCH_MAXR"):   # tuning aid: the per-frame list capacity (LDS of an analysis workgroup)
+        head_kw["max_pitches_per_frame"] = int(os.environ["RA_BENCH_MAXR"])
     run = Runner(api, torch, dev, local_rank, head_kw, S, n, 1234 + 100003 * rank, stream_ordered=args.stream_ordered)
     ctx, voice, out = run.ctx, run.voice, run.out
 

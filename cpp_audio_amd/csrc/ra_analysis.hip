@@ -17,6 +17,16 @@
 extern __shared__ __align__(16) unsigned char ra_smem[];
 
 __host__ __device__ inline int ra_list_capacity(const RaParams &p) { return (p.harm_pre != 0.f || p.harm_post != 0.f) ? 2 * p.maxr : p.maxr; }
+// The two reduced lists [cap] live INSIDE the FFT buffer when they fit its M slots (r03): by the time they are written (step 5c) the spectrum
+// and the peak list in it have been consumed — a thread first takes its (at most four) reduced items into registers, a barrier retires
+// every reader of the buffer, then the items are stored.  An analysis workgroup then holds the FFT buffer and ~1.5 KB (51 -> 34 KB at
+// N = 4096 with the default capacity of 512): beside the renderer's waves a CU takes a second one (measured with the kernel compiled for
+// 128 VGPRs: configs[1] 13.9 -> 13.2 ms per step; either change alone: nothing).  Otherwise (small windows, huge capacities) the lists follow
+// the buffer as before.
+__host__ __device__ inline bool ra_lists_in_fft_buffer(int M, int cap, int T) { return 2 * cap <= M && ((M >> 1) + T - 1) / T <= 4 && M >= 512; }
+// ints of the small area behind the FFT buffer: the block scans (T + 32), then from step 6 on the published scalars (16), the merge's scan
+// (T + 32) and — when the lists are in the buffer — the loudness tables (29 doubles + 29 floats)
+__host__ __device__ inline int ra_aux_ints(int T) { return 16 + (T + 32) + 96; }
 
 // tuning aid: -DRA_X_STOP=n ends the analysis kernel after phase n (instruction-count ablations with scripts/pmc_probe.sh); 0 = off
 #ifndef RA_X_STOP
@@ -140,7 +150,10 @@ __device__ inline void block_exclusive_scan(int *scan, int v, int tid) {
 }
 
 template <int T>
-__global__ void __launch_bounds__(T, (T >= 512 ? 4 : 1)) // 512 / 1024 threads: 4 waves per SIMD (<= 128 VGPRs), so that two 512-thread groups share a CU
+#ifndef RA_ANALYSIS_EU256
+#define RA_ANALYSIS_EU256 4 // the minimum waves per SIMD the 128 / 256-thread kernel is compiled for: 4 = at most 128 VGPRs (143 without; see ra_lists_in_fft_buffer)
+#endif
+__global__ void __launch_bounds__(T, (T >= 512 ? 4 : RA_ANALYSIS_EU256)) // 512 / 1024 threads: 4 waves per SIMD (<= 128 VGPRs), so that two 512-thread groups share a CU
 ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int64_t t0, int64_t n, int64_t f_lo, int fb0, int nfb_total, int nfb_launch) {
 #ifndef RA_ANALYSIS_PRIO
 #define RA_ANALYSIS_PRIO 0
@@ -165,9 +178,11 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   const int zs = ra_zshift(p.log2M);
   auto Z = [&](int i) -> double2 & { return z[ra_zslot(i, zs)]; };
   const int cap = ra_list_capacity(p);                         // harmonize may double a list; otherwise maxr entries suffice
-  double2 *listA = z + ra_zsize(M);                        // [cap]
+  const bool lists_in_z = ra_lists_in_fft_buffer(M, cap, T);
+  int *aux = reinterpret_cast<int *>(z + ra_zsize(M));         // [ra_aux_ints(T)] when the lists are in the buffer
+  double2 *listA = lists_in_z ? z : z + ra_zsize(M);           // [cap]
   double2 *listB = listA + cap;                                // [cap]
-  int *scan = reinterpret_cast<int *>(listA);                   // [T+1], aliases listA: consumed (K read) before the lists are written
+  int *scan = lists_in_z ? aux + 16 : reinterpret_cast<int *>(listA); // [T+1] (outside the buffer it aliases listA: consumed (K read) before the lists are written)
 
   RaPhaseClock clk(b.dbg_clk, tid == 0);
   // twiddles W^k, W^(M-k) of the real-spectrum split (step 3) for the pairs k0, k0 + T: fetched one trip ahead, the first trip's before the FFT
@@ -336,10 +351,13 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   //  5b the nxt chain from peak 0 lists the interval starts (tens to a few hundred hops): pointer jumping, ~log2 rounds
   //  5c each interval is summed by one thread in index order (the reference's summation order) and kept if its volume
   //     reaches min_volume; kept intervals are compacted in order with a block scan
-  // pointer jumping needs two ints per peak beside the scan area (all inside the list region, which is idle until 5c)
+  // pointer jumping needs two ints per peak: beside the scan area inside the list region, which is idle until 5c — or, when the lists live in
+  // the FFT buffer, the unused .x half of the peak's own slot (8 bytes: the pointer and the mark)
   const int area_ints = max(8 * cap, T + 32);
   int *jump = scan + T + 32, *mark = jump + K;
-  const bool par = K > 0 && K <= 4 * T && T + 32 + 2 * K <= area_ints;
+  const bool par = K > 0 && K <= 4 * T && (lists_in_z || T + 32 + 2 * K <= area_ints);
+  auto JP = [&](int i) -> int & { return lists_in_z ? reinterpret_cast<int *>(&Z(i).x)[0] : jump[i]; };
+  auto MK = [&](int i) -> int & { return lists_in_z ? reinterpret_cast<int *>(&Z(i).x)[1] : mark[i]; };
   for (int i = tid; i < K; i += T) {
     const double pi0 = Z(i).y;
     int lo = i + 1, hi = K;
@@ -347,7 +365,7 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
       int mid = (lo + hi) >> 1;
       if (Z(mid).y - pi0 > p.nearby) hi = mid; else lo = mid + 1;
     }
-    if (par) { jump[i] = lo; mark[i] = (i == 0) ? 1 : 0; } else Z(i).x = (double)lo;
+    if (par) { JP(i) = lo; MK(i) = (i == 0) ? 1 : 0; } else Z(i).x = (double)lo;
   }
   __syncthreads();
   clk.mark(5);
@@ -361,24 +379,24 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
       for (int q = 0; q < 4; ++q) {
         const int i = tid + T * q;
         if (i < K) {
-          const int j = jump[i];
-          if (j < K) { if (mark[i]) mark[j] = 1; jn[q] = jump[j]; } else jn[q] = K;
+          const int j = JP(i);
+          if (j < K) { if (MK(i)) MK(j) = 1; jn[q] = JP(j); } else jn[q] = K;
         }
       }
       __syncthreads();
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { const int i = tid + T * q; if (i < K) jump[i] = jn[q]; }
+      for (int q = 0; q < 4; ++q) { const int i = tid + T * q; if (i < K) JP(i) = jn[q]; }
       __syncthreads();
-      if (jump[0] >= K) break; // the same LDS word for every thread: uniform
+      if (JP(0) >= K) break; // the same LDS word for every thread: uniform
     }
     // the marked peaks, in index order, are the interval starts
     const int c = (K + T - 1) / T;
     const int a0 = min(K, tid * c), a1 = min(K, a0 + c);
     int cntm = 0;
-    for (int i = a0; i < a1; ++i) cntm += mark[i];
+    for (int i = a0; i < a1; ++i) cntm += MK(i);
     block_exclusive_scan<T>(scan, cntm, tid);
     int posm = scan[tid];
-    for (int i = a0; i < a1; ++i) if (mark[i]) Z(Mh + posm++).x = (double)i;
+    for (int i = a0; i < a1; ++i) if (MK(i)) Z(Mh + posm++).x = (double)i;
     if (tid == 0) Z(Mh + scan[T]).x = (double)K; // R <= K <= Mh - 1, so slot Mh + R exists; scan[T] = R stays for 5c
   } else if (tid == 0) {
     int R = 0;
@@ -404,11 +422,30 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   }
   int pos = scan[tid];
   const int Rk = scan[T];
-  __syncthreads(); // scan aliases listA: everyone has its offset before the list is written
-  for (int r = r0; r < r1; ++r) {
-    double sv, spv;
-    interval(r, sv, spv);
-    if (!(sv < p.min_volume)) { if (pos < cap) listA[pos] = make_double2(spv / sv, sv); ++pos; }
+  if (lists_in_z) { // the list overwrites what `interval` reads: the thread's items (chunkR <= 4) wait in registers for everybody's last read
+    double2 item[4];
+    unsigned have = 0; // (static indices only: a dynamically indexed private array would live in scratch memory)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = r0 + j;
+      item[j] = make_double2(0.0, 0.0);
+      if (r < r1) {
+        double sv, spv;
+        interval(r, sv, spv);
+        if (!(sv < p.min_volume)) { item[j] = make_double2(spv / sv, sv); have |= 1u << j; }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (have & (1u << j)) { if (pos < cap) listA[pos] = item[j]; ++pos; }
+  } else {
+    __syncthreads(); // scan aliases listA: everyone has its offset before the list is written
+    for (int r = r0; r < r1; ++r) {
+      double sv, spv;
+      interval(r, sv, spv);
+      if (!(sv < p.min_volume)) { if (pos < cap) listA[pos] = make_double2(spv / sv, sv); ++pos; }
+    }
   }
   __syncthreads();
   clk.mark(7);
@@ -420,10 +457,11 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   // The ISO-226 pitches [29 doubles] and, behind them as floats, the 60 phon row [29]: the loudness keys' binary search (step 8) stays
   // out of global memory.  They sit in the idle FFT buffer behind the scan area (from M = 512 up; smaller frames have LDS to spare and
   // keep them behind the lists) — 360 bytes that would otherwise push an 8192-point frame over half a CU's LDS.
-  double *lds_loud_pitches = M >= 512 ? reinterpret_cast<double *>(z + 384) : reinterpret_cast<double *>(listB + cap);
+  double *lds_loud_pitches = lists_in_z ? reinterpret_cast<double *>(aux + 16 + (T + 32)) : (M >= 512 ? reinterpret_cast<double *>(z + 384) : reinterpret_cast<double *>(listB + cap));
   float *lds_loud_elv = reinterpret_cast<float *>(lds_loud_pitches + 29);
   if (tid < 29) { lds_loud_pitches[tid] = b.loud_pitches[tid]; lds_loud_elv[tid] = b.loud_elv[tid]; } // read after step 7's barriers
-  int *pub = reinterpret_cast<int *>(z); // [0] = A, [1] = which list holds the result, [2] = Rn, [3] = input list, [4] = err, [5] = merge fallback, [6] = kept   (z is free now)
+  // [0] = A, [1] = which list holds the result, [2] = Rn, [3] = input list, [4] = err, [5] = merge fallback, [6] = kept   (z is free now; with the lists in it: the small area)
+  int *pub = lists_in_z ? aux : reinterpret_cast<int *>(z);
   if (tid == 0) {
     int err = Rk > cap ? 1 : 0;
     int Rn = min(Rk, cap);
@@ -458,7 +496,7 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   // index order.  That equals the sequential rule whenever pitches do not descend and neighbours closer than 1e-4 are equal (autotuned
   // pitches are table values; untuned neighbours are > nearby apart); anything else falls back to the one-lane loop.
   {
-    int *mscan = reinterpret_cast<int *>(z) + 16; // block scan area in the idle FFT buffer (the lists are live here)
+    int *mscan = lists_in_z ? aux + 16 : reinterpret_cast<int *>(z) + 16; // block scan area: the idle FFT buffer (the lists are live here), or the small area
     const int Rn = pub[2];
     double2 *cur = pub[3] ? listB : listA, *oth = pub[3] ? listA : listB;
     const bool parm = Rn <= 4 * T, wave_local = Rn <= 64;
@@ -631,6 +669,7 @@ int ra_analysis_threads(const RaParams &p) {
 
 size_t ra_analysis_lds_bytes(const RaParams &p) {
   size_t m = (size_t)ra_zsize(p.M);
+  if (ra_lists_in_fft_buffer(p.M, ra_list_capacity(p), ra_analysis_threads(p))) return m * sizeof(double2) + (size_t)ra_aux_ints(ra_analysis_threads(p)) * sizeof(int);
   size_t lists = 2 * (size_t)ra_list_capacity(p) * sizeof(double2);
   size_t scan = ((size_t)ra_analysis_threads(p) + 32) * sizeof(int);
   size_t tables = p.M >= 512 ? 0 : 29 * (sizeof(double) + sizeof(float)) + 12; // the loudness tables move into the FFT buffer from M = 512 up
