@@ -101,6 +101,55 @@ def measured_counters(S, n, N, H, P):
     return None, why
 
 
+def workload_evidence(name, streams, frames, bytes_per_frame=ALGO_BYTES_PER_FRAME):
+    """The committed rocprofv3 evidence of one `other_configs` workload (profiles/r*/<name>/counters.json, scripts/collect_profiles.sh workloads):
+    per kernel the average launch duration, launches per step, VALU issue fraction and HBM bytes against the algorithmic bytes, and the
+    roofline block of the workload's dominant kernel (largest time per step).  Only a profile of this build (csrc_sha256) and shape counts."""
+    import glob
+    here = csrc_sha256()
+    why = f"no profiles/r*/{name}/counters.json"
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name, "counters.json")), reverse=True):
+        try:
+            doc = json.load(open(path))
+        except Exception:
+            continue
+        rel = os.path.relpath(path, ROOT)
+        if doc.get("csrc_sha256") != here:
+            why = f"{rel} was collected on another build (csrc_sha256 {doc.get('csrc_sha256')} != {here})"
+            continue
+        w = doc["workload"]
+        if (w["streams"], w["frames_per_stream_per_step"]) != (streams, frames):
+            why = f"{rel} is for another workload size"
+            continue
+        algo_step = bytes_per_frame * streams * frames
+        kern = {}
+        for k, c in doc["kernels"].items():
+            if "total_ms_per_step" not in c:
+                continue
+            e = {"launches_per_step": c["launches_per_step"], "ms_per_step": c["total_ms_per_step"], "avg_launch_ms": c["avg_launch_ms"]}
+            if "SQ_INSTS_VALU" in c:
+                e["valu_insts_per_step"] = c["SQ_INSTS_VALU"]
+                e["issue_frac"] = c["SQ_INSTS_VALU"] / (c["total_ms_per_step"] * 1e-3) / 1e9 / VALU_PEAK_GINST
+            if "FETCH_SIZE_KB" in c and "WRITE_SIZE_KB" in c:
+                e["hbm_bytes_per_step"] = (2.0 * c["FETCH_SIZE_KB"] + c["WRITE_SIZE_KB"]) * 1024.0
+                e["hbm_over_algorithmic"] = e["hbm_bytes_per_step"] / algo_step
+            if "SQ_WAVE_CYCLES" in c and "SQ_BUSY_CYCLES" in c and c["SQ_BUSY_CYCLES"] > 0:
+                e["lds_conflict_frac"] = (c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]) if c.get("SQ_LDS_IDX_ACTIVE") else 0.0
+            kern[k] = e
+        if not kern:
+            continue
+        dom = max(kern, key=lambda k: kern[k]["ms_per_step"])
+        d = kern[dom]
+        algo_launch = algo_step / d["launches_per_step"]
+        achieved = algo_launch / (d["avg_launch_ms"] * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": algo_launch, "traffic": d.get("hbm_bytes_per_step", 0.0) / d["launches_per_step"] if "hbm_bytes_per_step" in d else None,
+                "kernel_ms_per_launch": d["avg_launch_ms"], "issue_frac": d.get("issue_frac"),
+                "note": "fp64-VALU issue bound, not HBM bound: issue_frac = SQ_INSTS_VALU / kernel time / 614 G wave-instructions per second"}
+        return {"from": rel, "roofline": roof, "kernels": kern}
+    return {"from": None, "why": why}
+
+
 def synth_inputs_torch(n_streams, n_frames, sr, seed, device):
     """Seeded synthetic streams of the SURVEY.md §8(d) recipe, generated on the GPU (float32, peak 0.5)."""
     import torch
@@ -314,7 +363,7 @@ def time_config(api, torch, dev, name, cfg_kw, S, seconds, steps, carrier=None):
     """An `other_configs` entry: full-size timing of another BASELINE config (same issue mode and clock as the headline)."""
     n = int(round(seconds * SR))
     warm = 2
-    r = Runner(api, torch, dev, 0, cfg_kw, S, n, 4321, carrier=carrier, total_steps=warm + steps + 3)
+    r = Runner(api, torch, dev, 0, cfg_kw, S, n, 4321, carrier=carrier, total_steps=warm + steps + 7)
     for _ in range(warm):
         r.step()
     r.finish()
@@ -329,7 +378,7 @@ def time_config(api, torch, dev, name, cfg_kw, S, seconds, steps, carrier=None):
     r.ctx.synchronize()
     over, launches = r.kernel_split(2)
     r.ctx.set_pipeline_serial(True)
-    alone, _ = r.kernel_split(1)
+    alone, _ = r.kernel_split(3)   # (three steps: a single serialised step is a noisy sample of the two chain kernels)
     r.ctx.set_pipeline_serial(False)
     st = r.ctx.stats()
     res = {"config": name, "streams": S, "seconds_per_step": seconds, "steps": steps, "ms_per_step": dt * 1e3, "frames_per_s": S * n / dt,
@@ -448,7 +497,7 @@ def main():
         lps = {k: launches[k] / calls for k in STAGES}
         # every kernel with the chip to itself: one more step, its stages serialised on one stream (outside the timed region)
         ctx.set_pipeline_serial(True)
-        alone_ms, _ = run.kernel_split(1)
+        alone_ms, _ = run.kernel_split(3)
         ctx.set_pipeline_serial(False)
         mono = head_kw["stereo_spread"] == 0.0
         KNAME = {"analysis": "ra_analysis_kernel", "track": "ra_track_kernel", "vocoder": "ra_voc_*_kernel", "propagate": "ra_synth_propagate_kernel",
@@ -548,26 +597,26 @@ def main():
                    vocoder_max_freq=20000.0, vocoder_modulator_window_size_seconds=0.10, vocoder_stride_seconds=0.005)
         others = []
         try:
-            ns = time_config(api, torch, dev, "north_star operating point: 1000 concurrent 48 kHz mono streams, 4096-pt window, 75 % overlap, 64 partials, on one MI355X "
-                             "(= one rank of configs[4])", dict(parity, window_size=N, stride=H, n_channels=P), 1000, 10.0, 3)
-            ns["target"] = ">= 10 x real time for each of the 1000 streams (BASELINE.json north_star)"
-            others.append(ns)
-            others.append(time_config(api, torch, dev, "configs[1] with stereo_spread = 1 (the reference default): 256 streams, N 4096, H 1024, P 64",
-                                      dict(parity, window_size=N, stride=H, n_channels=P, stereo_spread=1.0), 256, 10.0, 3))
-            others.append(time_config(api, torch, dev, "configs[2] FFT vocoder: 256 streams, 32 bands, S = 241, modulator FFT 8192, carrier FFT 512, carrier from a file",
-                                      voc, 256, 10.0, 3, carrier="wav"))
-            others.append(time_config(api, torch, dev, "configs[2] band-pass bank (vocoder_kind 1): 256 streams, 32 bands, carrier from the carrier synth (sine + saw voices, 16 channels)",
-                                      dict(voc, vocoder_kind=1, carrier_n_channels=16, vocoder_carrier_square_volume=0.0, vocoder_carrier_sine_volume=0.7,
-                                           vocoder_carrier_saw_volume=0.3), 256, 10.0, 3, carrier="synth"))
-            others.append(time_config(api, torch, dev, "configs[3]: 1000 stereo = 2000 mono streams, N = 8192, H = 2048, P = 128, autotune major / C",
-                                      dict(parity, window_size=8192, stride=2048, n_channels=128, use_autotune=1, autotune_type=0, autotune_scale_mode=0,
-                                           autotune_root_note=0), 2000, 10.0, 2))
-            for which in ("sweep", "birds", "robots"):
-                others.append(time_voice(api, torch, dev, which, 256, 10.0, 3))
+            wl = workloads(N, H, P)
+            for name, steps in (("north_star", 3), ("stereo", 3), ("voc_fft", 3), ("voc_bank", 4), ("configs3", 2)):
+                desc, kw, S2, carrier = wl[name]
+                o = time_config(api, torch, dev, desc, kw, S2, 10.0, steps, carrier=carrier)
+                o["workload"] = name
+                if name == "north_star":
+                    o["target"] = ">= 10 x real time for each of the 1000 streams (BASELINE.json north_star)"
+                others.append(o)
+            for name in ("voice_sweep", "voice_birds", "voice_robots"):
+                o = time_voice(api, torch, dev, wl[name][0], wl[name][1], 10.0, 4)
+                o["workload"] = name
+                others.append(o)
             if shim_result is not None:
                 others.append(shim_result)
         except Exception as e:  # a failure here must not cost the headline line
             others.append({"error": repr(e)})
+        # every entry's numbers with their committed evidence: rocprofv3 stats and counters of the same workload on the same build
+        for o in others:
+            if "workload" in o:
+                o["profile"] = workload_evidence(o["workload"], o["streams"], int(round(o["seconds_per_step"] * SR)), 8.0 if o["workload"].startswith("voice_") else ALGO_BYTES_PER_FRAME)
         result["other_configs"] = others
 
     if rank == 0:

@@ -97,8 +97,10 @@ struct ra_context {
   std::vector<std::deque<RaCarEv>> car_pending;
   std::vector<CarNoteIds> car_noteids;
   std::vector<int64_t> car_last_sample;
-  std::vector<RaCarEv> car_upload[2];   // host images of the blocks' event lists (kept until the set is reused)
-  std::vector<int32_t> car_upload_begin[2];
+  // host images of the blocks' event lists, in pinned memory: per scratch set one buffer [events][n_streams + 1 offsets] and an event that says
+  // when its copies have drained (the host waits for it before refilling the set two blocks later; pageable vectors made the "async" copies
+  // host-synchronous on the vocoder queue)
+  struct CarStage { char *h = nullptr; size_t cap = 0; size_t n_ev = 0; hipEvent_t done = nullptr; bool used = false; } car_stage[2];
   int64_t car_total_segs = 0;           // slots of the block's segment table (stage_carrier_events)
   bool pipeline_serial = false;         // measurement aid (ra_set_pipeline_serial): same chunks and launches, all on the caller's stream
   bool last_car_gen = false;            // the last block's carrier came from the synth (ra_get_carrier)
@@ -743,16 +745,26 @@ int stage_carrier_events(ra_context *c, int64_t t0, int64_t n) {
     if (!r) r = dev_alloc(c, &b.car_seg_i, (size_t)b.car_seg_cap * SI_COUNT * p.car_CH, false);
     if (r) { b.car_seg_cap = 0; return r; }
   }
-  std::vector<RaCarEv> &flat = c->car_upload[c->parity];
-  std::vector<int32_t> &begin = c->car_upload_begin[c->parity];
-  flat.clear();
-  begin.assign(S + 1, 0);
-  for (int s = 0; s < S; ++s) {
-    begin[s] = (int32_t)flat.size();
-    auto &q = c->car_pending[s];
-    while (!q.empty() && q.front().sample < t0 + n) { flat.push_back(q.front()); q.pop_front(); }
+  ra_context::CarStage &cs = c->car_stage[c->parity];
+  if (cs.used) HIP_TRY(hipEventSynchronize(cs.done)); // the copies of the block that used this set two blocks ago
+  const size_t need = total * sizeof(RaCarEv) + (size_t)(S + 1) * sizeof(int32_t);
+  if (need > cs.cap) {
+    if (cs.h) (void)hipHostFree(cs.h);
+    cs.h = nullptr; cs.cap = 0;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&cs.h), need + need / 2 + 256, hipHostMallocDefault));
+    cs.cap = need + need / 2 + 256;
   }
-  begin[S] = (int32_t)flat.size();
+  if (!cs.done) HIP_TRY(hipEventCreateWithFlags(&cs.done, hipEventDisableTiming));
+  RaCarEv *flat = reinterpret_cast<RaCarEv *>(cs.h);
+  int32_t *begin = reinterpret_cast<int32_t *>(cs.h + total * sizeof(RaCarEv));
+  size_t at = 0;
+  for (int s = 0; s < S; ++s) {
+    begin[s] = (int32_t)at;
+    auto &q = c->car_pending[s];
+    while (!q.empty() && q.front().sample < t0 + n) { flat[at++] = q.front(); q.pop_front(); }
+  }
+  begin[S] = (int32_t)at;
+  cs.n_ev = at;
   return RA_OK;
 }
 
@@ -798,11 +810,14 @@ int process_block_impl(ra_context *c, const float *d_voice, const float *d_carri
   const bool limit = p.post_limit && apply_post && d_out_final;
   float *d_out = limit ? nullptr : d_out_final;
   double *d_out_d = limit ? b.post_d : d_out_d_caller;
+  hipError_t car_copy_err = hipSuccess;
   auto launch_carrier = [&](hipStream_t st) { // K6: the carrier synth (when it supplies the carrier)
-    const std::vector<RaCarEv> &flat = c->car_upload[c->parity];
-    const std::vector<int32_t> &begin = c->car_upload_begin[c->parity];
-    if (!flat.empty()) (void)hipMemcpyAsync(b.car_ev, flat.data(), flat.size() * sizeof(RaCarEv), hipMemcpyHostToDevice, st);
-    (void)hipMemcpyAsync(b.car_ev_begin, begin.data(), begin.size() * sizeof(int32_t), hipMemcpyHostToDevice, st);
+    ra_context::CarStage &cs = c->car_stage[c->parity];
+    if (cs.n_ev) car_copy_err = hipMemcpyAsync(b.car_ev, cs.h, cs.n_ev * sizeof(RaCarEv), hipMemcpyHostToDevice, st);
+    if (car_copy_err == hipSuccess)
+      car_copy_err = hipMemcpyAsync(b.car_ev_begin, cs.h + cs.n_ev * sizeof(RaCarEv), (size_t)(p.n_streams + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st);
+    if (car_copy_err == hipSuccess) car_copy_err = hipEventRecord(cs.done, st);
+    cs.used = true;
     ra_launch_carrier_synth(p, b, t0, n, c->car_total_segs, st);
   };
   auto launch_vocoder = [&](hipStream_t st) { // K6 then K4 / K7 on one queue
@@ -989,6 +1004,7 @@ int process_block_impl(ra_context *c, const float *d_voice, const float *d_carri
   }
   // (the shim's render-ahead blocks roll the window history later, when the block's input is complete: shim_roll)
   if (n_chunks == 1 && !defer_history) RA_TRY(timed_launch(c, ST_HISTORY, user, [&] { ra_launch_roll_history(p, b, d_voice, n, user); }));
+  if (car_copy_err != hipSuccess) return fail(RA_EHIP, std::string("carrier event upload: ") + hipGetErrorString(car_copy_err));
   HIP_TRY(hipGetLastError());
   if (c->profiling) ++c->kernel_calls;
   c->last_f_lo = f_lo; c->last_nfb = nfb; c->last_n = n; c->last_t0 = t0;
@@ -1134,6 +1150,7 @@ void ra_destroy(ra_context *c) {
   if (c->shim.h_in) (void)hipHostFree(c->shim.h_in);
   if (c->shim.h_out) (void)hipHostFree(c->shim.h_out);
   if (c->shim.h_flags) (void)hipHostFree(c->shim.h_flags);
+  for (auto &cs : c->car_stage) { if (cs.h) (void)hipHostFree(cs.h); if (cs.done) (void)hipEventDestroy(cs.done); }
   for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->pipe_ready) {

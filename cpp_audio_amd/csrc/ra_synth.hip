@@ -284,11 +284,10 @@ __device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, dou
 template <bool MONO, bool PACKED>
 __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &k, const RaParams &p, int s, int l, int64_t t, int64_t seg_end,
                                          int64_t t0, int64_t n, const double *__restrict__ mix, float *__restrict__ out, double *__restrict__ out_d,
-                                         int32_t *b_error_flags, float *__restrict__ fb_mono, RaPhaseClock &clk, const int Ppad, const int64_t dB, const int split) {
+                                         int32_t *b_error_flags, float *__restrict__ fb_mono, RaPhaseClock &clk, const int Ppad, const int64_t dB) {
   constexpr bool packed = PACKED;
-  // packed (Ppad = 64, one wave): lanes 0 .. split - 1 carry the sounding channels of the hop that starts at t, the lanes from `split` on those
-  // of the hop that starts at t + dB and has the same length; every summing lane keeps one sum per hop (rows below / from `split`), and the
-  // lanes that write a frame write it for both hops.
+  // packed (Ppad = 64, one wave): lanes 0..31 carry the sounding channels of the hop that starts at t, lanes 32..63 those of the hop that
+  // starts at t + dB and has the same length; the channel sums then stop at 32 lanes and each half writes its own frames.
   const double inv_dur = 1.0 / k.dur;
   const double lim = k.dur - 0.5; // a glide step that finds cur > lim clamps (InterpolatedFreq::step, audioelement.h:2768-2770)
   bool stepped0 = (c.flags & FL_STEPPED0) != 0; // this hop's first step was taken by the propagate kernel: sample 0 only reads the state
@@ -463,63 +462,39 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
     else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
     if (l < 64 && !(RA_ABL & 2)) { // NOUT outputs x NPART channel groups
       double acc = 0.0, accR = 0.0; // mono: the sum; stereo: left and right
-      double acc2 = 0.0, accR2 = 0.0; // packed: the second hop's sums
       if (fr < m) {
         const double *q = col;
         constexpr int NJ = 64 / NPART; // channels of a group per 64-channel block
         const double2 *g = gains + part * (Ppad / NPART);
-        if (!packed) {
-          for (int blk = 0; blk < (Ppad >> 6); ++blk, q += NJ * ROW, g += NJ) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-              if (MONO) acc += q[j * ROW];
-              else { const double v = q[j * ROW]; const double2 gg = g[j]; acc += gg.x * v; accR += gg.y * v; }
-            }
-          }
-        } else { // rows of this lane's group below `split` belong to the first hop, the others to the second
-          const int js = min(max(split - part * NJ, 0), NJ);
+        for (int blk = 0; blk < (Ppad >> 6); ++blk, q += NJ * ROW, g += NJ) {
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
-            const double v = q[j * ROW];
-            const double va = (j < js) ? v : 0.0, vb = (j < js) ? 0.0 : v;
-            if (MONO) { acc += va; acc2 += vb; }
-            else { const double2 gg = g[j]; acc += gg.x * va; accR += gg.y * va; acc2 += gg.x * vb; accR2 += gg.y * vb; }
+            if (MONO) acc += q[j * ROW];
+            else { const double v = q[j * ROW]; const double2 gg = g[j]; acc += gg.x * v; accR += gg.y * v; }
           }
         }
       }
-      acc += lane_xor32_low(acc);
+      if (!packed) acc += lane_xor32_low(acc);
       if (NPART >= 4) acc += lane_xor16_even(acc);
       if (NPART >= 8) acc += lane_ror8(acc);
       if (!MONO) {
-        accR += lane_xor32_low(accR);
+        if (!packed) accR += lane_xor32_low(accR);
         if (NPART >= 4) accR += lane_xor16_even(accR);
         if (NPART >= 8) accR += lane_ror8(accR);
       }
-      if (packed) {
-        acc2 += lane_xor32_low(acc2);
-        if (NPART >= 4) acc2 += lane_xor16_even(acc2);
-        if (NPART >= 8) acc2 += lane_ror8(acc2);
-        if (!MONO) {
-          accR2 += lane_xor32_low(accR2);
-          if (NPART >= 4) accR2 += lane_xor16_even(accR2);
-          if (NPART >= 8) accR2 += lane_ror8(accR2);
+      const int lo_lane = packed ? (l & 31) : l; // packed: lanes 32.. hold the second hop's frames (even rows of 16: where the swaps are valid)
+      const int64_t t_mine = (packed && l >= 32) ? t + dB : t;
+      if (lo_lane < NOUT && fr < m) {
+        const int64_t rel = (t_mine - t0) + fr;
+        double oL = MONO ? gLm * acc : acc, oR = MONO ? gRm * acc : accR;
+        if (mix) { oL += mix[rel]; oR += mix[rel]; }
+        if (out) { // one 8-byte store per frame when the caller's buffer allows it (two 4-byte stores make partial-line writes)
+          float *op = out + ((size_t)s * n + rel) * 2;
+          if ((reinterpret_cast<uintptr_t>(out) & 7) == 0) *reinterpret_cast<float2 *>(op) = make_float2((float)oL, (float)oR);
+          else { op[0] = (float)oL; op[1] = (float)oR; }
         }
-      }
-      if (l < NOUT && fr < m) {
-        auto emit = [&](int64_t t_hop, double sL, double sR) {
-          const int64_t rel = (t_hop - t0) + fr;
-          double oL = MONO ? gLm * sL : sL, oR = MONO ? gRm * sL : sR;
-          if (mix) { oL += mix[rel]; oR += mix[rel]; }
-          if (out) { // one 8-byte store per frame when the caller's buffer allows it (two 4-byte stores make partial-line writes)
-            float *op = out + ((size_t)s * n + rel) * 2;
-            if ((reinterpret_cast<uintptr_t>(out) & 7) == 0) *reinterpret_cast<float2 *>(op) = make_float2((float)oL, (float)oR);
-            else { op[0] = (float)oL; op[1] = (float)oR; }
-          }
-          if (out_d) { out_d[((size_t)s * n + rel) * 2] = oL; out_d[((size_t)s * n + rel) * 2 + 1] = oR; }
-          if (fb_mono) fb_mono[rel] = (float)(oL + oR); // what the post processor publishes to the analysis (lib.cpp:1262-1272, pubsub.cpp:92)
-        };
-        emit(t, acc, accR);
-        if (packed) emit(t + dB, acc2, accR2);
+        if (out_d) { out_d[((size_t)s * n + rel) * 2] = oL; out_d[((size_t)s * n + rel) * 2 + 1] = oR; }
+        if (fb_mono) fb_mono[rel] = (float)(oL + oR); // what the post processor publishes to the analysis (lib.cpp:1262-1272, pubsub.cpp:92)
       }
     }
     if (Ppad > 64) __syncthreads();
@@ -700,6 +675,8 @@ __device__ inline void render_diag_segment(const RaParams &p, const RaBuffers &b
 // those of configs[3] (128 channels) have at most 32 sounding channels.  When both hops of the pair do and have the same length, their
 // sounding channels are compacted into the two halves of ONE wave (the workgroup's other waves leave) and the pair costs what one hop
 // did; otherwise the hops are rendered one after the other by the whole workgroup as before.
+// (r03: packing by the SUM of the two counts — an uneven split of the wave, every summing lane keeping one masked sum per hop — reaches 52 %
+// instead of 48 % of configs[1]'s hops and costs every packed tile its selects: 13.6 against 12.9 ms per step on one box; not kept.)
 template <bool MONO>
 __device__ inline void render_pair(const RaParams &p, const RaBuffers &b, const RaSpan &sp, float *__restrict__ out, double *__restrict__ out_d) {
   // blockDim.y > 1 (RA_RENDER_GROUP, single-wave streams only): wave y of the workgroup renders its own pair, nothing is shared between the
@@ -726,10 +703,10 @@ __device__ inline void render_pair(const RaParams &p, const RaBuffers &b, const 
 
   // sounding channels of both hops: every wave looks at all of them (Ppad / 64 state words per lane and hop), so the decision needs no barrier
   bool pack = end0 > beg0 && end1 > beg1 && (end0 - beg0) == (end1 - beg1) && p.render_pack && !(RA_ABL & 8);
-  int src = -1; // packed: the channel this lane renders (lanes 0 .. cnt[0] - 1: first hop, then the second hop's), -1: none
-  int cnt[2] = {0, 0};
+  int src = -1; // packed: the channel this lane renders (lanes 0..31: first hop, 32..63: second), -1: none
   if (pack) {
     const int lw = l & 63;
+    int cnt[2] = {0, 0};
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int32_t *st = b.seg_si + (seg0 + h) * SI_COUNT * Ppad + SI_ENV_STATE * Ppad;
@@ -738,18 +715,17 @@ __device__ inline void render_pair(const RaParams &p, const RaBuffers &b, const 
         const bool act = stv != ENV_SOON && stv != ENV_DONE2; // rt_active
         const unsigned long long m = __ballot(act);
         const int rank = cnt[h] + __popcll(m & ((1ull << lw) - 1ull));
-        // the lane that will render this channel: the first hop's channels fill the wave from lane 0, the second hop's follow them; the
-        // channel index is handed over through the wave's own tile
-        const int dest = (h == 0) ? rank : cnt[0] + rank;
-        if (act && dest < 64 && l < 64) reinterpret_cast<int *>(tile)[dest] = blk * 64 + lw;
+        // the lane that will render this channel is (h * 32 + rank): hand the channel index over through the wave's own tile
+        if (act && rank < 32 && l < 64) reinterpret_cast<int *>(tile)[h * 32 + rank] = blk * 64 + lw;
         cnt[h] += __popcll(m);
       }
     }
-    pack = cnt[0] + cnt[1] <= 64; // (r02 packed two hops of at most 32 channels each: 48 % of configs[1]'s hops; the sum reaches the pairs of an uneven split)
+    pack = cnt[0] <= 32 && cnt[1] <= 32;
     if (pack) {
       if (l >= 64) return; // the other waves of the workgroup have nothing to do (no barrier follows on this path)
+      const int h = l >> 5;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (l < cnt[0] + cnt[1]) src = reinterpret_cast<int *>(tile)[l]; // (one wave: its LDS operations execute in order; the fence pins the compiler's order)
+      if ((l & 31) < cnt[h]) src = reinterpret_cast<int *>(tile)[l]; // (one wave: its LDS operations execute in order; the fence pins the compiler's order)
     }
   }
   if (pack && second) return; // rendered by the workgroup of the pair's first hop
@@ -758,12 +734,12 @@ __device__ inline void render_pair(const RaParams &p, const RaBuffers &b, const 
   if (pack) {
     chan_init(c);
     if (src >= 0) {
-      const size_t seg = seg0 + (l >= cnt[0] ? 1 : 0);
+      const size_t seg = seg0 + (l >> 5);
       load_chan(c, b.seg_sd + seg * SD_COUNT * Ppad, b.seg_si + seg * SI_COUNT * Ppad, Ppad, src);
       chan_from_phase(c);
     }
     clk.mark(20);
-    render_range_fast<MONO, true>(c, tile, k, p, s, l, beg0, end0, sp.t0, sp.n, mix, out, out_d, b.error_flags, fb_mono, clk, 64, beg1 - beg0, cnt[0]);
+    render_range_fast<MONO, true>(c, tile, k, p, s, l, beg0, end0, sp.t0, sp.n, mix, out, out_d, b.error_flags, fb_mono, clk, 64, beg1 - beg0);
   } else {
     const int64_t bh = second ? beg1 : beg0, eh = second ? end1 : end0;
     if (eh <= bh) return;
@@ -774,7 +750,7 @@ __device__ inline void render_pair(const RaParams &p, const RaBuffers &b, const 
       else { chan_init(c); c.state = stv; }
     }
     clk.mark(20);
-    render_range_fast<MONO, false>(c, tile, k, p, s, l, bh, eh, sp.t0, sp.n, mix, out, out_d, b.error_flags, fb_mono, clk, Ppad, 0, Ppad);
+    render_range_fast<MONO, false>(c, tile, k, p, s, l, bh, eh, sp.t0, sp.n, mix, out, out_d, b.error_flags, fb_mono, clk, Ppad, 0);
   }
   if (clk.dst) { // workgroup lifetime: maximum and a histogram in steps of 200 k ticks
     const unsigned long long d = __builtin_readcyclecounter() - wg_t0;
