@@ -198,12 +198,25 @@ __device__ inline void regime_setup(Chan &c, const SynConst &k, double inv_dur, 
 #define RA_ABL 0
 #endif
 #ifndef RA_TILE_DEPTH
-#define RA_TILE_DEPTH 16 // samples per tile: 8 or 16 (the per-tile set-up and the channel sums are amortised over them)
+#define RA_TILE_DEPTH 32 // samples per tile: 8, 16 or 32 (the per-tile set-up, the span cutting and the channel sums are amortised over them)
+#endif
+#ifndef RA_TILE_FLOAT
+#define RA_TILE_FLOAT 1  // the LDS tile holds a channel's samples as floats (r03): a 32-sample tile then takes the LDS a 16-sample tile of doubles took
+#endif
+// A tile entry is one channel's contribution to one frame, |v| <= the channel's volume (a few 1e-2 on the BASELINE shapes); the sum over the
+// channels is formed in double and rounded to the float output.  Rounding the ENTRY to float first moves it by 6e-8 of itself — a few 1e-9
+// on the sum, below the 1e-8 the path has against the restatement anyway.  With 32-sample tiles of doubles the tile buffer halved the waves
+// per SIMD and the kernel got slower (r02); as floats the buffer keeps its size and the set-up of a span is paid half as often.
+#if RA_TILE_FLOAT
+using tile_t = float;
+#else
+using tile_t = double;
 #endif
 constexpr int TD = RA_TILE_DEPTH; // tile depth of the regime renderer
-static_assert(TD == 8 || TD == 16, "tile depth");
-constexpr int TROW_MONO = TD + 1; // the LDS tile is lane-major: [Ppad][TROW_MONO] doubles, one value per frame (odd row length: conflict-free both ways)
-constexpr int TSTEREO_EXTRA = 2;   // stereo: behind a workgroup's tile, the channels' two gains [Ppad] double2 (in doubles per channel)
+static_assert(TD == 8 || TD == 16 || TD == 32, "tile depth");
+constexpr int TROW_MONO = TD + 1; // the LDS tile is lane-major: [Ppad][TROW_MONO] entries, one value per frame (odd row length: conflict-free both ways)
+// bytes of one wave group's tile, and — stereo — of the channels' two gains [Ppad] double2 behind it
+__host__ __device__ inline size_t ra_tile_bytes(int Ppad, bool mono) { return (size_t)Ppad * TROW_MONO * sizeof(tile_t) + (mono ? 0 : (size_t)Ppad * sizeof(double2)); }
 
 // LEN steps (a whole tile, or half of one) of a lane whose wave has no transition inside them: straight-line code, no state machine.
 // GLIDE: some lane of the wave glides (the others run the same code with the identity rotation, alpha = 1, beta = 0);
@@ -219,11 +232,12 @@ constexpr int TSTEREO_EXTRA = 2;   // stereo: behind a workgroup's tile, the cha
 // applied as (1, tan) — two multiply-adds instead of four operations.  That turns by exactly the angle and stretches `mult` by 1 / cos,
 // i.e. by d^2 / 2 ~ 1e-10 .. 1e-8 per step: `mult` is renormalised at the end of the span like the phasor.
 template <int LEN, bool GLIDE, bool HI, bool KVAR, bool MONO>
-__device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, double cd0, double sd0, double tn, double al_da, double al_dda, double *mine,
+__device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, double cd0, double sd0, double tn, double al_da, double al_dda, tile_t *mine,
                                   int n) {
   const int len = LEN ? LEN : n;
   double cur = c.cur, mre = c.mre, mim = c.mim, cre = c.cre, cim = c.cim, y = c.y, value = c.value, alias = c.alias, f = c.inc;
   double kk = c.k, fin = c.finit, rr = 0.0, a_used = c.alias;
+  double tnr = tn; // the rotation of step j + 1 is that of step j times alpha (the time steps are a geometric sequence): one multiplication per step
   const double target = c.target;
   if (KVAR) rr = 1.0 / (1.0 + M_PI * c.finit);
   // w_i = (alias + i al_da) (value + (i + 1) dv), the product at step i; va holds w_{i-1} before step i
@@ -238,7 +252,7 @@ __device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, dou
       cur = fma(r.alpha, cur, r.beta);
       double mr, mi;
       if (FIRST) { mr = fma(mre, cd0, -(mim * sd0)); mi = fma(mre, sd0, mim * cd0); }
-      else { mr = fma(-tn, mim, mre); mi = fma(tn, mre, mim); }
+      else { mr = fma(-tnr, mim, mre); mi = fma(tnr, mre, mim); tnr *= r.alpha; }
       mre = mr; mim = mi;
       if (KVAR) { // BaseVolumeAdjusted::step, audioelement.h:1195-1216: k = a / (1 + a), a = pi min(max increment, |inc|); 1 / (1 + a) by Newton
         if (r.kvar && y != target) {
@@ -261,7 +275,7 @@ __device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, dou
     if (HI) d1 += d2;
     return y * (cim * va);
   };
-  auto put = [&](int i, double v) { mine[i] = v; }; // (stereo: the gains are applied in the channel sum)
+  auto put = [&](int i, double v) { mine[i] = (tile_t)v; }; // (stereo: the gains are applied in the channel sum)
   if (RA_ABL & 1) return;
   put(0, step(std::true_type{}));
   if (LEN) {
@@ -282,7 +296,7 @@ __device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, dou
 }
 
 template <bool MONO, bool PACKED>
-__device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &k, const RaParams &p, int s, int l, int64_t t, int64_t seg_end,
+__device__ inline void render_range_fast(Chan &c, tile_t *tile, const SynConst &k, const RaParams &p, int s, int l, int64_t t, int64_t seg_end,
                                          int64_t t0, int64_t n, const double *__restrict__ mix, float *__restrict__ out, double *__restrict__ out_d,
                                          int32_t *b_error_flags, float *__restrict__ fb_mono, RaPhaseClock &clk, const int Ppad, const int64_t dB) {
   constexpr bool packed = PACKED;
@@ -296,7 +310,7 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
   regime_setup(c, k, inv_dur, r);
   clk.mark(21);
   constexpr int ROW = TROW_MONO;
-  double *mine = tile + l * ROW;                                                // this lane's row
+  tile_t *mine = tile + l * ROW;                                                // this lane's row
   // stereo: every channel has its own two gains (StereoPanned, stereo.h:18-27); the lanes that sum a frame read them from LDS, so the tile
   // holds one value per frame and channel as in the mono kernel (half the LDS of a tile of gL v, gR v pairs: three waves per SIMD)
   double2 *gains = reinterpret_cast<double2 *>(tile + (size_t)Ppad * ROW);
@@ -305,7 +319,7 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
   // the 64 reducing lanes: output value o (frame fr of channel ch; entries of a row are laid out [ch][fr]) over one of NPART channel groups
   constexpr int NOUT = TD, NPART = 64 / NOUT;
   const int o = l & (NOUT - 1), fr = o & (TD - 1), part = (l & 63) / NOUT;
-  const double *col = tile + (part * (Ppad / NPART)) * ROW + o;
+  const tile_t *col = tile + (part * (Ppad / NPART)) * ROW + o;
   double gLm = 0.0, gRm = 0.0;
   if (MONO) { const double ang = (0.25 * M_PI) * (0.0 + 1.); gLm = cos(ang); gRm = sin(ang); } // stereo(0), stereo.h:18-27, as at note-on
 
@@ -352,7 +366,7 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
   auto clean_span = [&](auto len_tag, int off, int n_rt) -> bool {
     constexpr int LENC = decltype(len_tag)::value;
     const int LEN = LENC ? LENC : n_rt;
-    double *row = mine + off;
+    tile_t *row = mine + off;
     // a span is clean for a lane if no transition can fall inside it: then the loop needs no per-sample checks
     double step0 = 0.0;
     if (r.active && r.gliding) step0 = fma(r.alpha - 1.0, c.cur, r.beta); // cur increment of the span's first step
@@ -393,26 +407,21 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
         double cd0 = 1.0, sd0 = 0.0, tn = 0.0;
         if (r.gliding) {
           const double d0 = M_PI * (fma(r.slope, c.cur, r.base) - c.inc);
-          const double dA = (M_PI * r.slope) * step0 * (1.0 + 0.5 * (LEN - 2) * (r.alpha - 1.0));
+          const double dA = (M_PI * r.slope) * step0; // the second step's angle; every later one is alpha times its predecessor's (clean_tile)
           double d2 = d0 * d0;
           sd0 = d0 * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
           cd0 = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
           d2 = dA * dA;
-          tn = dA * fma(d2, fma(d2, 2.0 / 15.0, 1.0 / 3.0), 1.0); // tan: |dA| ~ 1e-5, the series' remainder ~ dA^7
+          tn = dA * fma(d2, 1.0 / 3.0, 1.0); // tan: |dA| ~ 1e-5 .. 1e-4 (the cubic term is kept for the first angle; it then shrinks or grows by alpha^3 per step: < 1e-13)
         }
         if (__any(r.active && r.kvar)) clk.tally<3>(); else if (__any(r.active && r.gliding && r.hi)) clk.tally<2>(); else clk.tally<1>();
         if (__any(r.active && r.kvar)) clean_tile<LENC, true, true, true, MONO>(c, r, k.max_filter_inc, cd0, sd0, tn, al_da, al_dda, row, LEN);
         else if (__any(r.active && r.gliding && r.hi)) clean_tile<LENC, true, true, false, MONO>(c, r, k.max_filter_inc, cd0, sd0, tn, al_da, al_dda, row, LEN);
         else clean_tile<LENC, true, false, false, MONO>(c, r, k.max_filter_inc, cd0, sd0, tn, 0.0, 0.0, row, LEN);
-        // over the m' = LEN - 1 later steps the even spread runs ahead of the exact (linearly growing) rotation by b (j+1)(m'-1-j)/2
-        // at step j, b = pi slope step0 (alpha - 1); the oscillator has integrated that: take the sum b (m'-1) m' (m'+1) / 12 back out
-        const double dl = (M_PI * r.slope) * step0 * (r.alpha - 1.0) * ((double)(LEN - 2) * (double)(LEN - 1) * (double)LEN * (1.0 / 12.0));
-        const double re = fma(c.cim, dl, c.cre), im = fma(-c.cre, dl, c.cim);
-        c.cre = re; c.cim = im;
       }
       r.pending += LEN; r.steps_left -= LEN;
     } else {
-      for (int i = 0; i < LEN; ++i) row[i] = 0.0;
+      for (int i = 0; i < LEN; ++i) row[i] = (tile_t)0;
     }
     clk.lap<0>();
     return true;
@@ -452,7 +461,7 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
         else v = checked_step();
       }
       stepped0 = false;
-      mine[pos] = v;
+      mine[pos] = (tile_t)v;
       ++pos;
       clk.lap<1>();
     }
@@ -463,14 +472,14 @@ __device__ inline void render_range_fast(Chan &c, double *tile, const SynConst &
     if (l < 64 && !(RA_ABL & 2)) { // NOUT outputs x NPART channel groups
       double acc = 0.0, accR = 0.0; // mono: the sum; stereo: left and right
       if (fr < m) {
-        const double *q = col;
+        const tile_t *q = col;
         constexpr int NJ = 64 / NPART; // channels of a group per 64-channel block
         const double2 *g = gains + part * (Ppad / NPART);
         for (int blk = 0; blk < (Ppad >> 6); ++blk, q += NJ * ROW, g += NJ) {
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
-            if (MONO) acc += q[j * ROW];
-            else { const double v = q[j * ROW]; const double2 gg = g[j]; acc += gg.x * v; accR += gg.y * v; }
+            if (MONO) acc += (double)q[j * ROW];
+            else { const double v = (double)q[j * ROW]; const double2 gg = g[j]; acc += gg.x * v; accR += gg.y * v; }
           }
         }
       }
@@ -698,7 +707,7 @@ __device__ inline void render_pair(const RaParams &p, const RaBuffers &b, const 
   const unsigned long long wg_t0 = clk.t;
   const SynConst k = syn_const(p, s);
   const double *mix = (p.voc_enabled && b.voc_mix) ? b.voc_mix + (size_t)s * sp.n : nullptr;
-  double *tile = reinterpret_cast<double *>(ra_smem_syn) + (size_t)wy * Ppad * (TROW_MONO + (MONO ? 0 : TSTEREO_EXTRA));
+  tile_t *tile = reinterpret_cast<tile_t *>(ra_smem_syn + (size_t)wy * ra_tile_bytes(Ppad, MONO));
   float *fb_mono = (b.fb_block && !p.post_limit) ? b.fb_block + (size_t)s * sp.n : nullptr; // with post "limit" the limiter publishes
 
   // sounding channels of both hops: every wave looks at all of them (Ppad / 64 state words per lane and hop), so the decision needs no barrier
@@ -794,7 +803,7 @@ void ra_launch_synth_render(const RaParams &p, const RaBuffers &b, const RaSpan 
   const int group_want = group_env > 0 ? group_env : 2;
   const unsigned group = (p.Ppad == 64) ? (unsigned)std::min(std::max(group_want, 1), RA_MAX_CHANNELS / 64) : 1u; // hops per workgroup
   const dim3 grid((unsigned)((sp.nfb + 1 + group - 1) / group), (unsigned)p.n_streams), block((unsigned)p.Ppad, group);
-  const size_t lds = (size_t)group * p.Ppad * (TROW_MONO + (p.stereo_spread == 0.f ? 0 : TSTEREO_EXTRA)) * sizeof(double); // the tiles (+ the gains)
+  const size_t lds = (size_t)group * ra_tile_bytes(p.Ppad, p.stereo_spread == 0.f); // the tiles (+ the gains)
   if (p.stereo_spread == 0.f) hipLaunchKernelGGL(ra_synth_render_mono_kernel, grid, block, lds, st, p, b, sp, d_out, d_out_d);
   else hipLaunchKernelGGL(ra_synth_render_kernel, grid, block, lds, st, p, b, sp, d_out, d_out_d);
 }
