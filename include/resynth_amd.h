@@ -221,14 +221,6 @@ int ra_process_device_async(ra_context *ctx, const float *d_voice, const float *
 int ra_join(ra_context *ctx);
 
 /*
- * The reference's block-compute boundary: ComputeFunc = bool(double* buffer, int nFrames)
- * (include/simple_audio_context.h:24-26), as registered by ImplCRTP::initialize (gen.crtp.h:258-264) and
- * Vocoder::initialize (vocoder.cpp:760-815).  ra_feed pushes the n input frames those computes will consume
- * (input_f, lib.cpp:1285-1291); ra_compute then ACCUMULATES (+=) nFrames (1..16) of stream `stream`
- * into the caller's interleaved double buffer [nFrames][2], exactly like the two registered computes together.
- * HOST pointers.  Returns 1 where the reference functor returns true, or a negative RA_E* code.
- */
-/*
  * Queues note events for the carrier synth (HOST pointer).  Per stream, samples must not decrease and must not lie before the frames
  * already processed; events are applied by the ra_process_* call whose block contains them.  Returns RA_OK, or RA_EINVAL at the first
  * bad event (earlier ones stay queued): unknown stream / type, a sample in the past, a note-off for a key with no pending note-on.
@@ -238,6 +230,22 @@ int ra_carrier_events(ra_context *ctx, const ra_carrier_event *h_events, int64_t
 /* debug / test tap: the carrier the vocoder was given during the LAST ra_process_* call, [n_frames] doubles of one stream (HOST pointer) */
 int ra_get_carrier(ra_context *ctx, int32_t stream, double *h_carrier, int64_t cap);
 
+/*
+ * The reference's block-compute boundary: ComputeFunc = bool(double* buffer, int nFrames)
+ * (include/simple_audio_context.h:24-26), as registered by ImplCRTP::initialize (gen.crtp.h:258-264) and
+ * Vocoder::initialize (vocoder.cpp:760-815).  ra_feed pushes the n input frames of stream `stream` those computes will consume
+ * (input_f, lib.cpp:1285-1291; h_carrier may be NULL: silence — or, on a context with a carrier synth, that synth's notes);
+ * ra_compute then ACCUMULATES (+=) nFrames (1..16) of stream `stream` into the caller's interleaved double buffer [nFrames][2],
+ * exactly like the two registered computes together (not post-processed: the post-processors run after every compute).
+ * One context serves the callables of all its streams: per tile every stream is fed before the first compute runs, as in
+ * SimpleAudioOutContext::step (:80-102); a stream that lags makes ra_compute fail with RA_EINVAL.
+ * A context without vocoder and without output feedback renders AHEAD: events apply where their analysis frame fires (:74-76), so the
+ * compute that reaches a fire sample renders the whole hop up to the next one for every stream in one launch sequence, and the
+ * following computes are served from a host ring (the hop's input is rolled into the window history once it has been fed).  With a
+ * vocoder or a feedback every tile is a block of its own.  post = limit together with an output feedback is refused here (the loop feeds
+ * back the limited signal, which only the caller of the computes has): use ra_process_*.
+ * HOST pointers.  Returns 1 where the reference functor returns true, or a negative RA_E* code.
+ */
 int ra_feed(ra_context *ctx, int32_t stream, const float *h_voice, const float *h_carrier, int32_t n_frames);
 int ra_compute(ra_context *ctx, int32_t stream, double *h_buffer, int32_t n_frames);
 
