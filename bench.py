@@ -600,7 +600,7 @@ def main():
         others = []
         try:
             wl = workloads(N, H, P)
-            for name, steps in (("north_star", 3), ("stereo", 3), ("voc_fft", 3), ("voc_bank", 4), ("configs3", 2)):
+            for name, steps in (("north_star", 3), ("stereo", 3), ("voc_fft", 3), ("voc_bank", 8), ("configs3", 2)):
                 desc, kw, S2, carrier = wl[name]
                 o = time_config(api, torch, dev, desc, kw, S2, 10.0, steps, carrier=carrier)
                 o["workload"] = name

@@ -595,8 +595,8 @@ int ensure_scratch(ra_context *c, int64_t nfb, int64_t n, int n_chunks) {
       const int64_t extra = std::max<int64_t>(kMaxChunks, n_chunks);
       size_t S = p.n_streams, G = static_cast<size_t>(nfb + 2 + extra);
       sc.seg_cap = nfb + 2 + extra;
-      if ((r = dev_alloc(c, &sc.seg_sd, S * G * SD_COUNT * p.Ppad, false))) return r;
-      if ((r = dev_alloc(c, &sc.seg_si, S * G * SI_COUNT * p.Ppad, false))) return r;
+      if ((r = dev_alloc(c, &sc.seg_sd, S * G * SD_HOP_COUNT * p.Ppad, false))) return r;
+      if ((r = dev_alloc(c, &sc.seg_si, S * G * SI_HOP_COUNT * p.Ppad, false))) return r;
     }
   }
   ra_context::Scratch &sc = c->scr[c->parity];

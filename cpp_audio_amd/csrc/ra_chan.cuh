@@ -578,3 +578,33 @@ __device__ inline void store_chan(const Chan &c, double *sd, int *si, int Ppad, 
   si[SI_ENV_AHDSTATE * Ppad + l] = c.ahdstate; si[SI_ENV_AHDCOUNTER * Ppad + l] = c.ahdcounter; si[SI_ENV_MINCH * Ppad + l] = c.minch;
   si[SI_ENV_NEXTMINCH * Ppad + l] = c.nextminch; si[SI_FLAGS * Ppad + l] = c.flags;
 }
+// A hop's start state as the propagate kernel hands it to the render kernel: the planes below SD_HOP_COUNT only (no gains when the render
+// applies the centre gains after the sum).  The phasor, the rotation and the anti-aliasing gain are derived from (theta, inc) by
+// chan_from_phase at the hop's start, vol is a copy of y, and the AHD state and the flags ride in the state word: 144 (128) instead of
+// 200 bytes per sounding channel and hop.
+__device__ inline void load_hop(Chan &c, const double *sd, const int *si, int Ppad, int l, bool mono) {
+  c.value = sd[SD_ENV_VALUE * Ppad + l]; c.top = sd[SD_ENV_TOP * Ppad + l];
+  c.from = sd[SD_CTRL_FROM * Ppad + l]; c.to = sd[SD_CTRL_TO * Ppad + l]; c.cur = sd[SD_CTRL_CUR * Ppad + l];
+  c.C = sd[SD_CTRL_C * Ppad + l]; c.fres = sd[SD_CTRL_FRES * Ppad + l]; c.inc = sd[SD_OSC_INC * Ppad + l];
+  c.target = sd[SD_VOL_TARGET * Ppad + l]; c.finit = sd[SD_VOL_FINIT * Ppad + l];
+  c.k = sd[SD_VOL_K * Ppad + l]; c.y = sd[SD_VOL_Y * Ppad + l]; c.vol = c.y;
+  c.theta = sd[SD_THETA * Ppad + l];
+  if (!mono) { c.gL = sd[SD_GAIN_L * Ppad + l]; c.gR = sd[SD_GAIN_R * Ppad + l]; } else { c.gL = 0.0; c.gR = 0.0; }
+  c.cre = 1.0; c.cim = 0.0; c.mre = 1.0; c.mim = 0.0; c.alias = 1.0; // chan_from_phase follows
+  const int w = si[SI_ENV_STATE * Ppad + l];
+  c.state = ra_hop_state(w); c.ahdstate = ((w >> 4) & 15) - 1; c.flags = w >> 8;
+  c.counter = si[SI_ENV_COUNTER * Ppad + l]; c.reldelay = si[SI_ENV_RELDELAY * Ppad + l];
+  c.ahdcounter = si[SI_ENV_AHDCOUNTER * Ppad + l]; c.minch = si[SI_ENV_MINCH * Ppad + l]; c.nextminch = si[SI_ENV_NEXTMINCH * Ppad + l];
+}
+__device__ inline void store_hop(const Chan &c, double *sd, int *si, int Ppad, int l, bool mono) {
+  sd[SD_ENV_VALUE * Ppad + l] = c.value; sd[SD_ENV_TOP * Ppad + l] = c.top;
+  sd[SD_CTRL_FROM * Ppad + l] = c.from; sd[SD_CTRL_TO * Ppad + l] = c.to; sd[SD_CTRL_CUR * Ppad + l] = c.cur;
+  sd[SD_CTRL_C * Ppad + l] = c.C; sd[SD_CTRL_FRES * Ppad + l] = c.fres; sd[SD_OSC_INC * Ppad + l] = c.inc;
+  sd[SD_VOL_TARGET * Ppad + l] = c.target; sd[SD_VOL_FINIT * Ppad + l] = c.finit;
+  sd[SD_VOL_K * Ppad + l] = c.k; sd[SD_VOL_Y * Ppad + l] = c.y;
+  sd[SD_THETA * Ppad + l] = c.theta;
+  if (!mono) { sd[SD_GAIN_L * Ppad + l] = c.gL; sd[SD_GAIN_R * Ppad + l] = c.gR; }
+  si[SI_ENV_STATE * Ppad + l] = ra_hop_word(c.state, c.ahdstate, c.flags);
+  si[SI_ENV_COUNTER * Ppad + l] = c.counter; si[SI_ENV_RELDELAY * Ppad + l] = c.reldelay;
+  si[SI_ENV_AHDCOUNTER * Ppad + l] = c.ahdcounter; si[SI_ENV_MINCH * Ppad + l] = c.minch; si[SI_ENV_NEXTMINCH * Ppad + l] = c.nextminch;
+}

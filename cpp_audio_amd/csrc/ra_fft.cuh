@@ -9,7 +9,9 @@
 // Stages with half = h, 2h, 4h of the radix-2 DIT network close over groups of 8 points {base + k h}: a thread loads one group,
 // runs the 3 x 4 butterflies exactly as the stage-by-stage network would (same operands, same twiddles, same operation order:
 // results are bit-identical) and stores it back, so an M-point transform takes ceil(log2 M / 3) LDS round trips and barriers
-// instead of log2 M.
+// instead of log2 M.  (The half = 8 and half = 64 passes both stay inside the 512 points a wave owns, so the barrier between them can be a
+// wave-local ordering point; measured r03: slower — modulator transform 22.0 -> 24.7 ms, analysis 3.73 -> 3.93 ms per step — the waves of a
+// workgroup drift apart and their LDS accesses collide more; every pass ends in the workgroup barrier.)
 //
 // LDS layout: element i of an M-point buffer lives in slot ra_zslot(i, ra_zshift(log2 M)) — the low four index bits XORed with bits
 // 3..6 and, from M = 128 up, the low three also with the top three bits (a bijection inside every aligned run of 16 slots, no padding).

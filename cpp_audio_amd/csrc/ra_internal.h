@@ -48,6 +48,8 @@ struct RaParams {
   int render_mode; // diagnostics: 0 regime renderer, 2 hop-parallel with the reference-order step, 3 with the cheap generic step
   int render_pack; // 1: two hops with at most 32 sounding channels each share a wave (ra_synth.hip: render_pair); 0 (reference_order 4): never
 };
+// the hop-parallel renderer applies the two centre gains after the channel sum (ra_synth_render_mono_kernel) and needs no per-channel gains
+__host__ __device__ inline bool ra_hop_mono(const RaParams &p) { return p.render_mode == 0 && p.stereo_spread == 0.f; }
 
 // ---- analysis -> tracking hand-off: one list per (stream, frame) ----------------------------------
 // pitch/vol/key arrays are [n_streams][frames_cap][maxr]; count is [n_streams][frames_cap]
@@ -78,13 +80,22 @@ struct RaTrackState {
 
 // ---- persistent per-channel synth state: struct of arrays [n_streams][field][Ppad] -----------------
 enum {
-  SD_ENV_VALUE, SD_ENV_TOP, SD_CTRL_FROM, SD_CTRL_TO, SD_CTRL_CUR, SD_CTRL_C, SD_CTRL_FRES,
-  SD_OSC_CRE, SD_OSC_CIM, SD_OSC_MRE, SD_OSC_MIM, SD_OSC_ALIAS, SD_OSC_INC,
-  SD_VOL, SD_VOL_TARGET, SD_VOL_FINIT, SD_VOL_K, SD_VOL_Y, SD_GAIN_L, SD_GAIN_R,
+  SD_ENV_VALUE, SD_ENV_TOP, SD_CTRL_FROM, SD_CTRL_TO, SD_CTRL_CUR, SD_CTRL_C, SD_CTRL_FRES, SD_OSC_INC,
+  SD_VOL_TARGET, SD_VOL_FINIT, SD_VOL_K, SD_VOL_Y,
   SD_THETA, // oscillator angle in rad/pi: authoritative in hop-parallel mode (cre/cim are derived from it), unused in reference order
+  SD_HOP_MONO_COUNT, // the planes a hop's start state hands to the render kernel (seg_sd) when every channel is panned to the centre ...
+  SD_GAIN_L = SD_HOP_MONO_COUNT, SD_GAIN_R,
+  SD_HOP_COUNT,      // ... and with per-channel gains.  The rest is derived at the hop's start (chan_from_phase: phasor, rotation and
+  SD_OSC_CRE = SD_HOP_COUNT, SD_OSC_CIM, SD_OSC_MRE, SD_OSC_MIM, SD_OSC_ALIAS, // anti-aliasing gain from theta and inc) or a copy (vol = y)
+  SD_VOL,
   SD_COUNT
 };
-enum { SI_ENV_STATE, SI_ENV_COUNTER, SI_ENV_RELDELAY, SI_ENV_AHDSTATE, SI_ENV_AHDCOUNTER, SI_ENV_MINCH, SI_ENV_NEXTMINCH, SI_FLAGS, SI_COUNT };
+enum { SI_ENV_STATE, SI_ENV_COUNTER, SI_ENV_RELDELAY, SI_ENV_AHDCOUNTER, SI_ENV_MINCH, SI_ENV_NEXTMINCH,
+       SI_HOP_COUNT, // a hop's start state (seg_si) ends here: its state word also carries the AHD state and the flags (ra_hop_word)
+       SI_ENV_AHDSTATE = SI_HOP_COUNT, SI_FLAGS, SI_COUNT };
+// seg_si's state word: envelope state (ENV_*, bits 0-3), AHD state + 1 (bits 4-7), flags (bits 8 up)
+__host__ __device__ inline int ra_hop_word(int state, int ahdstate, int flags) { return state | ((ahdstate + 1) << 4) | (flags << 8); }
+__host__ __device__ inline int ra_hop_state(int w) { return w & 15; }
 enum { FL_HAS_FRES = 1, FL_HAS_VOL = 2, FL_HAS_TARGET = 4,
        FL_STEPPED0 = 8 }; // hop-start states only (seg_si): the propagate kernel already took this hop's first step for the channel
 enum { ENV_SOON = 0, ENV_PRESSED = 1, ENV_RELEASED = 2, ENV_DONE1 = 3, ENV_DONE2 = 4 }; // audioelement.h:157-163
@@ -122,8 +133,8 @@ struct RaBuffers {
   int32_t *cmd_non;         // [n_streams][frames_cap] number of note-on commands of the frame (their RaCmd.type carries the rank << 8)
   double *voc_mix;          // [n_streams][n] when the vocoder is enabled
   int64_t mix_cap;
-  double *seg_sd;           // [n_streams][seg_cap][SD_COUNT][Ppad] channel state at the start of every segment of the block
-  int32_t *seg_si;          // [n_streams][seg_cap][SI_COUNT][Ppad]
+  double *seg_sd;           // [n_streams][seg_cap][SD_HOP_COUNT][Ppad] channel state at the start of every segment of the block
+  int32_t *seg_si;          // [n_streams][seg_cap][SI_HOP_COUNT][Ppad]
   int64_t seg_cap;
   // ---- output -> analysis feedback (only allocated when its gain is non-zero) ----
   float *fb_hist;           // [n_streams][fb_hist_len] mono output float(L + R) of the fb_hist_len frames before the current block

@@ -623,6 +623,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) RA_PROP_OCC ra_synth_propagat
   Chan c;
   load_chan(c, sd, si, Ppad, l);
   const SynConst k = syn_const(p, s);
+  const bool hop_mono = ra_hop_mono(p); // the render kernel that follows applies the centre gains after the channel sum: no gains handed over
   RaPhaseClock clk(b.dbg_clk, l == 0);
   int64_t t = sp.ct0;
   for (int64_t i = 0; i <= sp.nfb; ++i) {
@@ -638,8 +639,8 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) RA_PROP_OCC ra_synth_propagat
     }
     // the hop's start state for the render kernel: a channel that does not sound hands over its envelope state word only (the render
     // never looks at the rest: half of the 12.8 KB per hop and stream on the BASELINE shapes)
-    if (rt_active(c)) store_chan(c, b.seg_sd + seg * SD_COUNT * Ppad, b.seg_si + seg * SI_COUNT * Ppad, Ppad, l);
-    else (b.seg_si + seg * SI_COUNT * Ppad)[SI_ENV_STATE * Ppad + l] = c.state;
+    if (rt_active(c)) store_hop(c, b.seg_sd + seg * SD_HOP_COUNT * Ppad, b.seg_si + seg * SI_HOP_COUNT * Ppad, Ppad, l, hop_mono);
+    else (b.seg_si + seg * SI_HOP_COUNT * Ppad)[SI_ENV_STATE * Ppad + l] = c.state;
     c.flags &= ~FL_STEPPED0;
     clk.lap<0>();
     chan_jump_phase(c, k.ep, k.dur, k.max_filter_inc, len);
@@ -668,8 +669,8 @@ __device__ inline void render_diag_segment(const RaParams &p, const RaBuffers &b
   const size_t seg = (size_t)s * b.seg_cap + sp.seg0 + i;
   Chan c;
   {
-    const int stv = (b.seg_si + seg * SI_COUNT * Ppad)[SI_ENV_STATE * Ppad + l];
-    if (stv != ENV_SOON && stv != ENV_DONE2) { load_chan(c, b.seg_sd + seg * SD_COUNT * Ppad, b.seg_si + seg * SI_COUNT * Ppad, Ppad, l); chan_from_phase(c); }
+    const int stv = ra_hop_state((b.seg_si + seg * SI_HOP_COUNT * Ppad)[SI_ENV_STATE * Ppad + l]);
+    if (stv != ENV_SOON && stv != ENV_DONE2) { load_hop(c, b.seg_sd + seg * SD_HOP_COUNT * Ppad, b.seg_si + seg * SI_HOP_COUNT * Ppad, Ppad, l, false); chan_from_phase(c); }
     else { chan_init(c); c.state = stv; }
   }
   const SynConst k = syn_const(p, s);
@@ -718,9 +719,9 @@ __device__ inline void render_pair(const RaParams &p, const RaBuffers &b, const 
     int cnt[2] = {0, 0};
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int32_t *st = b.seg_si + (seg0 + h) * SI_COUNT * Ppad + SI_ENV_STATE * Ppad;
+      const int32_t *st = b.seg_si + (seg0 + h) * SI_HOP_COUNT * Ppad + SI_ENV_STATE * Ppad;
       for (int blk = 0; blk < (Ppad >> 6); ++blk) {
-        const int stv = st[blk * 64 + lw];
+        const int stv = ra_hop_state(st[blk * 64 + lw]);
         const bool act = stv != ENV_SOON && stv != ENV_DONE2; // rt_active
         const unsigned long long m = __ballot(act);
         const int rank = cnt[h] + __popcll(m & ((1ull << lw) - 1ull));
@@ -744,7 +745,7 @@ __device__ inline void render_pair(const RaParams &p, const RaBuffers &b, const 
     chan_init(c);
     if (src >= 0) {
       const size_t seg = seg0 + (l >> 5);
-      load_chan(c, b.seg_sd + seg * SD_COUNT * Ppad, b.seg_si + seg * SI_COUNT * Ppad, Ppad, src);
+      load_hop(c, b.seg_sd + seg * SD_HOP_COUNT * Ppad, b.seg_si + seg * SI_HOP_COUNT * Ppad, Ppad, src, MONO);
       chan_from_phase(c);
     }
     clk.mark(20);
@@ -754,8 +755,8 @@ __device__ inline void render_pair(const RaParams &p, const RaBuffers &b, const 
     if (eh <= bh) return;
     const size_t seg = seg0 + (second ? 1 : 0);
     { // (a silent channel's hop state is its envelope state word, see the propagate kernel)
-      const int stv = (b.seg_si + seg * SI_COUNT * Ppad)[SI_ENV_STATE * Ppad + l];
-      if (stv != ENV_SOON && stv != ENV_DONE2) { load_chan(c, b.seg_sd + seg * SD_COUNT * Ppad, b.seg_si + seg * SI_COUNT * Ppad, Ppad, l); chan_from_phase(c); }
+      const int stv = ra_hop_state((b.seg_si + seg * SI_HOP_COUNT * Ppad)[SI_ENV_STATE * Ppad + l]);
+      if (stv != ENV_SOON && stv != ENV_DONE2) { load_hop(c, b.seg_sd + seg * SD_HOP_COUNT * Ppad, b.seg_si + seg * SI_HOP_COUNT * Ppad, Ppad, l, MONO); chan_from_phase(c); }
       else { chan_init(c); c.state = stv; }
     }
     clk.mark(20);
@@ -803,7 +804,7 @@ void ra_launch_synth_render(const RaParams &p, const RaBuffers &b, const RaSpan 
   const int group_want = group_env > 0 ? group_env : 2;
   const unsigned group = (p.Ppad == 64) ? (unsigned)std::min(std::max(group_want, 1), RA_MAX_CHANNELS / 64) : 1u; // hops per workgroup
   const dim3 grid((unsigned)((sp.nfb + 1 + group - 1) / group), (unsigned)p.n_streams), block((unsigned)p.Ppad, group);
-  const size_t lds = (size_t)group * ra_tile_bytes(p.Ppad, p.stereo_spread == 0.f); // the tiles (+ the gains)
-  if (p.stereo_spread == 0.f) hipLaunchKernelGGL(ra_synth_render_mono_kernel, grid, block, lds, st, p, b, sp, d_out, d_out_d);
+  const size_t lds = (size_t)group * ra_tile_bytes(p.Ppad, ra_hop_mono(p)); // the tiles (+ the gains)
+  if (ra_hop_mono(p)) hipLaunchKernelGGL(ra_synth_render_mono_kernel, grid, block, lds, st, p, b, sp, d_out, d_out_d);
   else hipLaunchKernelGGL(ra_synth_render_kernel, grid, block, lds, st, p, b, sp, d_out, d_out_d);
 }
