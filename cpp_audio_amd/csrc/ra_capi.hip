@@ -83,6 +83,7 @@ struct ra_context {
   struct Scratch {
     int64_t frames_cap = 0, seg_cap = 0;
     double *pl_pitch = nullptr, *pl_vol = nullptr; float *pl_key = nullptr; int32_t *pl_count = nullptr;
+    float *pl_nf = nullptr, *pl_nv = nullptr; int32_t *pl_nmc = nullptr, *pl_ord = nullptr;
     RaCmd *cmd = nullptr; int32_t *cmd_non = nullptr;
     double *seg_sd = nullptr; int32_t *seg_si = nullptr;
     double *voc_mix = nullptr; int64_t mix_cap = 0; // [n_streams][n] the vocoder's mix of the block (added by the render)
@@ -578,6 +579,7 @@ int ensure_scratch(ra_context *c, int64_t nfb, int64_t n, int n_chunks) {
     if (nfb > sc.frames_cap) {
       HIP_TRY(hipDeviceSynchronize()); // nothing may still read the old buffers
       dev_free(c, sc.pl_pitch); dev_free(c, sc.pl_vol); dev_free(c, sc.pl_key); dev_free(c, sc.pl_count); dev_free(c, sc.cmd); dev_free(c, sc.cmd_non);
+      dev_free(c, sc.pl_nf); dev_free(c, sc.pl_nv); dev_free(c, sc.pl_nmc); dev_free(c, sc.pl_ord);
       // equal-length blocks differ by one frame depending on where they start: leave room, a reallocation synchronises the device
       size_t S = p.n_streams, F = static_cast<size_t>(nfb + 2);
       sc.frames_cap = nfb + 2;
@@ -585,6 +587,10 @@ int ensure_scratch(ra_context *c, int64_t nfb, int64_t n, int n_chunks) {
       if ((r = dev_alloc(c, &sc.pl_vol, S * F * p.maxr, false))) return r;
       if ((r = dev_alloc(c, &sc.pl_key, S * F * p.maxr, false))) return r;
       if ((r = dev_alloc(c, &sc.pl_count, S * F))) return r;
+      if ((r = dev_alloc(c, &sc.pl_nf, S * F * p.maxr, false))) return r;
+      if ((r = dev_alloc(c, &sc.pl_nv, S * F * p.maxr, false))) return r;
+      if ((r = dev_alloc(c, &sc.pl_nmc, S * F * p.maxr, false))) return r;
+      if ((r = dev_alloc(c, &sc.pl_ord, S * F * p.maxr, false))) return r;
       if ((r = dev_alloc(c, &sc.cmd, S * F * p.Ppad, false))) return r;
       if ((r = dev_alloc(c, &sc.cmd_non, S * F))) return r;
       HIP_TRY(hipStreamSynchronize(c->stream)); // the zero fills above ran on the caller's stream
@@ -602,6 +608,7 @@ int ensure_scratch(ra_context *c, int64_t nfb, int64_t n, int n_chunks) {
   ra_context::Scratch &sc = c->scr[c->parity];
   b.frames_cap = sc.frames_cap; b.seg_cap = sc.seg_cap;
   b.pl_pitch = sc.pl_pitch; b.pl_vol = sc.pl_vol; b.pl_key = sc.pl_key; b.pl_count = sc.pl_count;
+  b.pl_nf = sc.pl_nf; b.pl_nv = sc.pl_nv; b.pl_nmc = sc.pl_nmc; b.pl_ord = sc.pl_ord;
   b.cmd = sc.cmd; b.cmd_non = sc.cmd_non; b.seg_sd = sc.seg_sd; b.seg_si = sc.seg_si;
   if (p.post_limit && n > b.post_cap) {
     HIP_TRY(hipDeviceSynchronize());
@@ -840,7 +847,7 @@ int process_block_impl(ra_context *c, const float *d_voice, const float *d_carri
       sp.ct0 = (piece == 0) ? t0 : ra_fire_sample(p.N, p.H, f_lo + fb0);
       sp.ct1 = (fb1 == nfb) ? t0 + n : ra_fire_sample(p.N, p.H, f_lo + fb1);
       if (sp.nfb > 0) {
-        RA_TRY(timed_launch(c, ST_ANALYSIS, user, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, sp.fb0, sp.nfb, nfb, user); }));
+        RA_TRY(timed_launch(c, ST_ANALYSIS, user, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, sp.fb0, sp.nfb, nfb, user); ra_launch_track_prep(p, b, sp.fb0, sp.nfb, user); }));
         RA_TRY(timed_launch(c, ST_TRACK, user, [&] { ra_launch_track(p, b, f_lo, sp.fb0, sp.nfb, user); }));
       }
       if (c->cfg.reference_order == 1) RA_TRY(timed_launch(c, ST_RENDER, user, [&] { ra_launch_synth_serial(p, b, sp, d_out, d_out_d, user); }));
@@ -857,7 +864,7 @@ int process_block_impl(ra_context *c, const float *d_voice, const float *d_carri
     n_chunks = 1; // the window history is rolled on the caller's stream below
   } else if (n_chunks == 1) { // everything in order on the caller's stream
     RaSpan sp{t0, n, t0, t0 + n, f_lo, 0, nfb, 0};
-    RA_TRY(timed_launch(c, ST_ANALYSIS, user, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, 0, nfb, nfb, user); }));
+    RA_TRY(timed_launch(c, ST_ANALYSIS, user, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, 0, nfb, nfb, user); ra_launch_track_prep(p, b, 0, nfb, user); }));
     RA_TRY(timed_launch(c, ST_TRACK, user, [&] { ra_launch_track(p, b, f_lo, 0, nfb, user); }));
     if (p.voc_enabled) RA_TRY(timed_launch(c, ST_VOCODER, user, [&] { launch_vocoder(user); }));
     if (c->cfg.reference_order == 1) RA_TRY(timed_launch(c, ST_RENDER, user, [&] { ra_launch_synth_serial(p, b, sp, d_out, d_out_d, user); }));
@@ -972,7 +979,7 @@ int process_block_impl(ra_context *c, const float *d_voice, const float *d_carri
       const int a_first = (i == 0) ? 0 : 1 + ((i - 1) / agroup) * agroup, a_last = (i == 0) ? 0 : std::min(n_chunks - 1, a_first + agroup - 1);
       if (i == a_first) {
         const int64_t fb0 = cut(a_first), fb1 = (a_last == n_chunks - 1) ? nfb : cut(a_last + 1);
-        RA_TRY(timed_launch(c, ST_ANALYSIS, sA, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, fb0, fb1 - fb0, nfb, sA); }));
+        RA_TRY(timed_launch(c, ST_ANALYSIS, sA, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, fb0, fb1 - fb0, nfb, sA); ra_launch_track_prep(p, b, fb0, fb1 - fb0, sA); }));
         HIP_TRY(hipEventRecord(c->ev_chunk[0][a_first], sA));
       }
       HIP_TRY(hipStreamWaitEvent(sT, c->ev_chunk[0][a_first], 0));

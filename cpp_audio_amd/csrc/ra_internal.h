@@ -129,6 +129,10 @@ struct RaBuffers {
   double *pl_pitch, *pl_vol; // [n_streams][frames_cap][maxr]
   float *pl_key;
   int32_t *pl_count;        // [n_streams][frames_cap]
+  // per item, derived from the list alone by ra_track_prep_kernel (frame-parallel) so that the tracking chain does not compute them:
+  float *pl_nf, *pl_nv;     // the event payload: frequency and velocity as floats (events.h:19-29)
+  int32_t *pl_nmc;          // min change duration of that frequency
+  int32_t *pl_ord;          // the frame's loudness order: item index by descending key, ties in index order
   RaCmd *cmd;               // [n_streams][frames_cap][Ppad]
   int32_t *cmd_non;         // [n_streams][frames_cap] number of note-on commands of the frame (their RaCmd.type carries the rank << 8)
   double *voc_mix;          // [n_streams][n] when the vocoder is enabled
@@ -314,6 +318,7 @@ int ra_voice_launch_render(const RaVoiceParams &p, const RaVoiceJob *jobs, const
 void ra_launch_analysis(const RaParams &p, const RaBuffers &b, const float *d_voice, int64_t t0, int64_t n, int64_t f_lo, int64_t fb0, int64_t nfb_chunk,
                         int64_t nfb_total, hipStream_t st);
 void ra_launch_track(const RaParams &p, const RaBuffers &b, int64_t f_lo, int64_t fb0, int64_t n_frames_blk, hipStream_t st);
+void ra_launch_track_prep(const RaParams &p, const RaBuffers &b, int64_t fb0, int64_t n_frames_blk, hipStream_t st); // after the analysis of those frames
 void ra_launch_synth_serial(const RaParams &p, const RaBuffers &b, const RaSpan &sp, float *d_out, double *d_out_d, hipStream_t st);
 void ra_launch_synth_propagate(const RaParams &p, const RaBuffers &b, const RaSpan &sp, hipStream_t st);
 void ra_launch_synth_render(const RaParams &p, const RaBuffers &b, const RaSpan &sp, float *d_out, double *d_out_d, hipStream_t st);

@@ -47,17 +47,15 @@ __global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, i
 
   // per pitch-list item
   double *pitch = reinterpret_cast<double *>(ra_smem_trk);        // [maxr]
-  double *vol = pitch + maxr;                                     // [maxr]
   // per played note / channel (8-byte)
-  double *pl_pitch = vol + maxr;                                  // [P]
+  double *pl_pitch = pitch + maxr;                                // [P]
   double *tmp_pitch = pl_pitch + P;                               // [P]
   int64_t *pl_noteid = reinterpret_cast<int64_t *>(tmp_pitch + P); // [P]
   int64_t *tmp_noteid = pl_noteid + P;                            // [P]
   int64_t *free_at = tmp_noteid + P;                              // [P]
   int64_t *cnote = free_at + P;                                   // [P] staged commands: note id
   // per item (4-byte)
-  float *key = reinterpret_cast<float *>(cnote + P);              // [maxr]
-  float *nf = key + maxr;                                         // [maxr] new frequency (float, events.h:19-29)
+  float *nf = reinterpret_cast<float *>(cnote + P);               // [maxr] new frequency (float, events.h:19-29)
   float *nv = nf + maxr;                                          // [maxr] new velocity
   int *nmc = reinterpret_cast<int *>(nv + maxr);                  // [maxr] min change duration of the new frequency
   int *ord = nmc + maxr;                                          // [maxr]
@@ -91,42 +89,42 @@ __global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, i
   RaPhaseClock clk(b.dbg_clk, lane == 0);
   unsigned long long sumA = 0, sumPlayed = 0;
 
-  // The head of the next frame's list (one item per lane) and its length are requested a frame ahead: a frame's work is a chain of ~20 k
-  // cycles that would otherwise start with a global round trip.
-  auto fetch_head = [&](int64_t fbn, double &pt, double &v, float &k, int &cnt) {
-    pt = 0.0; v = 0.0; k = 0.f; cnt = 0;
+  // The head of the next frame's list (one item per lane: pitch, event payload, loudness order) and its length are requested a frame ahead
+  // into registers nothing else touches, and moved into the frame's LDS arrays at the END of the frame before (when they have long
+  // arrived): a frame's chain of ~10 k cycles never waits for a global round trip.  (r02 / early r03 handed the registers over at the top of
+  // the frame: the wait-count bookkeeping at the loop header then made every reuse of the first frame's load registers wait for the loads
+  // just issued, and the length — wave-uniform, so the compiler wanted it in an SGPR at once — cost a round trip of its own.)
+  struct Head { double pitch; float nf, nv; int nmc, ord, count; };
+  int lane_zero = 0;
+  asm volatile("" : "+v"(lane_zero)); // keeps the length's load a per-lane one: its value is needed a frame later
+  auto fetch_head = [&](int64_t fbn) {
+    Head h; h.pitch = 0.0; h.nf = 0.f; h.nv = 0.f; h.nmc = 0; h.ord = 0; h.count = 0;
     if (fbn < fb0 + n_frames_blk) {
       const size_t lb = ((size_t)s * b.frames_cap + fbn) * maxr;
-      cnt = b.pl_count[(size_t)s * b.frames_cap + fbn];
-      if (lane < maxr) { pt = b.pl_pitch[lb + lane]; v = b.pl_vol[lb + lane]; k = b.pl_key[lb + lane]; }
+      h.count = (b.pl_count + (size_t)s * b.frames_cap + fbn)[lane_zero];
+      if (lane < maxr) { h.pitch = b.pl_pitch[lb + lane]; h.nf = b.pl_nf[lb + lane]; h.nv = b.pl_nv[lb + lane]; h.nmc = b.pl_nmc[lb + lane]; h.ord = b.pl_ord[lb + lane]; }
     }
+    return h;
   };
-  double nx_pitch, nx_vol;
-  float nx_key;
-  int nx_count;
-  fetch_head(fb0, nx_pitch, nx_vol, nx_key, nx_count);
+  auto stage_head = [&](const Head &h) -> int { // into the arrays phases 1 and 5 read; returns the list's length
+    if (lane < maxr) { pitch[lane] = h.pitch; nf[lane] = h.nf; nv[lane] = h.nv; nmc[lane] = h.nmc; ord[lane] = h.ord; }
+    return __builtin_amdgcn_readfirstlane(h.count);
+  };
+  int A_next = stage_head(fetch_head(fb0));
+  __syncthreads();
 
   for (int64_t fb = fb0; fb < fb0 + n_frames_blk; ++fb) { // frames fb0 .. of the block; scratch is indexed by fb
     const int64_t k_f = ra_fire_sample(p.N, p.H, f_lo + fb);
     const size_t lbase = ((size_t)s * b.frames_cap + fb) * maxr;
-    const int A = nx_count;
-    const double head_pitch = nx_pitch, head_vol = nx_vol;
-    const float head_key = nx_key;
-    fetch_head(fb + 1, nx_pitch, nx_vol, nx_key, nx_count);
+    const int A = A_next;
+    const Head nx = fetch_head(fb + 1);
 
-    // ---- phase 0: the frame's list; per item the event payload (lib.cpp:319-324, midi.h:254-264) ----
-    for (int i = lane; i < A; i += 64) {
-      double pt, v;
-      float ky;
-      if (i < 64) { pt = head_pitch; v = head_vol; ky = head_key; }
-      else { pt = b.pl_pitch[lbase + i]; v = b.pl_vol[lbase + i]; ky = b.pl_key[lbase + i]; }
-      pitch[i] = pt; vol[i] = v; key[i] = ky;
-      float f = (float)((double)440.f * ra_pow(p.half_tone_ratio, pt - 69.0)); // midi.h:258-264; the power as in oracle_math.hpp (events are compared bit for bit)
-      nf[i] = f;
-      nv[i] = (float)((double)p.analysis_volume * v / (double)0.1f);
-      nmc[i] = min_change_for(f, p.sample_rate);
-      pc[i] = -1;
+    // ---- phase 0: the frame's list with the event payload and the loudness order (lib.cpp:319-324, midi.h:254-264, algo.cpp:375-411): all of
+    // it depends on the list alone and was computed by ra_track_prep_kernel, frame-parallel, off this chain; the first 64 items are staged ----
+    for (int i = 64 + lane; i < A; i += 64) {
+      pitch[i] = b.pl_pitch[lbase + i]; nf[i] = b.pl_nf[lbase + i]; nv[i] = b.pl_nv[lbase + i]; nmc[i] = b.pl_nmc[lbase + i]; ord[i] = b.pl_ord[lbase + i];
     }
+    for (int i = lane; i < A; i += 64) pc[i] = -1;
     for (int i = lane; i < P; i += 64) { ctype[i] = RA_CMD_NONE; if (i < n_played) cont[i] = 0; }
     __syncthreads();
 
@@ -134,26 +132,36 @@ __global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, i
     // ---- phase 1: track_pitches, algo.cpp:256-305 (sequential two-pointer scan) ----
     if (A <= 64 && n_played <= 64) {
       // The scan is a chain of comparisons; run by one lane out of LDS it costs two dependent LDS round trips per step (~200 cycles per
-      // step of either pointer).  Here lane j holds played note j's pitch: for item idx (its pitch broadcast with v_readlane) one vector
-      // comparison gives the mask of notes not below the window, the scan's pointer `it` masks off the notes already passed, the first
-      // bit left is where the reference's inner loop stops, and a second comparison says whether that note lies inside the window —
-      // one short scalar step per item, no inner loop.  (Played pitches ascend: sort_by_current_pitch, algo.cpp:434-439.)
-      const double my_pitch = lane < A ? pitch[lane] : 0.0, my_played = lane < n_played ? pl_pitch[lane] : 0.0;
-      const unsigned long long valid = n_played == 64 ? ~0ull : ((1ull << n_played) - 1ull);
-      int my_pc = -1;
-      unsigned long long cont_mask = 0ull;
+      // step of either pointer), and as one ballot step per item (r02) still ~290 cycles per item: broadcast, subtract, compare, mask, find
+      // first, all waiting for each other and for the pointer.  Played pitches ascend (sort_by_current_pitch, algo.cpp:434-439), so for an
+      // item with window [lo, hi] the notes below the window are the first L of them and the notes not above it the first U: both counts
+      // depend on the item alone and every item lane takes them in a loop over the played notes whose steps do not wait for each other.
+      // The reference's inner loop started at `it` stops at j = max(it, L); the note lies inside the window iff j < U.  What is left
+      // of the chain is integer: two lane reads, a maximum, a compare and an add per item.
+      const double my_played = lane < n_played ? pl_pitch[lane] : 0.0;
+      const double my_pitch = lane < A ? pitch[lane] : 0.0;
+      const double lo = my_pitch - p.max_track, hi = my_pitch + p.max_track;
+      int L = 0, U = 0;
+      for (int j = 0; j < n_played; ++j) {
+        const double pj = ra_readlane_f64(my_played, j);
+        L += (pj < lo) ? 1 : 0;
+        U += (pj <= hi) ? 1 : 0;
+      }
+      // (no branches: a taken branch costs a lone wave more than the three instructions it would skip.  U <= n_played, so "inside the window"
+      // implies "a note is left"; once `it` has reached n_played nothing matches any more, which is the reference's early exit.)
+      const int Uz = lane < A ? U : 0;                 // lanes past the list never match: the loop may run over them
+      int my_pc = -1, my_cont = 0;                     // lane = item: the note it continues; lane = played note: continued
       int it = 0;
-      for (int idx = 0; idx < A && it < n_played; ++idx) {
-        const double np = ra_readlane_f64(my_pitch, idx);
-        const unsigned long long not_below = __ballot(!(my_played < np - p.max_track)) & valid & (~0ull << it);
-        if (!not_below) { it = n_played; break; }      // every remaining note lies below this (and every later) window
-        const int j = __ffsll((long long)not_below) - 1;
-        const unsigned long long inside = __ballot(my_played <= np + p.max_track);
-        if ((inside >> j) & 1ull) { if (lane == idx) my_pc = j; cont_mask |= 1ull << j; it = j + 1; }
-        else it = j;
+#pragma unroll 4
+      for (int idx = 0; idx < ((A + 3) & ~3); ++idx) {
+        const int j = max(it, __builtin_amdgcn_readlane(L, idx));
+        const bool m = j < __builtin_amdgcn_readlane(Uz, idx);
+        it = j + (m ? 1 : 0);
+        if (lane == (m ? idx : -1)) my_pc = j;
+        if (lane == (m ? j : -1)) my_cont = 1;
       }
       if (lane < A) pc[lane] = my_pc;
-      if (lane < n_played) cont[lane] = (int)((cont_mask >> lane) & 1ull);
+      if (lane < n_played) cont[lane] = my_cont;
     } else if (lane == 0) {
       int it = 0;
       for (int idx = 0; idx < A; ++idx) {
@@ -166,22 +174,7 @@ __global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, i
       }
     }
     clk.lap<1>();
-    // ---- phase 2: loudness order = stable rank sort by key, descending ----
-    if (A <= 64) { // the keys are in registers (one per lane): the other items' keys come by v_readlane instead of LDS round trips
-      int r = 0;
-      const int kbits = __float_as_int(head_key);
-      for (int j = 0; j < A; ++j) {
-        const float kj = __int_as_float(__builtin_amdgcn_readlane(kbits, j));
-        r += (kj > head_key || (kj == head_key && j < lane)) ? 1 : 0;
-      }
-      if (lane < A) ord[r] = lane;
-    } else
-    for (int i = lane; i < A; i += 64) {
-      float k = key[i];
-      int r = 0;
-      for (int j = 0; j < A; ++j) { float kj = key[j]; r += (kj > k || (kj == k && j < i)) ? 1 : 0; }
-      ord[r] = i;
-    }
+    // (phase 2, the loudness order, is ra_track_prep_kernel's)
     __syncthreads();
 
     clk.lap<2>();
@@ -247,7 +240,6 @@ __global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, i
     }
     st.next_noteid += cand_base;
     st.dropped_note_on += cand_base - succ_base;
-    if (lane == 0) b.cmd_non[(size_t)s * b.frames_cap + fb] = succ_base;
     const int n_new = n_played + succ_base;
     __syncthreads();
 
@@ -258,7 +250,7 @@ __global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, i
       const double pj = lane < n_new ? pl_pitch[lane] : 0.0;
       const unsigned long long km = __ballot(is);
       int r = 0;
-      for (unsigned long long m = km; m; m &= m - 1) {
+      for (unsigned long long m = km; m; m &= m - 1) { // (r03: a straight loop over all lanes with the ties counted apart measured slower)
         const int i = __ffsll((long long)m) - 1;
         const double pi = ra_readlane_f64(pj, i);
         r += (pi < pj || (pi == pj && i < lane)) ? 1 : 0;
@@ -281,6 +273,10 @@ __global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, i
     n_played = kept;
     for (int i = lane; i < n_played; i += 64) { pl_pitch[i] = tmp_pitch[i]; pl_noteid[i] = tmp_noteid[i]; pl_chan[i] = tmp_chan[i]; }
 
+    // the next frame's list head (requested at the top of this frame) into the list arrays, which phase 5 was the last to read — before
+    // this frame's command stores are issued: a wait for the loads would wait for those stores too
+    A_next = stage_head(nx);
+    if (lane == 0) b.cmd_non[(size_t)s * b.frames_cap + fb] = succ_base;
     RaCmd *out = b.cmd + ((size_t)s * b.frames_cap + fb) * p.Ppad;
     for (int i = lane; i < p.Ppad; i += 64) {
       RaCmd c;
@@ -306,9 +302,54 @@ __global__ void __launch_bounds__(64) ra_track_kernel(RaParams p, RaBuffers b, i
   if (lane == 0) { st.n_played = n_played; b.track[s] = st; }
 }
 
+// ---- K2a: what tracking needs of a frame's list and the list alone determines — the event payload of every item (lib.cpp:319-324,
+// midi.h:254-264, the power as in oracle_math.hpp: events are compared bit for bit) and the frame's loudness order (stable rank sort by key,
+// descending: order_pitches_by_perceived_loudness, algo.cpp:375-411, ties in index order) — one wave per frame, RA_PREP_FRAMES frames per wave.
+// (r03: these were phases 0 and 2 of the tracking chain, 8.5 k of its 24 k cycles per frame.)
+#define RA_PREP_WAVES 4
+#define RA_PREP_FRAMES 4
+__global__ void __launch_bounds__(64 * RA_PREP_WAVES) ra_track_prep_kernel(RaParams p, RaBuffers b, int64_t fb0, int nfb) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, s = blockIdx.y, maxr = p.maxr;
+  float *keys = reinterpret_cast<float *>(ra_smem_trk) + (size_t)wave * maxr; // [maxr] per wave
+  for (int q = 0; q < RA_PREP_FRAMES; ++q) {
+    const int f = (blockIdx.x * RA_PREP_WAVES + wave) * RA_PREP_FRAMES + q;
+    if (f >= nfb) break; // wave-uniform
+    const size_t fi = (size_t)s * b.frames_cap + fb0 + f, base = fi * maxr;
+    const int A = min(b.pl_count[fi], maxr);
+    for (int i = lane; i < A; i += 64) {
+      const double pt = b.pl_pitch[base + i], v = b.pl_vol[base + i];
+      const float fr = (float)((double)440.f * ra_pow(p.half_tone_ratio, pt - 69.0));
+      b.pl_nf[base + i] = fr;
+      b.pl_nv[base + i] = (float)((double)p.analysis_volume * v / (double)0.1f);
+      b.pl_nmc[base + i] = min_change_for(fr, p.sample_rate);
+      keys[i] = b.pl_key[base + i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int i = lane; i < A; i += 64) {
+      const float k = keys[i];
+      int r = 0;
+      for (int j = 0; j < A; ++j) { const float kj = keys[j]; r += (kj > k || (kj == k && j < i)) ? 1 : 0; }
+      b.pl_ord[base + r] = i;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // keys are rewritten by the next frame
+  }
+}
+
 } // namespace
 
-size_t ra_track_lds_bytes(const RaParams &p) { return (size_t)p.maxr * (8 + 8 + 6 * 4) + (size_t)p.P * (6 * 8 + 10 * 4) + 64; }
+size_t ra_track_lds_bytes(const RaParams &p) { return (size_t)p.maxr * (8 + 5 * 4) + (size_t)p.P * (6 * 8 + 10 * 4) + 64; }
+
+void ra_launch_track_prep(const RaParams &p, const RaBuffers &b, int64_t fb0, int64_t n_frames_blk, hipStream_t st) {
+  if (n_frames_blk <= 0) return;
+  const size_t lds = (size_t)RA_PREP_WAVES * p.maxr * sizeof(float);
+  static unsigned long long attr_done = 0;
+  ra_once_per_device(attr_done, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_track_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RA_LDS_LIMIT_BYTES);
+  });
+  const int per_wg = RA_PREP_WAVES * RA_PREP_FRAMES;
+  hipLaunchKernelGGL(ra_track_prep_kernel, dim3((unsigned)((n_frames_blk + per_wg - 1) / per_wg), (unsigned)p.n_streams), dim3(64 * RA_PREP_WAVES), lds, st, p, b, fb0,
+                     (int)n_frames_blk);
+}
 
 void ra_launch_track(const RaParams &p, const RaBuffers &b, int64_t f_lo, int64_t fb0, int64_t n_frames_blk, hipStream_t st) {
   if (n_frames_blk <= 0) return;
