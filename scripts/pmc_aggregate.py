@@ -4,7 +4,8 @@ beside the counters (bench.json): bench.py quotes the counters only for exactly 
 import csv, glob, json, os, sys
 
 out = sys.argv[1]
-STAGE = {"ra_analysis_kernel": "analysis", "ra_track_kernel": "track", "ra_synth_propagate_kernel": "propagate", "ra_synth_render_mono_kernel": "render",
+STAGE = {"ra_analysis_kernel": "analysis", "ra_track_prep_kernel": "analysis",  # (the pre-pass is launched with every analysis launch)
+          "ra_track_kernel": "track", "ra_synth_propagate_kernel": "propagate", "ra_synth_render_mono_kernel": "render",
          "ra_synth_render_kernel": "render", "ra_roll_history_kernel": "history"}
 KERNELS = tuple(STAGE)
 
