@@ -1885,17 +1885,25 @@ struct ra_voice {
   std::unique_ptr<VoicePool> pool;
   // device side
   static constexpr int kTile = 256;
-  RaVoiceJob *d_jobs = nullptr; int32_t *d_order = nullptr, *d_slot_begin = nullptr;
-  int64_t jobs_cap = 0, slots_cap = 0, order_cap = 0;
-  RaVoiceState *d_states[2] = {nullptr, nullptr};
-  RaVoiceSeg *d_seg = nullptr;
+  // The state pre-pass (and the block's copies) run on a queue of their own: block k + 1's pre-pass — dependency chains a few hundred
+  // waves wide — beside block k's render.  Everything a render reads exists twice (the render of block k - 1 must be over before block
+  // k + 1's copies land: ev_render_done), the tile-boundary states three times (block k + 1 reads block k's and writes its own while the
+  // render of block k still reads block k - 1's and block k's).
+  hipStream_t pre_stream = nullptr;
+  hipEvent_t ev_pre_done[2] = {nullptr, nullptr}, ev_render_done[2] = {nullptr, nullptr};
+  bool set_used[2] = {false, false};
+  RaVoiceJob *d_jobs[2] = {nullptr, nullptr}; int32_t *d_order[2] = {nullptr, nullptr}, *d_slot_begin[2] = {nullptr, nullptr};
+  int64_t jobs_cap[2] = {0, 0}, slots_cap[2] = {0, 0}, order_cap[2] = {0, 0};
+  RaVoiceState *d_states[3] = {nullptr, nullptr, nullptr};
+  RaVoiceSeg *d_seg = nullptr; // (the pre-pass's own scratch: only ever touched on its queue, in block order)
   int64_t seg_cap = 0;
-  int64_t states_cap[2] = {0, 0};
-  int parity = 0;
+  int64_t states_cap[3] = {0, 0, 0};
+  int parity = 0;     // which of the two sets this block uses
+  int state_idx = 0;  // which of the three state arrays this block writes (the one before it holds the carry-in)
   struct Staging { void *h = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool used = false; } staging[2];
   int stage_parity = 0;
   // timing
-  struct Timed { hipEvent_t a, b, c; };
+  struct Timed { hipEvent_t a, b, b2, c; }; // pre-pass a -> b on its queue, render b2 -> c on the caller's
   std::vector<Timed> timed;
   std::vector<hipEvent_t> ev_pool;
   bool profiling = false;
@@ -2048,6 +2056,9 @@ int ra_voice_create(const ra_voice_config *cfg, int32_t n_streams, int32_t devic
   v->profiling = std::getenv("RA_VOICE_PROFILE") != nullptr;
   hipError_t e = hipSuccess;
   for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&v->staging[i].done, hipEventDisableTiming);
+  for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&v->ev_pre_done[i], hipEventDisableTiming);
+  for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&v->ev_render_done[i], hipEventDisableTiming);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&v->pre_stream, hipStreamNonBlocking);
   if (e != hipSuccess) { ra_voice_destroy(v); return fail(RA_EHIP, std::string("ra_voice_create: ") + hipGetErrorString(e)); }
   *out = v;
   return RA_OK;
@@ -2061,10 +2072,17 @@ void ra_voice_destroy(ra_voice *v) {
                  v->host_ms[5] / v->host_blocks);
   (void)hipSetDevice(v->device);
   (void)hipDeviceSynchronize();
-  (void)hipFree(v->out); (void)hipFree(v->d_jobs); (void)hipFree(v->d_order); (void)hipFree(v->d_slot_begin);
-  (void)hipFree(v->d_states[0]); (void)hipFree(v->d_states[1]); (void)hipFree(v->d_seg);
+  (void)hipFree(v->out);
+  for (int i = 0; i < 2; ++i) {
+    (void)hipFree(v->d_jobs[i]); (void)hipFree(v->d_order[i]); (void)hipFree(v->d_slot_begin[i]);
+    if (v->ev_pre_done[i]) (void)hipEventDestroy(v->ev_pre_done[i]);
+    if (v->ev_render_done[i]) (void)hipEventDestroy(v->ev_render_done[i]);
+  }
+  for (int i = 0; i < 3; ++i) (void)hipFree(v->d_states[i]);
+  (void)hipFree(v->d_seg);
+  if (v->pre_stream) (void)hipStreamDestroy(v->pre_stream);
   for (auto &s : v->staging) { if (s.h) (void)hipHostFree(s.h); if (s.done) (void)hipEventDestroy(s.done); }
-  for (auto &t : v->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); (void)hipEventDestroy(t.c); }
+  for (auto &t : v->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); (void)hipEventDestroy(t.b2); (void)hipEventDestroy(t.c); }
   for (auto &e : v->ev_pool) (void)hipEventDestroy(e);
   delete v;
 }
@@ -2072,6 +2090,7 @@ void ra_voice_destroy(ra_voice *v) {
 int ra_voice_set_hip_stream(ra_voice *v, void *hip_stream) {
   if (!v) return fail(RA_EINVAL, "null context");
   HIP_TRY(hipSetDevice(v->device));
+  HIP_TRY(hipStreamSynchronize(v->pre_stream));
   HIP_TRY(hipStreamSynchronize(v->stream)); // what was enqueued on the old stream is finished before anything follows on the new one
   v->stream = static_cast<hipStream_t>(hip_stream);
   return RA_OK;
@@ -2080,6 +2099,7 @@ int ra_voice_set_hip_stream(ra_voice *v, void *hip_stream) {
 int ra_voice_synchronize(ra_voice *v) {
   if (!v) return fail(RA_EINVAL, "null context");
   HIP_TRY(hipSetDevice(v->device));
+  HIP_TRY(hipStreamSynchronize(v->pre_stream));
   HIP_TRY(hipStreamSynchronize(v->stream));
   return RA_OK;
 }
@@ -2106,8 +2126,9 @@ int ra_voice_events(ra_voice *v, const ra_voice_event *ev, int64_t n) {
 }
 
 namespace {
-int voice_grow_bytes(void **ptr, int64_t &cap, int64_t need, size_t elem, hipStream_t st) { // device buffers only grow; the stream is drained before one is replaced
+int voice_grow_bytes(void **ptr, int64_t &cap, int64_t need, size_t elem, hipStream_t st, hipStream_t st2) { // device buffers only grow; both queues are drained before one is replaced
   if (need <= cap) return RA_OK;
+  HIP_TRY(hipStreamSynchronize(st2));
   HIP_TRY(hipStreamSynchronize(st));
   (void)hipFree(*ptr);
   *ptr = nullptr;
@@ -2115,7 +2136,7 @@ int voice_grow_bytes(void **ptr, int64_t &cap, int64_t need, size_t elem, hipStr
   HIP_TRY(hipMalloc(ptr, elem * (size_t)cap));
   return RA_OK;
 }
-#define voice_grow(ptr, cap, need, st) voice_grow_bytes(reinterpret_cast<void **>(ptr), cap, need, sizeof(**(ptr)), st)
+#define voice_grow(ptr, cap, need, v) voice_grow_bytes(reinterpret_cast<void **>(ptr), cap, need, sizeof(**(ptr)), (v)->stream, (v)->pre_stream)
 
 // the block's events of one stream: ImplCRTP::onEvent (gen.crtp.h:389-449, 541-588) with the engine's acquisition rule
 void voice_stream_events(ra_voice *v, int s, int64_t t0, int64_t t1) {
@@ -2302,42 +2323,51 @@ int voice_block(ra_voice *v, int64_t n, float *d_out) {
   lap(tp, 3);
   // ---- device buffers, copies, launches ----
   static_assert(sizeof(RaVoiceJob) == 120, "layout of the job record");
-  RA_TRY(voice_grow(&v->d_jobs, v->jobs_cap, n_jobs + 1, v->stream));
-  RA_TRY(voice_grow(&v->d_order, v->order_cap, n_work + 1, v->stream));
-  RA_TRY(voice_grow(&v->d_slot_begin, v->slots_cap, n_slots, v->stream));
-  const int cur = v->parity, prev = cur ^ 1;
-  RA_TRY(voice_grow(&v->d_states[cur], v->states_cap[cur], n_states + 1, v->stream));
-  RA_TRY(voice_grow(&v->d_seg, v->seg_cap, n_states + 1, v->stream));
-  if (!v->d_states[prev]) RA_TRY(voice_grow(&v->d_states[prev], v->states_cap[prev], 1, v->stream));
-  if (n_jobs) HIP_TRY(hipMemcpyAsync(v->d_jobs, hj, bytes_jobs, hipMemcpyHostToDevice, v->stream));
-  HIP_TRY(hipMemcpyAsync(v->d_slot_begin, hs, bytes_slots, hipMemcpyHostToDevice, v->stream));
-  if (n_work) HIP_TRY(hipMemcpyAsync(v->d_order, ho, bytes_order, hipMemcpyHostToDevice, v->stream));
+  const int bs = v->parity, cur = v->state_idx, prev = (cur + 2) % 3;
+  hipStream_t sP = v->pre_stream, sR = v->stream;
+  RA_TRY(voice_grow(&v->d_jobs[bs], v->jobs_cap[bs], n_jobs + 1, v));
+  RA_TRY(voice_grow(&v->d_order[bs], v->order_cap[bs], n_work + 1, v));
+  RA_TRY(voice_grow(&v->d_slot_begin[bs], v->slots_cap[bs], n_slots, v));
+  RA_TRY(voice_grow(&v->d_states[cur], v->states_cap[cur], n_states + 1, v));
+  RA_TRY(voice_grow(&v->d_seg, v->seg_cap, n_states + 1, v));
+  if (!v->d_states[prev]) RA_TRY(voice_grow(&v->d_states[prev], v->states_cap[prev], 1, v));
+  // this set and this state array were last read by the render of the block before last
+  if (v->set_used[bs]) HIP_TRY(hipStreamWaitEvent(sP, v->ev_render_done[bs], 0));
+  if (n_jobs) HIP_TRY(hipMemcpyAsync(v->d_jobs[bs], hj, bytes_jobs, hipMemcpyHostToDevice, sP));
+  HIP_TRY(hipMemcpyAsync(v->d_slot_begin[bs], hs, bytes_slots, hipMemcpyHostToDevice, sP));
+  if (n_work) HIP_TRY(hipMemcpyAsync(v->d_order[bs], ho, bytes_order, hipMemcpyHostToDevice, sP));
   {
     ra_voice::Staging &sg = v->staging[v->stage_parity];
-    HIP_TRY(hipEventRecord(sg.done, v->stream));
+    HIP_TRY(hipEventRecord(sg.done, sP));
     sg.used = true;
     v->stage_parity ^= 1;
   }
   lap(tp, 4);
-  ra_voice::Timed tm{nullptr, nullptr, nullptr};
+  ra_voice::Timed tm{nullptr, nullptr, nullptr, nullptr};
   if (v->profiling) {
-    hipEvent_t *evs[3] = {&tm.a, &tm.b, &tm.c};
+    hipEvent_t *evs[4] = {&tm.a, &tm.b, &tm.b2, &tm.c};
     for (auto *pe : evs) {
       if (!v->ev_pool.empty()) { *pe = v->ev_pool.back(); v->ev_pool.pop_back(); }
       else HIP_TRY(hipEventCreate(pe));
     }
-    HIP_TRY(hipEventRecord(tm.a, v->stream));
+    HIP_TRY(hipEventRecord(tm.a, sP));
   }
-  ra_voice_launch_pre(v->p, v->d_jobs, v->d_order, (int)n_work, (int)n_states, v->d_states[prev], v->d_states[cur], v->d_seg, L, v->stream);
+  ra_voice_launch_pre(v->p, v->d_jobs[bs], v->d_order[bs], (int)n_work, (int)n_states, v->d_states[prev], v->d_states[cur], v->d_seg, L, sP);
   HIP_TRY(hipGetLastError());
-  if (v->profiling) HIP_TRY(hipEventRecord(tm.b, v->stream));
-  if (ra_voice_launch_render(v->p, v->d_jobs, v->d_slot_begin, v->d_states[prev], v->d_states[cur], S, n, L, g_log2, d_out, v->stream) != 0)
+  if (v->profiling) HIP_TRY(hipEventRecord(tm.b, sP));
+  HIP_TRY(hipEventRecord(v->ev_pre_done[bs], sP));
+  HIP_TRY(hipStreamWaitEvent(sR, v->ev_pre_done[bs], 0));
+  if (v->profiling) HIP_TRY(hipEventRecord(tm.b2, sR));
+  if (ra_voice_launch_render(v->p, v->d_jobs[bs], v->d_slot_begin[bs], v->d_states[prev], v->d_states[cur], S, n, L, g_log2, d_out, sR) != 0)
     return fail(RA_EHIP, "ra_voice: the render launch was refused (too many (stream, tile) units, or hipFuncSetAttribute failed)");
   HIP_TRY(hipGetLastError());
-  if (v->profiling) { HIP_TRY(hipEventRecord(tm.c, v->stream)); v->timed.push_back(tm); ++v->launches[0]; ++v->launches[1]; }
+  HIP_TRY(hipEventRecord(v->ev_render_done[bs], sR));
+  v->set_used[bs] = true;
+  if (v->profiling) { HIP_TRY(hipEventRecord(tm.c, sR)); v->timed.push_back(tm); ++v->launches[0]; ++v->launches[1]; }
   lap(tp, 5);
   ++v->host_blocks;
   v->parity ^= 1;
+  v->state_idx = (v->state_idx + 1) % 3;
   v->t += n;
   return RA_OK;
 }
@@ -2385,13 +2415,14 @@ int64_t ra_voice_dropped_note_ons(ra_voice *v) {
 int ra_voice_get_kernel_ms(ra_voice *v, double *ms2, int64_t *launches2, int32_t reset) {
   if (!v) return fail(RA_EINVAL, "null context");
   HIP_TRY(hipSetDevice(v->device));
+  HIP_TRY(hipStreamSynchronize(v->pre_stream));
   HIP_TRY(hipStreamSynchronize(v->stream));
   for (auto &t : v->timed) {
     float a = 0.f, b = 0.f;
     HIP_TRY(hipEventElapsedTime(&a, t.a, t.b));
-    HIP_TRY(hipEventElapsedTime(&b, t.b, t.c));
+    HIP_TRY(hipEventElapsedTime(&b, t.b2, t.c));
     v->ms[0] += a; v->ms[1] += b;
-    v->ev_pool.push_back(t.a); v->ev_pool.push_back(t.b); v->ev_pool.push_back(t.c);
+    v->ev_pool.push_back(t.a); v->ev_pool.push_back(t.b); v->ev_pool.push_back(t.b2); v->ev_pool.push_back(t.c);
   }
   v->timed.clear();
   if (ms2) { ms2[0] = v->ms[0]; ms2[1] = v->ms[1]; }

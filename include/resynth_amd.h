@@ -397,15 +397,16 @@ int ra_voice_events(ra_voice *v, const ra_voice_event *h_events, int64_t n_event
 int ra_voice_process_host(ra_voice *v, int64_t n_frames, float *h_out);
 /* the same with the output resident in HBM: d_out [n_streams][n_frames][2] float32 (DEVICE pointer); returns when the block is done */
 int ra_voice_process_device(ra_voice *v, int64_t n_frames, float *d_out);
-/* hipStream_t on which every later call enqueues its work (NULL = the null stream) */
+/* hipStream_t on which every later call enqueues the work that writes d_out (NULL = the null stream) */
 int ra_voice_set_hip_stream(ra_voice *v, void *hip_stream);
-/* ra_voice_process_device without the wait: the block's bookkeeping runs on the host, its kernels and copies are enqueued on the
- * object's stream and the call returns; d_out is complete when the stream has drained (hipStreamSynchronize / ra_voice_synchronize). */
+/* ra_voice_process_device without the wait: the block's bookkeeping runs on the host, its render is enqueued on the object's stream
+ * and the call returns; d_out is complete when that stream has drained (hipStreamSynchronize / ra_voice_synchronize).  The block's
+ * copies and state pre-pass run on a queue the object owns, which the render waits for: block k + 1's pre-pass beside block k's render. */
 int ra_voice_process_device_async(ra_voice *v, int64_t n_frames, float *d_out);
 int ra_voice_synchronize(ra_voice *v);
 /* note-ons that found no channel (onDroppedNote), all streams; negative RA_E* on error */
 int64_t ra_voice_dropped_note_ons(ra_voice *v);
-/* device time of the two kernels of a block, accumulated since the last call with reset != 0 (HIP events on the object's stream):
+/* device time of the two kernels of a block, accumulated since the last call with reset != 0 (HIP events on the queue each runs on):
  * ms2 = {state pre-pass, render}, launches2 likewise; synchronises */
 int ra_voice_get_kernel_ms(ra_voice *v, double *ms2, int64_t *launches2, int32_t reset);
 
