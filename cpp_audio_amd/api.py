@@ -80,7 +80,7 @@ EXPORTED_SYMBOLS = [
     "ra_synchronize",
     "ra_feed", "ra_compute", "ra_get_stats", "ra_get_events", "ra_get_frame_pitches", "ra_resynth_notes", "ra_sqmag",
     "ra_set_profiling", "ra_get_kernel_ms", "ra_get_kernel_launches", "ra_render_note",
-    "ra_carrier_events", "ra_get_carrier", "ra_set_pipeline_serial", "ra_deduce_notes",
+    "ra_carrier_events", "ra_get_carrier", "ra_set_pipeline_serial", "ra_deduce_notes", "ra_deduce_notes_batch",
     "ra_voice_default_config", "ra_voice_program", "ra_voice_expand_note", "ra_voice_create", "ra_voice_destroy", "ra_voice_events", "ra_voice_process_host", "ra_voice_process_device",
     "ra_voice_process_device_async", "ra_voice_set_hip_stream", "ra_voice_synchronize", "ra_voice_get_kernel_ms", "ra_voice_dropped_note_ons",
 ]
@@ -117,6 +117,8 @@ def lib():
         L.ra_resynth_notes.restype = C.c_int64
         L.ra_deduce_notes.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]
         L.ra_deduce_notes.restype = C.c_int64
+        L.ra_deduce_notes_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
+        L.ra_deduce_notes_batch.restype = C.c_int64
         L.ra_sqmag.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]
         L.ra_set_profiling.argtypes = [C.c_void_p, C.c_int32]
         L.ra_set_pipeline_serial.argtypes = [C.c_void_p, C.c_int32]
@@ -306,6 +308,20 @@ def deduce_notes(signal, sr, half_window_size, window_center_stride, window_kind
     if n:
         _check(lib().ra_deduce_notes(_p(x), len(x), sr, half_window_size, window_kind, window_center_stride, device, _p(notes), n))
     return notes
+
+
+def deduce_notes_batch(signals, sr, half_window_size, window_center_stride, window_kind=0, device=0):
+    """ra_deduce_notes_batch: [n_signals][n_frames] float32 -> a list of note arrays, one per signal (one context, one analysis launch sequence)."""
+    x = np.ascontiguousarray(signals, np.float32)
+    if x.ndim != 2:
+        raise ValueError("signals must be [n_signals][n_frames]")
+    S, n = x.shape
+    offs = np.zeros(S + 1, np.int64)
+    total = _check(lib().ra_deduce_notes_batch(_p(x), S, n, sr, half_window_size, window_kind, window_center_stride, device, None, 0, _p(offs)))
+    notes = np.zeros(total, NOTE_DTYPE)
+    if total:
+        _check(lib().ra_deduce_notes_batch(_p(x), S, n, sr, half_window_size, window_kind, window_center_stride, device, _p(notes), total, _p(offs)))
+    return [notes[offs[s]:offs[s + 1]] for s in range(S)]
 
 
 VOICE_BIRDS, VOICE_ROBOTS, VOICE_SWEEP, VOICE_WIND = 0, 1, 2, 3

@@ -1603,58 +1603,22 @@ int ra_sqmag(const float *h_windows, int32_t n_windows, int32_t window_size, int
 }
 
 // deduceNotesSlow as main.resynth uses it (main.resynth.cpp:39-46): see include/resynth_amd.h for what is built and why.
-int64_t ra_deduce_notes(const float *h_signal, int64_t n, int32_t sample_rate, int32_t half_window_size, int32_t window_kind, int32_t stride,
-                        int32_t device, ra_note *h_notes, int64_t cap) {
-  if (!h_signal || n < 0) return fail(RA_EINVAL, "bad signal");
-  if (half_window_size < 1 || stride < 1) return fail(RA_EINVAL, "bad half window size / stride");
-  if (cap < 0 || (cap > 0 && !h_notes)) return fail(RA_EINVAL, "bad notes buffer");
-  ra_config cfg;
-  ra_default_config(&cfg);
-  cfg.sample_rate = sample_rate;
-  cfg.window_size = 2 * half_window_size;
-  cfg.stride = stride;
-  cfg.window_kind = window_kind;
-  cfg.n_channels = 2;
-  cfg.min_volume = 0.f;            // every peak is kept ...
-  cfg.nearby_distance_tones = 0.f; // ... as an interval of its own: the frame lists are the peaks (pitch, 10^(dB/20)) in ascending pitch
-  cfg.analysis_volume = 0.f;       // nothing is synthesised
-  cfg.carrier_volume = 0.f;
-  cfg.max_pitches_per_frame = std::min(4096, std::max(64, fft_length_for(cfg.window_size) / 4));
-  ra_context *c = nullptr;
-  int r = ra_create(&cfg, 1, device, &c);
-  if (r) return r;
-  // PeriodicFFT swallows input samples 0 and 1 in the offline job (SURVEY §3B): two leading zeros put frame h on signal[h * stride ...)
-  std::vector<float> in(static_cast<size_t>(n) + 2, 0.f), out((static_cast<size_t>(n) + 2) * 2);
-  std::memcpy(in.data() + 2, h_signal, sizeof(float) * static_cast<size_t>(n));
-  r = ra_process_host(c, in.data(), nullptr, n + 2, out.data());
-  std::vector<int64_t> fire, offs;
-  std::vector<double> pitch, vol;
-  int64_t nf = 0;
-  if (!r) {
-    nf = c->last_nfb;
-    fire.resize(nf + 1); offs.resize(nf + 2);
-    size_t items = static_cast<size_t>(nf) * c->p.maxr + 1;
-    pitch.resize(items); vol.resize(items);
-    int64_t got = ra_get_frame_pitches(c, 0, fire.data(), offs.data(), nf + 1, pitch.data(), vol.data(), static_cast<int64_t>(items));
-    if (got < 0) r = static_cast<int>(got);
-  }
-  std::string keep = g_last_error;
-  ra_destroy(c);
-  g_last_error = keep;
-  if (r) return r;
-  // linking, with track_pitches' scan (algo.cpp:256-305): open notes and peaks both ascend in pitch
+namespace {
+// linking, with track_pitches' scan (algo.cpp:256-305): open notes and peaks both ascend in pitch; one linker per signal, fed frame by frame
+struct NoteLinker {
   struct Open { int32_t start, last; double last_pitch, sum_v, sum_pv, max_db; };
   std::vector<Open> open, next;
+  std::vector<char> cont;
   std::vector<ra_note> notes;
-  auto close = [&](const Open &o) {
+  void close(const Open &o) {
     const double mean_pitch = o.sum_pv / o.sum_v;
     notes.push_back({o.start, o.last, 440.0 * std::pow(2.0, (mean_pitch - 69.0) / 12.0), o.max_db});
-  };
-  for (int64_t h = 0; h < nf; ++h) {
+  }
+  void frame(int64_t h, const double *pitch, const double *vol, int count) {
     next.clear();
     size_t it = 0;
-    std::vector<char> cont(open.size(), 0);
-    for (int64_t i = offs[h]; i < offs[h + 1]; ++i) {
+    cont.assign(open.size(), 0);
+    for (int i = 0; i < count; ++i) {
       const double pt = pitch[i], v = vol[i];
       if (!(v > 0.0)) continue;
       const double db = 20.0 * std::log10(v);
@@ -1675,10 +1639,96 @@ int64_t ra_deduce_notes(const float *h_signal, int64_t n, int32_t sample_rate, i
     std::stable_sort(next.begin(), next.end(), [](const Open &a, const Open &b) { return a.last_pitch < b.last_pitch; }); // sort_by_current_pitch, algo.cpp:434-439
     open.swap(next);
   }
-  for (const Open &o : open) close(o);
-  const int64_t total = static_cast<int64_t>(notes.size());
-  for (int64_t i = 0; i < total && i < cap; ++i) h_notes[i] = notes[i];
-  return total;
+  void finish() { for (const Open &o : open) close(o); open.clear(); }
+};
+} // namespace
+
+// n_signals signals of n frames each through ONE context: the analysis of all of them is one launch sequence per block (blocks of at most
+// 2^18 frames bound the buffers), the frame lists of a block come back in three strided copies and every signal's linker runs on a host thread.
+int64_t ra_deduce_notes_batch(const float *h_signals, int32_t n_signals, int64_t n, int32_t sample_rate, int32_t half_window_size, int32_t window_kind, int32_t stride,
+                              int32_t device, ra_note *h_notes, int64_t cap, int64_t *h_offsets) {
+  if (!h_signals || n < 0 || n_signals < 1) return fail(RA_EINVAL, "bad signals");
+  if (half_window_size < 1 || stride < 1) return fail(RA_EINVAL, "bad half window size / stride");
+  if (cap < 0 || (cap > 0 && !h_notes)) return fail(RA_EINVAL, "bad notes buffer");
+  ra_config cfg;
+  ra_default_config(&cfg);
+  cfg.sample_rate = sample_rate;
+  cfg.window_size = 2 * half_window_size;
+  cfg.stride = stride;
+  cfg.window_kind = window_kind;
+  cfg.n_channels = 2;
+  cfg.min_volume = 0.f;            // every peak is kept ...
+  cfg.nearby_distance_tones = 0.f; // ... as an interval of its own: the frame lists are the peaks (pitch, 10^(dB/20)) in ascending pitch
+  cfg.analysis_volume = 0.f;       // nothing is synthesised
+  cfg.carrier_volume = 0.f;
+  cfg.max_pitches_per_frame = std::min(4096, std::max(64, fft_length_for(cfg.window_size) / 4));
+  ra_context *c = nullptr;
+  int r = ra_create(&cfg, n_signals, device, &c);
+  if (r) return r;
+  const size_t S = static_cast<size_t>(n_signals);
+  // PeriodicFFT swallows input samples 0 and 1 in the offline job (SURVEY §3B): two leading zeros put frame h on signal[h * stride ...)
+  const int64_t total = n + 2, B = std::min<int64_t>(total, int64_t(1) << 18);
+  float *d_in = nullptr, *d_out = nullptr;
+  std::vector<float> stage(S * static_cast<size_t>(B));
+  std::vector<int32_t> counts;
+  std::vector<double> pitch, vol;
+  std::vector<NoteLinker> linkers(S);
+  auto body = [&]() -> int {
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_in), S * B * sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_out), S * B * 2 * sizeof(float)));
+    for (int64_t t = 0; t < total; t += B) {
+      const int64_t len = std::min(B, total - t);
+      for (size_t s = 0; s < S; ++s) {
+        float *dst = stage.data() + s * len;
+        const float *src = h_signals + s * static_cast<size_t>(n);
+        for (int64_t i = 0; i < len; ++i) { const int64_t a = t + i - 2; dst[i] = a >= 0 ? src[a] : 0.f; }
+      }
+      HIP_TRY(hipMemcpy(d_in, stage.data(), S * len * sizeof(float), hipMemcpyHostToDevice));
+      RA_TRY(ra_process_device(c, d_in, nullptr, len, d_out));
+      RA_TRY(ra_synchronize(c));
+      const int64_t nfb = c->last_nfb, f_lo = c->last_f_lo;
+      if (nfb == 0) continue;
+      const size_t maxr = c->p.maxr, row = static_cast<size_t>(nfb) * maxr;
+      counts.resize(S * nfb); pitch.resize(S * row); vol.resize(S * row);
+      HIP_TRY(hipMemcpy2D(counts.data(), nfb * sizeof(int32_t), c->b.pl_count, c->b.frames_cap * sizeof(int32_t), nfb * sizeof(int32_t), S, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy2D(pitch.data(), row * sizeof(double), c->b.pl_pitch, c->b.frames_cap * maxr * sizeof(double), row * sizeof(double), S, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy2D(vol.data(), row * sizeof(double), c->b.pl_vol, c->b.frames_cap * maxr * sizeof(double), row * sizeof(double), S, hipMemcpyDeviceToHost));
+      const int threads = static_cast<int>(std::min<size_t>(S, std::max(1u, std::thread::hardware_concurrency() / 2)));
+      auto work = [&](int tix) {
+        for (size_t s = tix; s < S; s += threads)
+          for (int64_t fb = 0; fb < nfb; ++fb)
+            linkers[s].frame(f_lo + fb, pitch.data() + s * row + fb * maxr, vol.data() + s * row + fb * maxr, counts[s * nfb + fb]);
+      };
+      if (threads == 1) work(0);
+      else {
+        std::vector<std::thread> th;
+        for (int tix = 0; tix < threads; ++tix) th.emplace_back(work, tix);
+        for (auto &x : th) x.join();
+      }
+    }
+    return RA_OK;
+  };
+  r = body();
+  std::string keep = g_last_error;
+  (void)hipFree(d_in); (void)hipFree(d_out);
+  ra_destroy(c);
+  g_last_error = keep;
+  if (r) return r;
+  int64_t at = 0;
+  for (size_t s = 0; s < S; ++s) {
+    linkers[s].finish();
+    if (h_offsets) h_offsets[s] = at;
+    for (const ra_note &nt : linkers[s].notes) { if (at < cap) h_notes[at] = nt; ++at; }
+  }
+  if (h_offsets) h_offsets[S] = at;
+  return at;
+}
+
+int64_t ra_deduce_notes(const float *h_signal, int64_t n, int32_t sample_rate, int32_t half_window_size, int32_t window_kind, int32_t stride,
+                        int32_t device, ra_note *h_notes, int64_t cap) {
+  if (!h_signal) return fail(RA_EINVAL, "bad signal");
+  return ra_deduce_notes_batch(h_signal, 1, n, sample_rate, half_window_size, window_kind, stride, device, h_notes, cap, nullptr);
 }
 
 // One note on one driver-(A) element, starting from a given oscillator phasor.  This is what the element duck-type shim

@@ -298,6 +298,12 @@ int64_t ra_resynth_notes(const ra_note *notes, int32_t n_notes, int32_t stride, 
  */
 int64_t ra_deduce_notes(const float *h_signal, int64_t n_frames, int32_t sample_rate, int32_t half_window_size, int32_t window_kind,
                         int32_t window_center_stride, int32_t device, ra_note *h_notes, int64_t cap);
+/* The same for n_signals signals of n_frames each (h_signals [n_signals][n_frames], HOST pointer) through one context: one analysis launch
+ * sequence per block over all of them, every signal's linking on a host thread.  The notes of signal s are
+ * h_notes[h_offsets[s] .. h_offsets[s + 1]) (h_offsets [n_signals + 1], may be NULL); returns the total number of notes (the first `cap`
+ * stored) or a negative RA_E* code.  A batch of 256 signals of 10 s is one call, not 256 contexts (main.resynth.cpp:39-46 over a folder). */
+int64_t ra_deduce_notes_batch(const float *h_signals, int32_t n_signals, int64_t n_frames, int32_t sample_rate, int32_t half_window_size, int32_t window_kind,
+                              int32_t window_center_stride, int32_t device, ra_note *h_notes, int64_t cap, int64_t *h_offsets);
 
 /* audioelement::AHDSR (include/audioelement.h:314-335) in frames; every interpolation is itp::LINEAR on this path */
 typedef struct ra_ahdsr {

@@ -93,6 +93,27 @@ def test_deduce_notes_matches_oracle(api, oracle):
         assert abs(best["start_frame"] * 400 / sr - t0) < 0.05 and abs(best["end_frame"] * 400 / sr - t1) < 0.05, (f, best)
 
 
+def test_deduce_notes_batch_equals_one_call_per_signal_and_the_oracle(api, oracle):
+    # ra_deduce_notes_batch: many signals through ONE context (one analysis launch sequence per block over all of them, a linker thread per
+    # signal); a long signal is cut into blocks of 2^18 frames, which must not show.  Same notes as one call per signal, and as the oracle.
+    sr = 44100
+    base = three_tone_signal(sr, 7.0)                     # 308 700 frames: two blocks
+    rng = np.random.default_rng(3)
+    sigs = np.stack([np.roll(base, 997 * k) * (0.5 + 0.1 * k) + 1e-4 * rng.standard_normal(len(base)).astype(np.float32) for k in range(5)]).astype(np.float32)
+    got = api.deduce_notes_batch(sigs, sr, 400, 400)
+    assert len(got) == 5
+    for k in range(5):
+        one = api.deduce_notes(sigs[k], sr, 400, 400)
+        assert len(got[k]) == len(one) > 4 and np.array_equal(got[k], one)
+    st, en, fr, am = oracle.deduce_notes(sigs[2], sr, 400, 400)
+    g = got[2]
+    assert len(g) == len(st)
+    assert np.array_equal(g["start_frame"], st) and np.array_equal(g["end_frame"], en)
+    assert np.max(np.abs(g["frequency"] / fr - 1.0)) < 1e-12 and np.max(np.abs(g["amplitude_db"] - am)) < 1e-10
+    with pytest.raises(api.RaError):
+        api.deduce_notes_batch(np.zeros((0, 10), np.float32), sr, 400, 400)
+
+
 def test_driver_a_end_to_end_wav_to_notes_to_wav(api, oracle, tmp_path, run_program):
     # main.resynth (source/main.resynth.cpp:5-81): WAV -> deduceNotesSlow -> 60 dB filter -> resynth -> WAV, all on the HIP backend
     from scipy.io import wavfile
