@@ -310,13 +310,14 @@ def time_voice(api, torch, dev, which, S, seconds, steps):
     their own (ra_voice_process_device_async): the host's share of block k + 1 (events, Markov chains, schedules, job tables) runs while the
     device renders block k, as the headline's blocks do.  `kernel_ms` = HIP events around the two kernels of a block."""
     n = int(round(seconds * SR))
-    cfg, rows, desc = voice_workload(api, which, S, seconds, steps + 2)
+    cfg, rows, desc = voice_workload(api, which, S, seconds, steps + 4)
     out = torch.empty(S, n, 2, dtype=torch.float32, device=dev)
     st = torch.cuda.Stream()
     with api.Voice(cfg, S, 0) as v:
         v.set_hip_stream(st.cuda_stream)
         v.events(rows)
-        v.process_device(n, out.data_ptr())   # warm-up block
+        for _ in range(3):                    # warm-up blocks: every one of the object's double / triple buffers has been sized once
+            v.process_device(n, out.data_ptr())
         v.kernel_ms(reset=True)
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -608,7 +609,7 @@ def main():
                     o["target"] = ">= 10 x real time for each of the 1000 streams (BASELINE.json north_star)"
                 others.append(o)
             for name in ("voice_sweep", "voice_birds", "voice_robots"):
-                o = time_voice(api, torch, dev, wl[name][0], wl[name][1], 10.0, 4)
+                o = time_voice(api, torch, dev, wl[name][0], wl[name][1], 10.0, 6)
                 o["workload"] = name
                 others.append(o)
             if shim_result is not None:

@@ -2108,7 +2108,11 @@ int ra_voice_create(const ra_voice_config *cfg, int32_t n_streams, int32_t devic
   for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&v->staging[i].done, hipEventDisableTiming);
   for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&v->ev_pre_done[i], hipEventDisableTiming);
   for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&v->ev_render_done[i], hipEventDisableTiming);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&v->pre_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) { // above the caller's stream in dispatch priority: beside a render whose grid fills the chip an equal-priority queue waits for the grid's tail
+    int prio_least = 0, prio_greatest = 0;
+    e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&v->pre_stream, hipStreamNonBlocking, prio_greatest);
+  }
   if (e != hipSuccess) { ra_voice_destroy(v); return fail(RA_EHIP, std::string("ra_voice_create: ") + hipGetErrorString(e)); }
   *out = v;
   return RA_OK;
@@ -2375,10 +2379,14 @@ int voice_block(ra_voice *v, int64_t n, float *d_out) {
   static_assert(sizeof(RaVoiceJob) == 120, "layout of the job record");
   const int bs = v->parity, cur = v->state_idx, prev = (cur + 2) % 3;
   hipStream_t sP = v->pre_stream, sR = v->stream;
-  RA_TRY(voice_grow(&v->d_jobs[bs], v->jobs_cap[bs], n_jobs + 1, v));
-  RA_TRY(voice_grow(&v->d_order[bs], v->order_cap[bs], n_work + 1, v));
-  RA_TRY(voice_grow(&v->d_slot_begin[bs], v->slots_cap[bs], n_slots, v));
-  RA_TRY(voice_grow(&v->d_states[cur], v->states_cap[cur], n_states + 1, v));
+  // (a buffer that must grow drains both queues first: its twin and the third state array grow with it, so that blocks of a steady size stop
+  // growing anything after the first one; the array holding the carry-in keeps its contents and its size)
+  for (int q : {bs, bs ^ 1}) {
+    RA_TRY(voice_grow(&v->d_jobs[q], v->jobs_cap[q], n_jobs + 1, v));
+    RA_TRY(voice_grow(&v->d_order[q], v->order_cap[q], n_work + 1, v));
+    RA_TRY(voice_grow(&v->d_slot_begin[q], v->slots_cap[q], n_slots, v));
+  }
+  for (int q : {cur, (cur + 1) % 3}) RA_TRY(voice_grow(&v->d_states[q], v->states_cap[q], n_states + 1, v));
   RA_TRY(voice_grow(&v->d_seg, v->seg_cap, n_states + 1, v));
   if (!v->d_states[prev]) RA_TRY(voice_grow(&v->d_states[prev], v->states_cap[prev], 1, v));
   // this set and this state array were last read by the render of the block before last
