@@ -1667,7 +1667,10 @@ int64_t ra_deduce_notes_batch(const float *h_signals, int32_t n_signals, int64_t
   if (r) return r;
   const size_t S = static_cast<size_t>(n_signals);
   // PeriodicFFT swallows input samples 0 and 1 in the offline job: two leading zeros put frame h on signal[h * stride ...)
-  const int64_t total = n + 2, B = std::min<int64_t>(total, int64_t(1) << 18);
+  // block length: at most 2^18 frames, and few enough analysis frames that a block's lists (16 B per item and signal on the host) stay near 1 GB
+  const int64_t total = n + 2;
+  const int64_t frames_budget = std::max<int64_t>(8, (int64_t(1) << 30) / (int64_t(n_signals) * c->p.maxr * 16));
+  const int64_t B = std::min<int64_t>(total, std::min<int64_t>(int64_t(1) << 18, frames_budget * stride + cfg.window_size));
   float *d_in = nullptr, *d_out = nullptr;
   std::vector<float> stage(S * static_cast<size_t>(B));
   std::vector<int32_t> counts;
