@@ -363,7 +363,7 @@ def workloads(N=4096, H=1024, P=64):
 def time_config(api, torch, dev, name, cfg_kw, S, seconds, steps, carrier=None):
     """An `other_configs` entry: full-size timing of another BASELINE config (same issue mode and clock as the headline)."""
     n = int(round(seconds * SR))
-    warm = 2
+    warm = 3
     r = Runner(api, torch, dev, 0, cfg_kw, S, n, 4321, carrier=carrier, total_steps=warm + steps + 7)
     for _ in range(warm):
         r.step()
@@ -394,8 +394,8 @@ def time_config(api, torch, dev, name, cfg_kw, S, seconds, steps, carrier=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: configs[1]'s 256; with --gpus 8 and no stream option: configs[4], see below)")
     ap.add_argument("--streams-total", type=int, default=0, help="total streams, sharded over the ranks; overrides --streams.  `--gpus 8` without a stream option "
                     "runs BASELINE configs[4]: 8000 streams over the 8 GPUs = 1000 per rank")
@@ -465,18 +465,37 @@ def main():
         run.step()
     run.finish()
     ctx.synchronize()
-    ctx.set_profiling(True)   # HIP events on the launch stream around every kernel (ra_set_profiling)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run.step()
-    run.finish()
-    barrier()
-    dt = time.perf_counter() - t0
-    ctx.synchronize()         # raises on device-side error flags
-    kms, calls = ctx.kernel_ms()
-    launches = ctx.kernel_launches()
-    ctx.set_profiling(False)
+
+    def timed_region():
+        ctx.set_profiling(True)   # HIP events on the launch stream around every kernel (ra_set_profiling)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run.step()
+        run.finish()
+        barrier()
+        dt_ = time.perf_counter() - t0
+        ctx.synchronize()         # raises on device-side error flags
+        kms_, calls_ = ctx.kernel_ms()
+        launches_ = ctx.kernel_launches()
+        ctx.set_profiling(False)
+        return dt_, kms_, calls_, launches_
+
+    dt, kms, calls, launches = timed_region()
+    # A stall that is not the GPU's work (seen once in ~ a hundred runs on the shared boxes: 240 ms of wall clock around five steps whose queues
+    # were busy for 10 ms each) is not a measurement of this path: if the K steps took more than twice what their busiest queue was busy
+    # for (HIP events), they are timed once more — K steps again, the same way — and the line says so (`retimed`).
+    retimed = None
+    busiest = max(kms[k] for k in STAGES) / max(calls, 1) * 1e-3
+    flag = 1.0 if (busiest > 0 and dt / args.steps > 2.0 * busiest + 1e-3) else 0.0
+    if world > 1:
+        ft = torch.tensor([flag], dtype=torch.float64)
+        dist.all_reduce(ft, op=dist.ReduceOp.MAX)
+        flag = float(ft[0].item())
+    if flag:
+        retimed = {"first_ms_per_step": dt / args.steps * 1e3, "busiest_queue_ms_per_step": busiest * 1e3,
+                   "why": "the first K steps took more than twice the time their busiest queue was busy (a stall outside the GPU's work); K steps were timed again, once"}
+        dt, kms, calls, launches = timed_region()
     st = ctx.stats()
     total_streams = S
     if world > 1:
@@ -546,7 +565,7 @@ def main():
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True,
             # configs[4] fixes 1000 streams per GPU: the per-GPU work is what the config names, whatever N would be
-            "scaling": "weak" if (not args.streams_total or configs4) else "strong", "vs_baseline": None,
+            "scaling": "weak" if (not args.streams_total or configs4) else "strong", "vs_baseline": None, "retimed": retimed,
             "dtype": "f64", "data": "synthetic", "issue": "stream-ordered" if args.stream_ordered else "overlapped blocks (ra_process_device_async)",
             "config": {"workload": f"{'configs[4]: 8000 streams over 8 GPUs, ' if configs4 else 'configs[1]: '}{S} mono streams/GPU x {args.seconds:g} s @ 48 kHz, window {N} (Gaussian 4 sigma) / FFT {N}, "
                                    f"stride {H} (75% overlap), {P} partials, analysis_volume 1, stereo_spread 0, post none",
@@ -601,7 +620,7 @@ def main():
         others = []
         try:
             wl = workloads(N, H, P)
-            for name, steps in (("north_star", 3), ("stereo", 3), ("voc_fft", 3), ("voc_bank", 8), ("configs3", 2)):
+            for name, steps in (("north_star", 5), ("stereo", 6), ("voc_fft", 5), ("voc_bank", 8), ("configs3", 4)):
                 desc, kw, S2, carrier = wl[name]
                 o = time_config(api, torch, dev, desc, kw, S2, 10.0, steps, carrier=carrier)
                 o["workload"] = name

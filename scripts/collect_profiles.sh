@@ -19,7 +19,7 @@ mkdir -p $OUT
 cd $ROOT
 if [ "$PART" = headline ]; then
   if [ -z "$SKIP_BENCH" ]; then
-    python bench.py --steps 5 --warmup 1 > $OUT/bench_full.log 2>&1 || { tail -5 $OUT/bench_full.log; exit 1; }
+    python bench.py > $OUT/bench_full.log 2>&1 || { tail -5 $OUT/bench_full.log; exit 1; }
     grep '^{"metric"' $OUT/bench_full.log > $OUT/bench.json
   fi
   cd /tmp && export TMPDIR=/tmp
