@@ -245,11 +245,17 @@ __device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, dou
   double va = alias * value - (HI ? al_da * value : 0.0); // = w_{-1} = (alias - al_da) * value
   double d1 = HI ? fma(al_da, value, (alias - al_da) * r.dv) + al_da * r.dv : alias * r.dv; // w_0 - w_{-1}
   const double d2 = HI ? 2.0 * (al_da * r.dv) : 0.0;
+  // A full tile whose filter coefficient does not follow the increment needs the glide's time `cur` only at its end: the affine step
+  // cur' = alpha cur + beta is then composed with itself by doubling (A_2n = A_n^2, B_2n = A_n B_n + B_n) and applied as 16 + 8 + 4 + 2 + 1
+  // steps (the increment of the last step wants cur one step before the end), 15 instructions instead of 33 per tile.
+  constexpr bool CLOSED = GLIDE && !KVAR && (LEN == 8 || LEN == 16 || LEN == 32);
   auto step = [&](auto first_tag) -> double {
     constexpr bool FIRST = decltype(first_tag)::value;
     if (GLIDE) {
-      f = fma(r.slope, cur, r.base);
-      cur = fma(r.alpha, cur, r.beta);
+      if (!CLOSED) {
+        f = fma(r.slope, cur, r.base);
+        cur = fma(r.alpha, cur, r.beta);
+      }
       double mr, mi;
       if (FIRST) { mr = fma(mre, cd0, -(mim * sd0)); mi = fma(mre, sd0, mim * cd0); }
       else { mr = fma(-tnr, mim, mre); mi = fma(tnr, mre, mim); tnr *= r.alpha; }
@@ -283,6 +289,17 @@ __device__ inline void clean_tile(Chan &c, Regime &r, double max_filter_inc, dou
     for (int i = 1; i < LEN; ++i) put(i, step(std::false_type{}));
   } else {
     for (int i = 1; i < len; ++i) put(i, step(std::false_type{}));
+  }
+  if (CLOSED) {
+    constexpr int LG = LEN == 32 ? 5 : LEN == 16 ? 4 : 3;
+    double A[LG], B[LG];
+    A[0] = r.alpha; B[0] = r.beta;
+#pragma unroll
+    for (int q = 1; q < LG; ++q) { A[q] = A[q - 1] * A[q - 1]; B[q] = fma(A[q - 1], B[q - 1], B[q - 1]); }
+#pragma unroll
+    for (int q = LG - 1; q >= 0; --q) cur = fma(A[q], cur, B[q]); // LEN - 1 steps
+    f = fma(r.slope, cur, r.base);
+    cur = fma(r.alpha, cur, r.beta);
   }
   const double g = 0.5 * (3.0 - fma(cre, cre, cim * cim));
   c.cre = cre * g; c.cim = cim * g;
