@@ -92,3 +92,22 @@ def test_voice_full_size_block_cuts(env, oracle, which):
         ref, dropped = oracle.voice_run(oracle.voice_params_from(cfg, cfg.seed + s), [(r[0], r[2], r[3], r[4], r[5]) for r in rows if r[1] == s], n)
         got = outs[0][s].cpu().numpy()
         assert dropped == 0 and np.sqrt(np.mean((got.astype(np.float64) - ref) ** 2)) <= 6e-8, s
+
+
+def test_note_deduction_of_a_batch_at_full_size(env):
+    # driver (A) over a folder: 64 signals of 10 s (main.resynth's half window 400 / stride 400) through ra_deduce_notes_batch — one context, two blocks —
+    # against single calls for a sample of them; notes come out ordered by closing frame, every note spans at least one frame and lies inside the signal
+    torch, bench, api = env
+    sr, S = 44100, 64
+    x = bench.synth_inputs_torch(S, 10 * sr, sr, 99, torch.device("cuda", 0)).cpu().numpy()
+    got = api.deduce_notes_batch(x, sr, 400, 400)
+    assert len(got) == S
+    n_frames = 10 * sr // 400 + 1
+    for s in range(S):
+        g = got[s]
+        assert len(g) > 10
+        assert np.all(g["start_frame"] <= g["end_frame"]) and g["start_frame"].min() >= 0 and g["end_frame"].max() <= n_frames
+        assert np.all(np.diff(g["end_frame"]) >= 0)
+        assert np.all(g["frequency"] > 0) and np.all(np.isfinite(g["amplitude_db"]))
+    for s in (0, 31, 63):
+        assert np.array_equal(got[s], api.deduce_notes(x[s], sr, 400, 400))
