@@ -39,7 +39,8 @@ FP64_VALU_PEAK_TFLOPS = 78.6   # nominal vector fp64
 # and SIMD with >= 2 waves resident (~70 % of nominal) and 4.4 ns with one wave.
 VALU_PEAK_GINST = 1024 * 2.4 / 4.0
 SR = 48000
-STAGES = ("analysis", "track", "vocoder", "propagate", "render", "history")
+STAGES = ("analysis", "track", "vocoder", "propagate", "render", "history", "prep")
+COMPACT_LIMIT = 4096           # bytes: the driver keeps an 8 KB tail of stdout and parses its last line
 
 
 def algo_flops_per_frame(N, H, P):
@@ -391,6 +392,103 @@ def time_config(api, torch, dev, name, cfg_kw, S, seconds, steps, carrier=None):
     return res
 
 
+def _sig(x, digits=5):
+    """floats rounded to `digits` significant figures (the compact line carries figures, not bit patterns)"""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}") if math.isfinite(x) else None
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(result, details_path=None):
+    """The LAST stdout line: the headline object the driver parses, < COMPACT_LIMIT bytes whatever the detail holds (the single
+    30 KB line of r03 did not survive the driver's 8 KB tail).  Everything else goes to the detail file / the earlier stdout line."""
+    c = _pick(result, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                       "x_realtime_per_stream", "gpu_over_cpu", "csrc_sha256"))
+    cfg = result.get("config", {})
+    c["config"] = _pick(cfg, ("workload", "streams_per_gpu", "streams_total", "frames_per_stream_per_step", "sharding"))
+    roof_keys = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms_per_launch", "launches_per_step", "algorithmic_bytes_per_launch",
+                 "issue_frac", "kernel_selected_by")
+    if "roofline" in result:
+        c["roofline"] = _pick(result["roofline"], roof_keys)
+    if "roofline_second" in result:
+        c["roofline_second"] = _pick(result["roofline_second"], roof_keys[:-1])
+    if "cpu_baseline" in result:
+        c["cpu_baseline"] = _pick(result["cpu_baseline"], ("value", "unit", "cores", "kind", "sample", "gpu_vs_oracle_max_rms"))
+    v = result.get("valu", {})
+    c["valu"] = _pick(v, ("step_issue_frac", "achieved_tflops_fp64", "effective_clock_ghz", "step_issue_frac_at_held_clock"))
+    k = result.get("kernels", {})
+    c["kernel_ms_per_step"] = {name: {"alone": e.get("alone_ms_per_step"), "overlapped": e.get("overlapped_ms_per_step")} for name, e in k.items() if name != "history"}
+    others = {}
+    for o in result.get("other_configs", []) or []:
+        if "workload" in o and "ms_per_step" in o:
+            others[o["workload"]] = o["ms_per_step"]
+            if o["workload"] == "north_star":
+                c["north_star"] = {"ms_per_step": o["ms_per_step"], "x_realtime": o.get("x_realtime_per_stream"), "streams": o.get("streams"),
+                                   "pcie_inclusive_ms_per_step": (o.get("pcie_inclusive") or {}).get("ms_per_step")}
+        elif "error" in o:
+            others["error"] = str(o["error"])[:120]
+    if others:
+        c["other_ms_per_step"] = others
+    if "pcie_inclusive" in result:
+        c["pcie_inclusive"] = _pick(result["pcie_inclusive"], ("ms_per_step", "streams", "GBs_host_link"))
+    if result.get("retimed"):
+        c["retimed"] = _pick(result["retimed"], ("first_ms_per_step", "busiest_queue_ms_per_step"))
+    c["checks"] = result.get("checks")
+    if details_path:
+        c["details"] = details_path
+    c = _sig(c)
+    line = json.dumps(c, separators=(",", ":"))
+    # never let an unexpected field push the line past the limit: drop the optional blocks, least important first
+    for drop in ("other_ms_per_step", "kernel_ms_per_step", "roofline_second", "checks", "retimed", "pcie_inclusive", "valu", "north_star"):
+        if len(line) < COMPACT_LIMIT:
+            break
+        c.pop(drop, None)
+        line = json.dumps(c, separators=(",", ":"))
+    return line
+
+
+def emit(result, details_path, out=None):
+    """Writes the full result to `details_path` (and as an EARLIER stdout line), then the compact headline as the LAST stdout line."""
+    out = out or sys.stdout
+    where = None
+    if details_path:
+        try:
+            with open(details_path, "w") as f:
+                json.dump(result, f, indent=1)
+            where = os.path.relpath(details_path, ROOT) if os.path.abspath(details_path).startswith(ROOT) else details_path
+        except OSError:
+            where = None
+    out.write(json.dumps({"bench_details": result}) + "\n")
+    line = compact_line(result, where)
+    out.write(line + "\n")
+    out.flush()
+    return line
+
+
+def pcie_inclusive(api, torch, cfg, S, n, local_rank):
+    """The PCIe-inclusive rate DESIGN.md quotes beside `value` (never value itself): one block of S streams through ra_process_host — pageable
+    host buffers up, the block, float32 stereo down, synchronised — on a fresh context (its second block: the first sizes the staging)."""
+    import numpy as np
+    hv = (np.random.default_rng(7).standard_normal((S, n), dtype=np.float32) * 0.05)
+    with api.Context(cfg, S, local_rank) as c:
+        c.process_host(hv[:, :min(n, SR)])
+        c.reset()
+        c.process_host(hv)
+        t0 = time.perf_counter()
+        c.process_host(hv)
+        dt = time.perf_counter() - t0
+    return {"ms_per_step": dt * 1e3, "streams": S, "frames_per_stream": n, "GBs_host_link": 12.0 * S * n / dt / 1e9,
+            "how": "ra_process_host: H2D of [S][n] float32 from pageable memory, the block, D2H of [S][n][2] float32, synchronised"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -407,6 +505,11 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="only the headline (profiling runs)")
     ap.add_argument("--stream-ordered", action="store_true", help="issue every block with ra_process_device (no overlap between consecutive blocks)")
     ap.add_argument("--cpu-streams", type=int, default=0, help="streams in the CPU baseline sample (0 = all)")
+    ap.add_argument("--no-alone", action="store_true", help="skip the serialised extra steps (kernels{}.alone_ms): every ra_* launch of the run then belongs to the "
+                    "pipeline, which is what the rocprofv3 --stats summary of profiles/rNN/kernel_stats.csv is taken on")
+    ap.add_argument("--clock-stamps", action="store_true", help="diagnostic (needs RESYNTH_AMD_LIB = the `make clk` build): after the timed region, >= 2 s of back-to-back "
+                    "steps with s_memtime / s_memrealtime stamps around every analysis / render workgroup; reports the clock the chip held (valu.effective_clock_ghz_measured)")
+    ap.add_argument("--details", default=os.path.join(ROOT, "bench_details.json"), help="file the full result is written to (the last stdout line is the compact headline)")
     args = ap.parse_args()
 
     import numpy as np
@@ -510,54 +613,102 @@ def main():
     value = total_streams * n * args.steps / dt
     ms_per_step = dt / args.steps * 1e3
 
+    clock = None
+    if rank == 0 and args.clock_stamps:
+        # MI355X_MICROARCH.md, DVFS give-back item 6: the in-kernel clock after >= 2 s of back-to-back launches on the real (random) data
+        heat = int(math.ceil(2.0 / (ms_per_step * 1e-3)))
+        ctx.set_clock_stamps(True)
+        for _ in range(heat):
+            run.step()
+        run.finish()
+        ctx.synchronize()
+        ctx.set_clock_stamps(True)   # clears the sums: what follows is measured on a chip that has been busy for 2 s
+        m_steps = max(20, heat // 4)
+        t1 = time.perf_counter()
+        for _ in range(m_steps):
+            run.step()
+        run.finish()
+        ctx.synchronize()
+        dt_clk = (time.perf_counter() - t1) / m_steps
+        cs = ctx.clock_stamps()
+        ctx.set_clock_stamps(False)
+        clock = {"analysis_ghz": cs["analysis"][0], "render_ghz": cs["render"][0], "analysis_workgroups": cs["analysis"][1], "render_workgroups": cs["render"][1],
+                 "steps_before": heat, "steps_measured": m_steps, "ms_per_step_while_stamping": dt_clk * 1e3, "csrc_sha256": csrc_sha256(),
+                 "how": "diagnostic build (-DRA_CLOCK_STAMPS=1): lane 0 of every analysis / render workgroup stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) at its "
+                        "start and end; GHz = 0.1 x sum of shader ticks / sum of 100 MHz ticks over the measured steps (duration-weighted mean over workgroups)"}
+
     result = None
     if rank == 0:
         calls = max(calls, 1)
         over_ms = {k: kms[k] / calls for k in STAGES}
         lps = {k: launches[k] / calls for k in STAGES}
-        # every kernel with the chip to itself: one more step, its stages serialised on one stream (outside the timed region)
-        ctx.set_pipeline_serial(True)
-        alone_ms, _ = run.kernel_split(3)
-        ctx.set_pipeline_serial(False)
+        # every kernel with the chip to itself: three more steps, their stages serialised on one stream (outside the timed region)
+        if args.no_alone:
+            alone_ms = {k: None for k in STAGES}
+        else:
+            ctx.set_pipeline_serial(True)
+            alone_ms, _ = run.kernel_split(3)
+            ctx.set_pipeline_serial(False)
         mono = head_kw["stereo_spread"] == 0.0
         KNAME = {"analysis": "ra_analysis_kernel", "track": "ra_track_kernel", "vocoder": "ra_voc_*_kernel", "propagate": "ra_synth_propagate_kernel",
-                 "render": "ra_synth_render_mono_kernel" if mono else "ra_synth_render_kernel", "history": "ra_roll_history_kernel"}
+                 "render": "ra_synth_render_mono_kernel" if mono else "ra_synth_render_kernel", "history": "ra_roll_history_kernel", "prep": "ra_track_prep_kernel"}
         flops = algo_flops_per_frame(N, H, P)
         pmc_doc, pmc_src = measured_counters(S, n, N, H, P)
         kernels = {}
         for k in STAGES:
             if lps[k] == 0:
                 continue
-            per_launch_alone = alone_ms[k] / lps[k]
+            per_launch_alone = alone_ms[k] / lps[k] if alone_ms[k] is not None else None
             per_launch_over = over_ms[k] / lps[k]
             algo_bytes = ALGO_BYTES_PER_FRAME * frames_per_step_gpu / lps[k]   # a launch covers 1 / launches_per_step of the block
             e = {"kernel": KNAME[k], "launches_per_step": lps[k], "alone_ms_per_step": alone_ms[k], "overlapped_ms_per_step": over_ms[k],
                  "alone_ms_per_launch": per_launch_alone, "overlapped_ms_per_launch": per_launch_over,
-                 "algorithmic_GBs_alone": algo_bytes / (per_launch_alone * 1e-3) / 1e9 if per_launch_alone > 0 else None}
+                 "algorithmic_GBs_alone": algo_bytes / (per_launch_alone * 1e-3) / 1e9 if per_launch_alone else None}
             c = pmc_doc["kernels"].get(KNAME[k]) if pmc_doc else None
             if c:
                 e["hbm_bytes_per_launch"] = (2.0 * c["FETCH_SIZE_KB"] + c["WRITE_SIZE_KB"]) * 1024.0 / c.get("launches", 1)
-                if "SQ_INSTS_VALU" in c and alone_ms[k] > 0:
+                if "SQ_INSTS_VALU" in c:
                     e["valu_insts_per_step"] = c["SQ_INSTS_VALU"]
-                    e["issue_frac_alone"] = c["SQ_INSTS_VALU"] / (alone_ms[k] * 1e-3) / 1e9 / VALU_PEAK_GINST
+                    if alone_ms[k]:
+                        e["issue_frac_alone"] = c["SQ_INSTS_VALU"] / (alone_ms[k] * 1e-3) / 1e9 / VALU_PEAK_GINST
             kernels[k] = e
-        # the dominant kernel is derived: the one whose launches take longest inside the timed region (HIP events on its own stream).  (r02 took
-        # the largest time ALONE; since the renderer's r03 cuts the two chain kernels — 256 single waves each, hidden behind the renderer in
-        # the pipeline — need about as long alone as the renderer does, and a chain is not what bounds the step.)
-        dom = max((k for k in kernels if k != "history"), key=lambda k: kernels[k]["overlapped_ms_per_step"])
-        d = kernels[dom]
-        dom_ms = d["overlapped_ms_per_launch"]          # HIP events over the timed region, on the stream the kernel is launched on
-        algo_bytes = ALGO_BYTES_PER_FRAME * frames_per_step_gpu / d["launches_per_step"]
-        achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # The dominant kernel is derived, by the rule the rocprofv3 summary is read with: the kernel with the largest SUMMED launch
+        # duration over the timed region — HIP events around every launch, on the stream it is launched on; since r04 the tracking pre-pass is
+        # timed as a kernel of its own instead of inside the analysis stage.  The runner-up (analysis or render, whichever is not dominant) is
+        # reported beside it as `roofline_second`.  Launch durations inside the pipeline overlap each other (co-resident kernels stretch each
+        # other); `kernels{}.alone_ms_per_step` is each kernel with the chip to itself.
+        ranked = sorted((k for k in kernels if k != "history"), key=lambda k: -kernels[k]["overlapped_ms_per_step"])
+
+        def roof(k):
+            d = kernels[k]
+            ms = d["overlapped_ms_per_launch"]          # HIP events over the timed region, on the stream the kernel is launched on
+            ab = ALGO_BYTES_PER_FRAME * frames_per_step_gpu / d["launches_per_step"]
+            ach = ab / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            r_ = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": d.get("hbm_bytes_per_launch"),
+                  "kernel": d["kernel"], "kernel_ms_per_launch": ms, "launches_per_step": d["launches_per_step"], "algorithmic_bytes_per_launch": ab,
+                  "summed_launch_ms_per_step": d["overlapped_ms_per_step"]}
+            if "valu_insts_per_step" in d and d["overlapped_ms_per_step"] > 0:
+                # VALU wave-instructions per second of the kernel's own (overlapped) launch time against 614 G/s; alone: kernels{}.issue_frac_alone
+                r_["issue_frac"] = d.get("issue_frac_alone", d["valu_insts_per_step"] / (d["overlapped_ms_per_step"] * 1e-3) / 1e9 / VALU_PEAK_GINST)
+            return r_
+
         total_valu = sum(c.get("SQ_INSTS_VALU", 0.0) for c in pmc_doc["kernels"].values()) if pmc_doc else None
         valu = {"algorithmic_flop_per_frame": flops,
                 "achieved_tflops_fp64": flops * frames_per_step_gpu / (ms_per_step * 1e-3) / 1e12,   # whole-step flops / step time
                 "frac_of_peak_fp64_vector": flops * frames_per_step_gpu / (ms_per_step * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                "peak_tflops_fp64_vector": FP64_VALU_PEAK_TFLOPS, "peak_issue_rate_ginst_s": VALU_PEAK_GINST}
+                "peak_tflops_fp64_vector": FP64_VALU_PEAK_TFLOPS, "peak_issue_rate_ginst_s": VALU_PEAK_GINST, "nominal_clock_ghz": 2.4}
         if total_valu:
             valu.update({"valu_insts_per_step_all_kernels": total_valu, "step_issue_frac": total_valu / (ms_per_step * 1e-3) / 1e9 / VALU_PEAK_GINST,
                          "render_valu_insts_per_channel_sample": pmc_doc["kernels"].get(KNAME["render"], {}).get("SQ_INSTS_VALU", 0.0) * 64.0 / (frames_per_step_gpu * P),
                          "counters_from": pmc_src})
+            # the clock the chip HELD inside the two throughput kernels (s_memtime / s_memrealtime stamps of the diagnostic build, merged into
+            # profiles/rNN/traffic.json by scripts/pmc_aggregate.py): the issue fraction against the nominal 2.4 GHz and against the held clock
+            clk = pmc_doc.get("effective_clock_ghz")
+            if clk:
+                held = min(clk["analysis_ghz"], clk["render_ghz"]) if isinstance(clk, dict) else float(clk)
+                valu["effective_clock_ghz"] = held
+                valu["effective_clock"] = clk
+                valu["step_issue_frac_at_held_clock"] = valu["step_issue_frac"] * 2.4 / held
         else:
             valu["counters"] = f"null: {pmc_src}"
         result = {
@@ -571,17 +722,24 @@ def main():
                                    f"stride {H} (75% overlap), {P} partials, analysis_volume 1, stereo_spread 0, post none",
                        "streams_per_gpu": S, "streams_total": total_streams, "frames_per_stream_per_step": n, "sharding": f"streams x{world}, no collective"},
             "x_realtime_per_stream": value / (SR * total_streams),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": d.get("hbm_bytes_per_launch"), "kernel": d["kernel"],
-                         "kernel_selected_by": "largest overlapped_ms_per_step among kernels{} (summed launch durations inside the timed region)",
-                         "kernel_ms_per_launch": dom_ms, "launches_per_step": d["launches_per_step"], "algorithmic_bytes_per_launch": algo_bytes,
-                         "traffic_source": pmc_src if pmc_doc else f"null: {pmc_src}",
-                         "note": "the path is fp64-VALU issue bound, not HBM bound (SURVEY.md §8d): see valu and kernels{}.issue_frac_alone"},
+            "roofline": dict(roof(ranked[0]),
+                             kernel_selected_by="largest summed launch duration over the timed region (HIP events per launch on its own stream)",
+                             traffic_source=pmc_src if pmc_doc else f"null: {pmc_src}",
+                             note="the path is fp64-VALU issue bound, not HBM bound (SURVEY.md §8d): see valu and kernels{}.issue_frac_alone"),
             "valu": valu,
             "kernels": kernels,
             "csrc_sha256": csrc_sha256(),
             "checks": {"out_rms": out_rms, "dropped_note_on": int(st.dropped_note_on), "error_flags": int(st.error_flags)},
         }
+        if len(ranked) > 1:
+            result["roofline_second"] = roof(ranked[1])
+        if clock:
+            result["valu"]["effective_clock_ghz_measured"] = clock
+        if world > 1 and S >= 1000:   # configs[4] / a north_star rank: what feeding one rank's streams from the host costs (never `value`)
+            try:
+                result["pcie_inclusive"] = pcie_inclusive(api, torch, run.cfg, S, n, local_rank)
+            except Exception as e:
+                result["pcie_inclusive"] = {"error": repr(e)}
 
     # CPU baseline: the oracle (a port; the reference itself cannot be built here) on the host cores, bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -626,6 +784,7 @@ def main():
                 o["workload"] = name
                 if name == "north_star":
                     o["target"] = ">= 10 x real time for each of the 1000 streams (BASELINE.json north_star)"
+                    o["pcie_inclusive"] = pcie_inclusive(api, torch, api.default_config(sample_rate=SR, **kw), S2, 10 * SR, local_rank)
                 others.append(o)
             for name in ("voice_sweep", "voice_birds", "voice_robots"):
                 o = time_voice(api, torch, dev, wl[name][0], wl[name][1], 10.0, 6)
@@ -642,7 +801,7 @@ def main():
         result["other_configs"] = others
 
     if rank == 0:
-        print(json.dumps(result))
+        emit(result, args.details)
     if world > 1:
         dist.destroy_process_group()
 

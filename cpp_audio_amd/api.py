@@ -79,7 +79,7 @@ EXPORTED_SYMBOLS = [
     "ra_create", "ra_destroy", "ra_reset", "ra_set_hip_stream", "ra_process_device", "ra_process_device_async", "ra_join", "ra_process_host",
     "ra_synchronize",
     "ra_feed", "ra_compute", "ra_get_stats", "ra_get_events", "ra_get_frame_pitches", "ra_resynth_notes", "ra_sqmag",
-    "ra_set_profiling", "ra_get_kernel_ms", "ra_get_kernel_launches", "ra_render_note",
+    "ra_set_profiling", "ra_get_kernel_ms", "ra_get_kernel_launches", "ra_get_stage_timing", "ra_set_clock_stamps", "ra_get_clock_stamps", "ra_render_note",
     "ra_carrier_events", "ra_get_carrier", "ra_set_pipeline_serial", "ra_deduce_notes", "ra_deduce_notes_batch",
     "ra_voice_default_config", "ra_voice_program", "ra_voice_expand_note", "ra_voice_create", "ra_voice_destroy", "ra_voice_events", "ra_voice_process_host", "ra_voice_process_device",
     "ra_voice_process_device_async", "ra_voice_set_hip_stream", "ra_voice_synchronize", "ra_voice_get_kernel_ms", "ra_voice_dropped_note_ons",
@@ -124,6 +124,9 @@ def lib():
         L.ra_set_pipeline_serial.argtypes = [C.c_void_p, C.c_int32]
         L.ra_get_kernel_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
         L.ra_get_kernel_launches.argtypes = [C.c_void_p, C.c_void_p]
+        L.ra_get_stage_timing.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+        L.ra_set_clock_stamps.argtypes = [C.c_void_p, C.c_int32]
+        L.ra_get_clock_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.ra_carrier_events.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.ra_get_carrier.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
         L.ra_even_window_size_frames.argtypes = [C.c_float, C.c_int]
@@ -249,18 +252,37 @@ class Context:
         """Measurement aid: run a block's stages one after the other (each kernel alone on the chip) instead of overlapped."""
         _check(lib().ra_set_pipeline_serial(self._h, 1 if on else 0))
 
-    def kernel_ms(self):
-        """({'analysis','track','vocoder','propagate','render','history'} -> accumulated ms, number of calls)."""
-        ms = np.zeros(6, np.float64)
+    STAGES = ("analysis", "track", "vocoder", "propagate", "render", "history", "prep")
+
+    def _stage_timing(self):
+        ms = np.zeros(8, np.float64)
+        k = np.zeros(8, np.int64)
         calls = C.c_int64(0)
-        _check(lib().ra_get_kernel_ms(self._h, _p(ms), C.byref(calls)))
-        return dict(zip(("analysis", "track", "vocoder", "propagate", "render", "history"), ms.tolist())), calls.value
+        n = _check(lib().ra_get_stage_timing(self._h, 8, _p(ms), _p(k), C.byref(calls)))
+        assert n == len(self.STAGES), n
+        return ms[:n].tolist(), k[:n].tolist(), calls.value
+
+    def kernel_ms(self):
+        """({'analysis','track','vocoder','propagate','render','history','prep'} -> accumulated ms, number of calls); 'prep' is the
+        tracking pre-pass ra_track_prep_kernel, launched behind every analysis launch (ra_get_stage_timing)."""
+        ms, _, calls = self._stage_timing()
+        return dict(zip(self.STAGES, ms)), calls
 
     def kernel_launches(self):
         """kernel launches behind each kernel_ms() entry (a block is cut into pipeline chunks)."""
-        k = np.zeros(6, np.int64)
-        _check(lib().ra_get_kernel_launches(self._h, _p(k)))
-        return dict(zip(("analysis", "track", "vocoder", "propagate", "render", "history"), k.tolist()))
+        _, k, _ = self._stage_timing()
+        return dict(zip(self.STAGES, k))
+
+    def set_clock_stamps(self, on=True):
+        """Diagnostic (ra_set_clock_stamps): stamp s_memtime / s_memrealtime around every analysis / render workgroup; clears the sums."""
+        _check(lib().ra_set_clock_stamps(self._h, 1 if on else 0))
+
+    def clock_stamps(self):
+        """{'analysis': (GHz, workgroups), 'render': (GHz, workgroups)}: the clock the chip held inside the two throughput kernels."""
+        g = np.zeros(2, np.float64)
+        k = np.zeros(2, np.int64)
+        _check(lib().ra_get_clock_stamps(self._h, _p(g), _p(k)))
+        return {"analysis": (float(g[0]), int(k[0])), "render": (float(g[1]), int(k[1]))}
 
     def stats(self):
         s = RaStats()

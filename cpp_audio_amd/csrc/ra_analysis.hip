@@ -185,6 +185,7 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   int *scan = lists_in_z ? aux + 16 : reinterpret_cast<int *>(listA); // [T+1] (outside the buffer it aliases listA: consumed (K read) before the lists are written)
 
   RaPhaseClock clk(b.dbg_clk, tid == 0);
+  RaClockStamp stamp(b.dbg_stamp, tid == 0);
   // twiddles W^k, W^(M-k) of the real-spectrum split (step 3) for the pairs k0, k0 + T: fetched one trip ahead, the first trip's before the FFT
   double2 sw[4] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
   auto split_twiddles = [&](int k0) {
@@ -605,6 +606,7 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
     }
   }
   clk.mark(9);
+  stamp.finish(0);
 }
 
 // keeps the last N input samples of every stream for the next block's overlapping windows

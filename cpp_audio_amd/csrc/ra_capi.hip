@@ -65,14 +65,15 @@ struct ra_context {
   } shim;
   double *dbg_sqmag = nullptr;
   unsigned long long *dbg_clk = nullptr;
+  unsigned long long *dbg_stamp = nullptr; // ra_set_clock_stamps
   // optional per-kernel timing with HIP events on the launch stream (ra_set_profiling)
   bool profiling = false;
   struct Timed { int stage; hipEvent_t a, b; };
   std::vector<Timed> timed;          // launches of the calls not yet resolved
   std::vector<hipEvent_t> ev_pool;   // recycled timing events
-  double kernel_ms[6] = {0, 0, 0, 0, 0, 0}; // analysis, track, vocoder, propagate, render, history
+  double kernel_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // analysis, track, vocoder, propagate, render, history, tracking pre-pass (ST_*)
   int64_t kernel_calls = 0;
-  int64_t kernel_launches[6] = {0, 0, 0, 0, 0, 0};
+  int64_t kernel_launches[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // chunk pipeline: analysis / tracking / propagation / render streams and the events chaining them
   bool pipe_ready = false;
   hipStream_t pipe_stream[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // analysis, tracking, propagation, render, vocoder, carrier synth
@@ -675,7 +676,7 @@ void frames_in_block(const RaParams &p, int64_t t0, int64_t n, int64_t &f_lo, in
 }
 
 // ---- per-launch timing with HIP events on the stream each kernel is launched on -------------------------------------
-enum { ST_ANALYSIS = 0, ST_TRACK, ST_VOCODER, ST_PROPAGATE, ST_RENDER, ST_HISTORY, ST_COUNT };
+enum { ST_ANALYSIS = 0, ST_TRACK, ST_VOCODER, ST_PROPAGATE, ST_RENDER, ST_HISTORY, ST_PREP, ST_COUNT }; // ST_PREP: ra_track_prep_kernel, timed on its own since r04
 
 int resolve_timing(ra_context *c) {
   for (auto &t : c->timed) {
@@ -811,6 +812,7 @@ int process_block_impl(ra_context *c, const float *d_voice, const float *d_carri
   ra_context::Scratch &sc = c->scr[c->parity];
   c->b.dbg_sqmag = c->dbg_sqmag;
   c->b.dbg_clk = c->dbg_clk;
+  c->b.dbg_stamp = c->dbg_stamp;
   const RaBuffers &b = c->b;
   hipStream_t user = c->stream;
   // post "limit": the render leaves the double mix in post_d and the limiter kernel produces the float output (and the mono publication)
@@ -847,7 +849,8 @@ int process_block_impl(ra_context *c, const float *d_voice, const float *d_carri
       sp.ct0 = (piece == 0) ? t0 : ra_fire_sample(p.N, p.H, f_lo + fb0);
       sp.ct1 = (fb1 == nfb) ? t0 + n : ra_fire_sample(p.N, p.H, f_lo + fb1);
       if (sp.nfb > 0) {
-        RA_TRY(timed_launch(c, ST_ANALYSIS, user, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, sp.fb0, sp.nfb, nfb, user); ra_launch_track_prep(p, b, sp.fb0, sp.nfb, user); }));
+        RA_TRY(timed_launch(c, ST_ANALYSIS, user, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, sp.fb0, sp.nfb, nfb, user); }));
+        RA_TRY(timed_launch(c, ST_PREP, user, [&] { ra_launch_track_prep(p, b, sp.fb0, sp.nfb, user); }));
         RA_TRY(timed_launch(c, ST_TRACK, user, [&] { ra_launch_track(p, b, f_lo, sp.fb0, sp.nfb, user); }));
       }
       if (c->cfg.reference_order == 1) RA_TRY(timed_launch(c, ST_RENDER, user, [&] { ra_launch_synth_serial(p, b, sp, d_out, d_out_d, user); }));
@@ -864,7 +867,8 @@ int process_block_impl(ra_context *c, const float *d_voice, const float *d_carri
     n_chunks = 1; // the window history is rolled on the caller's stream below
   } else if (n_chunks == 1) { // everything in order on the caller's stream
     RaSpan sp{t0, n, t0, t0 + n, f_lo, 0, nfb, 0};
-    RA_TRY(timed_launch(c, ST_ANALYSIS, user, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, 0, nfb, nfb, user); ra_launch_track_prep(p, b, 0, nfb, user); }));
+    RA_TRY(timed_launch(c, ST_ANALYSIS, user, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, 0, nfb, nfb, user); }));
+    RA_TRY(timed_launch(c, ST_PREP, user, [&] { ra_launch_track_prep(p, b, 0, nfb, user); }));
     RA_TRY(timed_launch(c, ST_TRACK, user, [&] { ra_launch_track(p, b, f_lo, 0, nfb, user); }));
     if (p.voc_enabled) RA_TRY(timed_launch(c, ST_VOCODER, user, [&] { launch_vocoder(user); }));
     if (c->cfg.reference_order == 1) RA_TRY(timed_launch(c, ST_RENDER, user, [&] { ra_launch_synth_serial(p, b, sp, d_out, d_out_d, user); }));
@@ -979,7 +983,8 @@ int process_block_impl(ra_context *c, const float *d_voice, const float *d_carri
       const int a_first = (i == 0) ? 0 : 1 + ((i - 1) / agroup) * agroup, a_last = (i == 0) ? 0 : std::min(n_chunks - 1, a_first + agroup - 1);
       if (i == a_first) {
         const int64_t fb0 = cut(a_first), fb1 = (a_last == n_chunks - 1) ? nfb : cut(a_last + 1);
-        RA_TRY(timed_launch(c, ST_ANALYSIS, sA, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, fb0, fb1 - fb0, nfb, sA); ra_launch_track_prep(p, b, fb0, fb1 - fb0, sA); }));
+        RA_TRY(timed_launch(c, ST_ANALYSIS, sA, [&] { ra_launch_analysis(p, b, d_voice, t0, n, f_lo, fb0, fb1 - fb0, nfb, sA); }));
+        RA_TRY(timed_launch(c, ST_PREP, sA, [&] { ra_launch_track_prep(p, b, fb0, fb1 - fb0, sA); }));
         HIP_TRY(hipEventRecord(c->ev_chunk[0][a_first], sA));
       }
       HIP_TRY(hipStreamWaitEvent(sT, c->ev_chunk[0][a_first], 0));
@@ -1195,8 +1200,36 @@ int ra_set_profiling(ra_context *c, int32_t enable) {
   int r = resolve_timing(c);
   if (r) return r;
   c->profiling = enable != 0;
-  for (int i = 0; i < 6; ++i) { c->kernel_ms[i] = 0; c->kernel_launches[i] = 0; }
+  for (int i = 0; i < ST_COUNT; ++i) { c->kernel_ms[i] = 0; c->kernel_launches[i] = 0; }
   c->kernel_calls = 0;
+  return RA_OK;
+}
+
+int ra_set_clock_stamps(ra_context *c, int32_t on) {
+  if (!c) return fail(RA_EINVAL, "null context");
+  if (on && !RA_CLOCK_STAMPS) return fail(RA_EINVAL, "clock stamps need the diagnostic build (make -C cpp_audio_amd/csrc clk; RESYNTH_AMD_LIB=.../libresynth_amd_clk.so)");
+  HIP_TRY(hipSetDevice(c->device));
+  { int jr = join_streams(c); if (jr) return jr; }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (on && !c->dbg_stamp) RA_TRY(dev_alloc(c, &c->dbg_stamp, 16, true));
+  if (c->dbg_stamp) HIP_TRY(hipMemsetAsync(c->dbg_stamp, 0, 16 * sizeof(unsigned long long), c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (!on && c->dbg_stamp) { dev_free(c, c->dbg_stamp); c->dbg_stamp = nullptr; }
+  return RA_OK;
+}
+
+int ra_get_clock_stamps(ra_context *c, double *ghz2, int64_t *workgroups2) {
+  if (!c || !ghz2 || !workgroups2) return fail(RA_EINVAL, "null argument");
+  if (!c->dbg_stamp) return fail(RA_EINVAL, "clock stamps are off (ra_set_clock_stamps)");
+  HIP_TRY(hipSetDevice(c->device));
+  { int jr = join_streams(c); if (jr) return jr; }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  unsigned long long h[16];
+  HIP_TRY(hipMemcpy(h, c->dbg_stamp, sizeof(h), hipMemcpyDeviceToHost));
+  for (int k = 0; k < 2; ++k) { // slots 0..2: analysis, 4..6: render — shader ticks, 100 MHz ticks, workgroups
+    ghz2[k] = h[4 * k + 1] ? 0.1 * (double)h[4 * k] / (double)h[4 * k + 1] : 0.0;
+    workgroups2[k] = (int64_t)h[4 * k + 2];
+  }
   return RA_OK;
 }
 
@@ -1225,6 +1258,16 @@ int ra_get_kernel_launches(ra_context *c, int64_t *launches6) {
   if (r) return r;
   for (int i = 0; i < 6; ++i) launches6[i] = c->kernel_launches[i];
   return RA_OK;
+}
+
+int ra_get_stage_timing(ra_context *c, int32_t cap, double *ms, int64_t *launches, int64_t *calls) {
+  if (!c || cap < 0 || (cap > 0 && (!ms || !launches))) return fail(RA_EINVAL, "bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  int r = resolve_timing(c);
+  if (r) return r;
+  for (int i = 0; i < ST_COUNT && i < cap; ++i) { ms[i] = c->kernel_ms[i]; launches[i] = c->kernel_launches[i]; }
+  if (calls) *calls = c->kernel_calls;
+  return ST_COUNT;
 }
 
 int ra_process_device(ra_context *c, const float *d_voice, const float *d_carrier, int64_t n_frames, float *d_out) {

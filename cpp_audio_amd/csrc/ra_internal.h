@@ -146,6 +146,7 @@ struct RaBuffers {
   int64_t fb_hist_len, fb_block_cap;
   double *dbg_sqmag;        // optional [frames][M] tap of |X|^2 (ra_sqmag), normally null
   unsigned long long *dbg_clk; // optional [128] in-kernel phase clocks (env RA_PHASE_CLOCKS=1, printed by ra_destroy), normally null
+  unsigned long long *dbg_stamp; // optional [16] clock stamps of the two throughput kernels (ra_set_clock_stamps, RaClockStamp), normally null
   // ---- post: "limit" ----
   double *post_d;           // [n_streams][n][2] the double mix of the block, read by the limiter kernel
   int64_t post_cap;
@@ -219,6 +220,34 @@ struct RaPhaseClock {
     for (int i = 0; i < 4; ++i) if (cnt[i]) atomicAdd(dst + base + 8 + i, (unsigned long long)cnt[i]);
   }
 };
+
+// The clock a kernel's waves actually ran at (MI355X_MICROARCH.md, DVFS give-back item 6): s_memtime ticks are shader cycles, s_memrealtime
+// ticks a constant 100 MHz; lane 0 of a workgroup stamps both once at its start and once at its end and adds the two differences and a count
+// to dst[slot .. slot + 2].  Sum of shader ticks / sum of 100 MHz ticks x 0.1 = the duration-weighted mean clock in GHz over the stamped
+// workgroups.  Only in the DIAGNOSTIC build (-DRA_CLOCK_STAMPS=1, `make clk` -> ../libresynth_amd_clk.so): the four live registers of a
+// stamp cost the analysis kernel 77 more spilled VGPRs at its 128-register budget and the renderer 29; in the product build the type is
+// empty and no stamp exists.
+#ifndef RA_CLOCK_STAMPS
+#define RA_CLOCK_STAMPS 0
+#endif
+#if RA_CLOCK_STAMPS
+struct RaClockStamp {
+  unsigned long long *dst, t0, r0;
+  __device__ inline RaClockStamp(unsigned long long *d, bool on) : dst(on ? d : nullptr), t0(0), r0(0) {
+    if (dst) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+  }
+  __device__ inline void finish(int slot) {
+    if (!dst) return;
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    atomicAdd(dst + slot, t1 - t0); atomicAdd(dst + slot + 1, r1 - r0); atomicAdd(dst + slot + 2, 1ull);
+  }
+};
+#else
+struct RaClockStamp {
+  __device__ inline RaClockStamp(unsigned long long *, bool) {}
+  __device__ inline void finish(int) {}
+};
+#endif
 
 // Runs fn the first time the calling site is reached on the current device (function attributes are per device: a process may hold
 // contexts on several GPUs).  `done` is the site's own static bit set; the lock keeps a second host thread from launching before the

@@ -722,6 +722,7 @@ __device__ inline void render_pair(const RaParams &p, const RaBuffers &b, const 
   const int64_t beg0 = hop_begin(i0), end0 = hop_end(i0), beg1 = two ? hop_begin(i0 + 1) : 0, end1 = two ? hop_end(i0 + 1) : 0;
   const size_t seg0 = (size_t)s * b.seg_cap + sp.seg0 + i0;
   RaPhaseClock clk(b.dbg_clk, l == 0);
+  RaClockStamp stamp(b.dbg_stamp, l == 0);
   const unsigned long long wg_t0 = clk.t;
   const SynConst k = syn_const(p, s);
   const double *mix = (p.voc_enabled && b.voc_mix) ? b.voc_mix + (size_t)s * sp.n : nullptr;
@@ -779,6 +780,7 @@ __device__ inline void render_pair(const RaParams &p, const RaBuffers &b, const 
     clk.mark(20);
     render_range_fast<MONO, false>(c, tile, k, p, s, l, bh, eh, sp.t0, sp.n, mix, out, out_d, b.error_flags, fb_mono, clk, Ppad, 0);
   }
+  stamp.finish(4);
   if (clk.dst) { // workgroup lifetime: maximum and a histogram in steps of 200 k ticks
     const unsigned long long d = __builtin_readcyclecounter() - wg_t0;
     atomicMax(clk.dst + 39, d);

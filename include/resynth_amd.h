@@ -254,6 +254,8 @@ int ra_compute(ra_context *ctx, int32_t stream, double *h_buffer, int32_t n_fram
  * reference's per-stage ThreadCPUTimer gauges (periodicfft.cpp:140-151, lib.cpp:1586-1617, getDurationFft/Extract/Step).
  * ms6 = accumulated milliseconds of {analysis (fft+extract+stateless step), tracking (step), vocoder, synthesis state
  * propagation, synthesis render (compute), history copy} over `calls` ra_process_* calls since profiling was enabled.
+ * (Since r04 the tracking pre-pass ra_track_prep_kernel — the per-item half of synthesize_sounds' payloads and of
+ * order_pitches_by_perceived_loudness, lib.cpp:316-376,1716-1727 — is timed as a stage of its own, see ra_get_stage_timing.)
  */
 int ra_set_profiling(ra_context *ctx, int32_t enable);
 /* Measurement aid: with on != 0 the stages of a block (same chunks, same launches) run one after the other on the caller's stream
@@ -263,6 +265,20 @@ int ra_set_pipeline_serial(ra_context *ctx, int32_t on);
 int ra_get_kernel_ms(ra_context *ctx, double *ms6, int64_t *calls);
 /* number of kernel launches behind each entry of ms6 (a block is cut into pipeline chunks: several launches per stage and call) */
 int ra_get_kernel_launches(ra_context *ctx, int64_t *launches6);
+/* every timed stage: ms[i] / launches[i] for i < min(cap, returned count), in the order {analysis, tracking, vocoder, propagation, render,
+ * history copy, tracking pre-pass}; returns the number of stages (7) or a negative RA_E* code */
+int ra_get_stage_timing(ra_context *ctx, int32_t cap, double *ms, int64_t *launches, int64_t *calls);
+
+/*
+ * Diagnostic: the clock the chip HELD inside the two throughput kernels.  With on != 0 lane 0 of every analysis / render workgroup stamps
+ * s_memtime (shader cycles) and s_memrealtime (100 MHz) at its start and end; ra_get_clock_stamps returns, for {analysis, render}, the
+ * duration-weighted mean clock in GHz over the workgroups stamped since the switch-on (or the last call of ra_set_clock_stamps, which
+ * also clears the sums) and their number.  Only the diagnostic build has the stamps (make -C cpp_audio_amd/csrc clk -> libresynth_amd_clk.so:
+ * they cost both kernels registers); in the product build ra_set_clock_stamps(on) returns RA_EINVAL and no stamp exists.  Nothing in the
+ * reference corresponds: it exists so that bench.py can say against which clock its VALU issue fractions are taken.
+ */
+int ra_set_clock_stamps(ra_context *ctx, int32_t on);
+int ra_get_clock_stamps(ra_context *ctx, double *ghz2, int64_t *workgroups2);
 
 /* counters and device-side error flags (synchronises) */
 int ra_get_stats(ra_context *ctx, ra_stats *stats);

@@ -4,7 +4,7 @@ beside the counters (bench.json): bench.py quotes the counters only for exactly 
 import csv, glob, json, os, sys
 
 out = sys.argv[1]
-STAGE = {"ra_analysis_kernel": "analysis", "ra_track_prep_kernel": "analysis",  # (the pre-pass is launched with every analysis launch)
+STAGE = {"ra_analysis_kernel": "analysis", "ra_track_prep_kernel": "prep",  # (the pre-pass is launched behind every analysis launch; a stage of its own since r04)
           "ra_track_kernel": "track", "ra_synth_propagate_kernel": "propagate", "ra_synth_render_mono_kernel": "render",
          "ra_synth_render_kernel": "render", "ra_roll_history_kernel": "history"}
 KERNELS = tuple(STAGE)
@@ -17,7 +17,8 @@ def short(name):
     return None
 
 
-bench = json.load(open(os.path.join(out, "bench.json")))
+# the full result of the stats run (bench.py --details): launches per step of every stage, the workload and the source hash
+bench = json.load(open(os.path.join(out, "stats_details.json")))
 LAUNCHES = {k: v["launches_per_step"] for k, v in bench["kernels"].items()}
 cfgw = bench["config"]
 import re
@@ -32,8 +33,8 @@ for ctr in counters:
         print("no counter file for", ctr)
         continue
     rows = list(csv.DictReader(open(files[0])))
-    # one row per dispatch (and counter).  The bench ran its set-up block, 1 warm-up step, 1 timed step and the serialised extra step
-    # (kernels{}.alone): the timed step's dispatches of a kernel are the launches_per_step before the last launches_per_step
+    # one row per dispatch (and counter).  The bench ran its set-up block, 1 warm-up step and 1 timed step (--no-alone: no serialised extra
+    # steps): the timed step's dispatches of a kernel are its last launches_per_step
     per = {}
     for r in rows:
         k = short(r["Kernel_Name"])
@@ -42,13 +43,13 @@ for ctr in counters:
     for k, lst in per.items():
         lst.sort()
         nl = int(round(LAUNCHES.get(STAGE[k], 0))) or 1
-        last = lst[-2 * nl:-nl] if len(lst) >= 2 * nl else lst[-nl:]
+        last = lst[-nl:]
         d = kern.setdefault(k, {})
         d[ctr + "_KB" if ctr in ("FETCH_SIZE", "WRITE_SIZE") else ctr] = sum(v for _, v in last)
         d["launches"] = len(last)
 doc = {
     "collected_with": "rocprofv3 --kernel-trace --pmc <one counter per run> -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline "
-                      "--no-other-configs ; sums over the launches of the timed step (scripts/collect_profiles.sh, scripts/pmc_aggregate.py)",
+                      "--no-other-configs --no-alone ; sums over the launches of the timed step (scripts/collect_profiles.sh, scripts/pmc_aggregate.py)",
     "units": "FETCH/WRITE in KB as reported by rocprofv3; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 — the x2 is the gfx950 correction of "
              "MI355X_MICROARCH.md §HBM for streaming reads; SQ_INSTS_VALU in wave-instructions; SQ_WAVES waves launched; SQ_BUSY_CYCLES / "
              "SQ_WAVE_CYCLES summed over SEs as rocprofv3 reports them; SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE in cycles",
@@ -56,6 +57,16 @@ doc = {
     "csrc_sha256": bench.get("csrc_sha256"),
     "kernels": kern,
 }
+# the clock the chip held inside the two throughput kernels: the diagnostic build's stamps (bench.py --clock-stamps), same sources
+try:
+    clk = json.load(open(os.path.join(out, "clock_details.json")))["valu"]["effective_clock_ghz_measured"]
+    if clk.get("csrc_sha256") == doc["csrc_sha256"]:
+        doc["effective_clock_ghz"] = clk
+        json.dump(clk, open(os.path.join(out, "clock.json"), "w"), indent=1)
+    else:
+        print("clock stamps are from another build: not merged")
+except Exception as e:
+    print("no clock stamps:", e)
 json.dump(doc, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 stats = glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
