@@ -444,7 +444,8 @@ def compact_line(result, details_path=None):
     c["checks"] = result.get("checks")
     if details_path:
         c["details"] = details_path
-    c = _sig(c)
+    # value and ms_per_step keep every digit (the driver checks one against the other); the diagnostic blocks carry 5 significant figures
+    c = {k: (v if k in ("value", "ms_per_step") else _sig(v)) for k, v in c.items()}
     line = json.dumps(c, separators=(",", ":"))
     # never let an unexpected field push the line past the limit: drop the optional blocks, least important first
     for drop in ("other_ms_per_step", "kernel_ms_per_step", "roofline_second", "checks", "retimed", "pcie_inclusive", "valu", "north_star"):

@@ -33,7 +33,7 @@ def test_last_line_is_compact_and_complete(tmp_path):
     c = json.loads(line)
     for k in HEADLINE_KEYS:
         assert k in c, k
-    assert c["value"] == float(f"{full['value']:.5g}") and c["ms_per_step"] == float(f"{full['ms_per_step']:.5g}")
+    assert c["value"] == full["value"] and c["ms_per_step"] == full["ms_per_step"]   # every digit: the driver checks one against the other
     assert c["config"]["workload"] == full["config"]["workload"]
     for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms_per_launch", "issue_frac"):
         assert k in c["roofline"], k
