@@ -228,9 +228,32 @@ int validate(const ra_config &c, int32_t n_streams) {
   if (c.vocoder_kind == RA_VOCODER_BANDPASS && !(c.vocoder_env_follower_cutoff_ratio > 0.f)) return fail(RA_EINVAL, "vocoder_env_follower_cutoff_ratio must be > 0");
   if (c.post != RA_POST_NONE && c.post != RA_POST_LIMIT) return fail(RA_EINVAL, "unknown post (RA_POST_NONE / RA_POST_LIMIT)");
   if (c.carrier_n_channels < 0 || c.carrier_n_channels > RA_MAX_CHANNELS) return fail(RA_EINVAL, "carrier_n_channels must be in 0..256");
-  if (c.carrier_n_channels > 0 && c.vocoder_carrier_noise_volume != 0.f)
-    return fail(RA_EINVAL, "vocoder_carrier_noise_volume must be 0: the noise voice plays a sound buffer of cpp.algorithms, which is absent (DESIGN.md §8)");
   return RA_OK;
+}
+
+// The white-noise sound buffer the carrier's noise voice plays: getWhiteNoise(sample_rate) (source/sound.cpp:3-21) =
+// soundBuffer(soundId{sample_rate, Sound::NOISE, noise_duration = .05f}) — the constant is consumed as a frequency (include/sound.h:53-60), so
+// the buffer holds freq_to_period_in_samples(.05f, sample_rate) = int(float(sample_rate) / .05f) frames (include/sound.functions.h:45-50;
+// 960 000 at 48 kHz) of white_gaussian_noise (sound.cpp:134-147 -> generate :84-100; include/noise.h:3-5), each a float widened to double.
+// The draw itself — std::normal_distribution<float> over the OS-seeded mersenne<SEEDED::No>() — is this build's declared policy (DESIGN.md
+// §5): sample i = Box-Muller of two 24-bit uniforms from the counter hash of (a fixed key, i), evaluated in double, rounded to float.
+uint64_t mix64_noise(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+std::vector<double> build_white_noise(int sample_rate) {
+  const float freq_hz = .05f, sr = static_cast<float>(sample_rate);
+  const int period = std::max(1, static_cast<int>(sr / freq_hz));
+  std::vector<double> v(static_cast<size_t>(period));
+  for (size_t i = 0; i < v.size(); ++i) {
+    const uint64_t h = mix64_noise(0x77686974656e6f69ull ^ mix64_noise(static_cast<uint64_t>(i) * 2 + 7));
+    const double u1 = (static_cast<double>(h >> 40) + 1.0) * (1.0 / 16777216.0);            // (0, 1]
+    const double u2 = static_cast<double>((h >> 16) & 0xffffffull) * (1.0 / 16777216.0);     // [0, 1)
+    v[i] = static_cast<float>(std::sqrt(-2.0 * std::log(u1)) * std::cos(2.0 * M_PI * u2));
+  }
+  return v;
 }
 
 // twiddle / bit-reversal tables of a real FFT of length L done as an M = L/2 point complex FFT
@@ -441,6 +464,11 @@ int build_tables(ra_context *c) {
     if ((r = upload(c, &b.allowed, allowed))) return r;
   }
   if (p.voc_enabled && (r = build_vocoder_tables(c))) return r;
+  if (p.car_P > 0 && cfg.vocoder_carrier_noise_volume != 0.f) { // the noise voice's sound buffer: 7.7 MB at 48 kHz, shared by every stream and channel
+    std::vector<double> nz = build_white_noise(cfg.sample_rate);
+    b.car_noise_len = static_cast<int32_t>(nz.size());
+    if ((r = upload(c, &b.car_noise, nz))) return r;
+  }
   return RA_OK;
 }
 
@@ -525,6 +553,7 @@ int init_state(ra_context *c) {
         d[SD_OSC_CRE * p.car_Ppad + l] = 1.0; d[SD_OSC_MRE * p.car_Ppad + l] = 1.0; d[SD_OSC_ALIAS * p.car_Ppad + l] = 1.0;
         i[SI_ENV_STATE * p.car_Ppad + l] = ENV_DONE2; i[SI_ENV_RELDELAY * p.car_Ppad + l] = -1; i[SI_ENV_AHDSTATE * p.car_Ppad + l] = -1;
         ext[s * CX_COUNT * p.car_Ppad + CX_PH_ALIAS * p.car_Ppad + l] = 1.0;
+        ext[s * CX_COUNT * p.car_Ppad + CX_NZ_INDEX * p.car_Ppad + l] = -1.0; // soundBufferWrapperAlgo::index, audioelement.h:1581
       }
     HIP_TRY(hipMemcpyAsync(b.car_sd, sd.data(), sd.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(b.car_si, si.data(), si.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));

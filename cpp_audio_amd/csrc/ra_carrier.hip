@@ -11,8 +11,10 @@
 //      * the four Phased oscillators share one angle: same start angle (UnityGainMix::setStartAngle / synchronizeAngles,
 //        :1940-1964), same increments, same steps;
 //      * the pulse's "used" width / levels: reset by forgetPastSignals and re-latched by the initializer at every note-on.
-//    The noise voice (soundBufferWrapperAlgo<NOISE>, an L0 buffer) has volume 0 (ra_create enforces it): 0 * sample = 0; its constant
-//    angleIncrements() = 0.5f (include/sound.h:256-258) still enters UnityGainMix::angleIncrements() (:1948-1958).
+//    The noise voice (soundBufferWrapperAlgo<NOISE>, audioelement.h:1507-1583) is an index into the white-noise sound buffer
+//    (source/sound.cpp:3-21; uploaded once per context, ra_capi.hip: build_white_noise): setStartAngle / synchronizeAngles set it, every
+//    step increments it modulo the buffer's length, imag() reads the buffer; its constant angleIncrements() = 0.5f (include/sound.h:256-258)
+//    enters UnityGainMix::angleIncrements() (:1948-1958).  With volume 0 (the reference default) no buffer exists and the voice is skipped.
 //
 // K7 ra_voc_bank_kernel: Modulator<1, double> + Carrier<1, double> (source/rt.resynth.lib.vocoder.cpp:310-394, 667-732) inside the
 //    Vocoder compute lambda (:763-812).  One wavefront per stream, lane = band, samples in order; per sample and band five one-pole
@@ -38,7 +40,15 @@ __device__ inline double phase_to_normal_form(double phase) { // audioelement.h:
   return nf;
 }
 
-struct CarX { double ph_angle, ph_inc, ph_alias; }; // the Phased oscillators (one shared angle, see above)
+struct CarX { double ph_angle, ph_inc, ph_alias; int nz; }; // the Phased oscillators (one shared angle, see above); the noise voice's index
+// soundBufferWrapperAlgo::setStartAngle (audioelement.h:1544-1557), a in [-1, 1]
+__device__ inline int noise_start_index(double a, int size) {
+  int index = (int)(((a + 1.) * (double)size * 0.5) + 0.5);
+  if (index < 0) index = 0;
+  return index - 1; // "because index will be incremented in step before being used"
+}
+// soundBufferWrapperAlgo::step (:1568-1574), k >= 0 times: ++index; if (index >= size) index = 0
+__device__ inline int noise_advance(int index, int k, int size) { return k > 0 ? (int)(((long long)index + k) % size) : index; }
 
 // FreqCtrl_::angleIncrements (audioelement.h:3117-3124) over UnityGainMix::angleIncrements (:1948-1958): noise 0.5f, the four Phased
 // increments, the sine's
@@ -64,11 +74,15 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_synth_serial_kerne
   double *ext = b.car_ext + (size_t)s * CX_COUNT * Ppad;
   load_chan(c, sd, si, Ppad, l);
   x.ph_angle = ext[CX_PH_ANGLE * Ppad + l]; x.ph_inc = ext[CX_PH_INC * Ppad + l]; x.ph_alias = ext[CX_PH_ALIAS * Ppad + l];
+  x.nz = (int)ext[CX_NZ_INDEX * Ppad + l];
   int64_t noteid = b.car_noteid[(size_t)s * Ppad + l];
   int dropped = 0;
   const RaEnvParams ep = {p.envA, p.envH, p.envD, p.envR, p.SMinusOne};
   const uint64_t seed = p.seed + (uint64_t)s;
   // VocoderCarrierElementInitializer (lib.cpp:155-171): volume targets (float -> T) and PulseTrainAlgo_::setPulseWidth (audioelement.h:1701-1719)
+  const double *nzb = b.car_noise; // null: noise volume 0
+  const int nzn = b.car_noise_len;
+  const double v_noise = nzb ? (double)p.car_vol[0] : 0.0;
   const double v_saw = (double)p.car_vol[1], v_tri = (double)p.car_vol[2], v_sq = (double)p.car_vol[3],
                v_sine = (double)p.car_vol[4], v_pulse = (double)p.car_vol[5];
   double pw = (double)p.car_pulse_width;
@@ -115,18 +129,20 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_synth_serial_kerne
           if (l != sel && l < P && rt_active(c) && car_angle_increments(c, x) == xch[0]) atomicMin(&xi[1], l);
           __syncthreads();
           const int src = xi[1];
-          if (src != 0x7fffffff && l == src) { xch[1] = x.ph_angle; xch[2] = c.cre; xch[3] = c.cim; }
+          if (src != 0x7fffffff && l == src) { xch[1] = x.ph_angle; xch[2] = c.cre; xch[3] = c.cim; xi[2] = x.nz; }
           __syncthreads();
           if (l == sel) {
             if (src != 0x7fffffff) {
               x.ph_angle = phase_to_normal_form(xch[1]); // Phased::synchronizeAngles -> setStartAngle, audioelement.h:1433-1439
               c.cre = xch[2]; c.cim = xch[3];            // SineOscillatorAlgo::synchronizeAngles :2397-2399
+              x.nz = xi[2];                              // soundBufferWrapperAlgo::synchronizeAngles :1532-1537
             } else {
               const float a = (p.phase_policy == RA_PHASE_HASH) ? hash_uniform_pm1(seed, (uint64_t)q.noteid, 2) : 0.f;
               x.ph_angle = phase_to_normal_form((double)a);
               double sn, cs;
               sincos(M_PI * (double)a, &sn, &cs);          // setStartAngle :2401-2403
               c.cre = cs; c.cim = sn;
+              if (nzb) x.nz = noise_start_index((double)a, nzn);
             }
             env_on_key_pressed(c, q.delay);
           }
@@ -157,6 +173,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_synth_serial_kerne
     if (__syncthreads_and(!act || holds)) {
       if (act) {
         double ang = x.ph_angle, cre = c.cre, cim = c.cim;
+        int nz = x.nz;
         const double inc = x.ph_inc, al = x.ph_alias, mre = c.mre, mim = c.mim, sal = c.alias, vol = c.vol, val = c.value;
         // a lane's samples form two recurrences (angle; phasor) with the mix hanging off them: unrolled, so that the mix of one sample
         // issues in the shadow of the next sample's recurrence (one wave per SIMD: nothing else hides the fp64 latency)
@@ -167,6 +184,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_synth_serial_kerne
           const double g = 0.5 * (3.0 - (re * re + im * im));
           cre = re * g; cim = im * g;
           double sum = 0.f;                                          // UnityGainMix::imag, as below
+          if (v_noise != 0.) { nz = (nz + 1 >= nzn) ? 0 : nz + 1; sum += v_noise * nzb[nz]; } // soundBufferWrapperAlgo::step / imag :1563-1574
           if (v_saw != 0.) sum += v_saw * (al * wave_saw(ang));
           if (v_tri != 0.) sum += v_tri * (al * wave_triangle(ang));
           if (v_sq != 0.) sum += v_sq * (al * wave_square(ang));
@@ -180,7 +198,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_synth_serial_kerne
         } else {
           for (int i = 0; i < m; ++i) one(i);
         }
-        x.ph_angle = ang; c.cre = cre; c.cim = cim;
+        x.ph_angle = ang; c.cre = cre; c.cim = cim; x.nz = nz;
         c.counter += m;
         if (c.reldelay >= 0) c.reldelay -= m;
       } else {
@@ -200,6 +218,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_synth_serial_kerne
           x.ph_inc = phase_to_normal_form(f); x.ph_alias = alias_mult(f); // Phased::setAngleIncrements :1443-1446
           osc_set_inc(c, f);
         }
+        if (v_noise != 0.) x.nz = (x.nz + 1 >= nzn) ? 0 : x.nz + 1;   // soundBufferWrapperAlgo::step :1568-1574 (the mix's first voice)
         x.ph_angle += x.ph_inc;                                        // Phased::step :1452-1470
         if (x.ph_angle > 2.0) x.ph_angle -= 2.0;
         { // SineOscillatorAlgo::step
@@ -225,6 +244,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_synth_serial_kerne
           // UnityGainMix::imag (:1966-1972): sum = 0.f; sum += volume_i * (aliasingMult * wave_i(angle)), in tuple order.  A voice whose
           // volume is 0 adds +-0 to a sum that started at +0: skipped (workgroup-uniform tests)
           double sum = 0.f;
+          if (v_noise != 0.) sum += v_noise * nzb[x.nz];
           if (v_saw != 0.) sum += v_saw * (x.ph_alias * wave_saw(x.ph_angle));
           if (v_tri != 0.) sum += v_tri * (x.ph_alias * wave_triangle(x.ph_angle));
           if (v_sq != 0.) sum += v_sq * (x.ph_alias * wave_square(x.ph_angle));
@@ -251,6 +271,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_synth_serial_kerne
   clk.flush(8);
   store_chan(c, sd, si, Ppad, l);
   ext[CX_PH_ANGLE * Ppad + l] = x.ph_angle; ext[CX_PH_INC * Ppad + l] = x.ph_inc; ext[CX_PH_ALIAS * Ppad + l] = x.ph_alias;
+  ext[CX_NZ_INDEX * Ppad + l] = (double)x.nz;
   b.car_noteid[(size_t)s * Ppad + l] = noteid;
   if (l == 0 && dropped) b.car_dropped[s] += dropped;
 }
@@ -272,13 +293,13 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_synth_serial_kerne
 // renormalised phasor product, a 1e-13 difference.
 constexpr int CAR_G = 256; // samples per segment (segments are also cut at events)
 enum { CS_VALUE, CS_TOP, CS_FROM, CS_TO, CS_CUR, CS_C, CS_FRES, CS_INC, CS_ALIAS, CS_VOL, CS_TARGET, CS_FINIT, CS_K, CS_Y, CS_THETA, CS_PH_ANGLE, CS_PH_INC,
-       CS_PH_ALIAS, CS_COUNT };
+       CS_PH_ALIAS, CS_NZ_INDEX, CS_COUNT };
 
 __device__ inline void car_store_seg(const Chan &c, const CarX &x, double *d, int *i, int CH, int ch) {
   d[CS_VALUE * CH + ch] = c.value; d[CS_TOP * CH + ch] = c.top; d[CS_FROM * CH + ch] = c.from; d[CS_TO * CH + ch] = c.to; d[CS_CUR * CH + ch] = c.cur;
   d[CS_C * CH + ch] = c.C; d[CS_FRES * CH + ch] = c.fres; d[CS_INC * CH + ch] = c.inc; d[CS_ALIAS * CH + ch] = c.alias; d[CS_VOL * CH + ch] = c.vol;
   d[CS_TARGET * CH + ch] = c.target; d[CS_FINIT * CH + ch] = c.finit; d[CS_K * CH + ch] = c.k; d[CS_Y * CH + ch] = c.y; d[CS_THETA * CH + ch] = c.theta;
-  d[CS_PH_ANGLE * CH + ch] = x.ph_angle; d[CS_PH_INC * CH + ch] = x.ph_inc; d[CS_PH_ALIAS * CH + ch] = x.ph_alias;
+  d[CS_PH_ANGLE * CH + ch] = x.ph_angle; d[CS_PH_INC * CH + ch] = x.ph_inc; d[CS_PH_ALIAS * CH + ch] = x.ph_alias; d[CS_NZ_INDEX * CH + ch] = (double)x.nz;
   i[SI_ENV_STATE * CH + ch] = c.state; i[SI_ENV_COUNTER * CH + ch] = c.counter; i[SI_ENV_RELDELAY * CH + ch] = c.reldelay;
   i[SI_ENV_AHDSTATE * CH + ch] = c.ahdstate; i[SI_ENV_AHDCOUNTER * CH + ch] = c.ahdcounter; i[SI_ENV_MINCH * CH + ch] = c.minch;
   i[SI_ENV_NEXTMINCH * CH + ch] = c.nextminch; i[SI_FLAGS * CH + ch] = c.flags;
@@ -287,7 +308,7 @@ __device__ inline void car_load_seg(Chan &c, CarX &x, const double *d, const int
   c.value = d[CS_VALUE * CH + ch]; c.top = d[CS_TOP * CH + ch]; c.from = d[CS_FROM * CH + ch]; c.to = d[CS_TO * CH + ch]; c.cur = d[CS_CUR * CH + ch];
   c.C = d[CS_C * CH + ch]; c.fres = d[CS_FRES * CH + ch]; c.inc = d[CS_INC * CH + ch]; c.alias = d[CS_ALIAS * CH + ch]; c.vol = d[CS_VOL * CH + ch];
   c.target = d[CS_TARGET * CH + ch]; c.finit = d[CS_FINIT * CH + ch]; c.k = d[CS_K * CH + ch]; c.y = d[CS_Y * CH + ch]; c.theta = d[CS_THETA * CH + ch];
-  x.ph_angle = d[CS_PH_ANGLE * CH + ch]; x.ph_inc = d[CS_PH_INC * CH + ch]; x.ph_alias = d[CS_PH_ALIAS * CH + ch];
+  x.ph_angle = d[CS_PH_ANGLE * CH + ch]; x.ph_inc = d[CS_PH_INC * CH + ch]; x.ph_alias = d[CS_PH_ALIAS * CH + ch]; x.nz = (int)d[CS_NZ_INDEX * CH + ch];
   c.state = i[SI_ENV_STATE * CH + ch]; c.counter = i[SI_ENV_COUNTER * CH + ch]; c.reldelay = i[SI_ENV_RELDELAY * CH + ch];
   c.ahdstate = i[SI_ENV_AHDSTATE * CH + ch]; c.ahdcounter = i[SI_ENV_AHDCOUNTER * CH + ch]; c.minch = i[SI_ENV_MINCH * CH + ch];
   c.nextminch = i[SI_ENV_NEXTMINCH * CH + ch]; c.flags = i[SI_FLAGS * CH + ch];
@@ -328,6 +349,9 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_walk_kernel(RaPara
   double *ext = b.car_ext + (size_t)s * CX_COUNT * Ppad;
   load_chan(c, sd, si, Ppad, l);
   x.ph_angle = ext[CX_PH_ANGLE * Ppad + l]; x.ph_inc = ext[CX_PH_INC * Ppad + l]; x.ph_alias = ext[CX_PH_ALIAS * Ppad + l];
+  x.nz = (int)ext[CX_NZ_INDEX * Ppad + l];
+  const bool has_noise = b.car_noise != nullptr; // (noise volume != 0)
+  const int nzn = b.car_noise_len;
   int64_t noteid = b.car_noteid[(size_t)s * Ppad + l];
   int dropped = 0;
   const RaEnvParams ep = {p.envA, p.envH, p.envD, p.envR, p.SMinusOne};
@@ -371,16 +395,18 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_walk_kernel(RaPara
           if (l != sel && l < P && rt_active(c) && car_angle_increments(c, x) == xch[0]) atomicMin(&xi[1], l);
           __syncthreads();
           const int src = xi[1];
-          if (src != 0x7fffffff && l == src) { xch[1] = x.ph_angle; xch[2] = c.theta; }
+          if (src != 0x7fffffff && l == src) { xch[1] = x.ph_angle; xch[2] = c.theta; xi[2] = x.nz; }
           __syncthreads();
           if (l == sel) {
             if (src != 0x7fffffff) {
               x.ph_angle = phase_to_normal_form(xch[1]);
               c.theta = xch[2];                          // SineOscillatorAlgo::synchronizeAngles :2397-2399, in the phase domain
+              x.nz = xi[2];                              // soundBufferWrapperAlgo::synchronizeAngles :1532-1537
             } else {
               const float a = (p.phase_policy == RA_PHASE_HASH) ? hash_uniform_pm1(seed, (uint64_t)q.noteid, 2) : 0.f;
               x.ph_angle = phase_to_normal_form((double)a);
               c.theta = (double)a;                       // setStartAngle :2401-2403
+              if (has_noise) x.nz = noise_start_index((double)a, nzn);
             }
             env_on_key_pressed(c, q.delay);
           }
@@ -446,6 +472,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_walk_kernel(RaPara
         th -= 2.0 * floor(0.5 * th);
         c.theta = th;
       }
+      if (has_noise) x.nz = noise_advance(x.nz, na, nzn); // soundBufferWrapperAlgo::step, `na` times
     }
     t = seg_end;
   }
@@ -453,6 +480,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_walk_kernel(RaPara
   for (int64_t q = seg + l; q < seg_stop; q += blockDim.x) b.car_seg_info[q] = make_int4(s, 0, 0, 0);
   store_chan(c, sd, si, Ppad, l);
   ext[CX_PH_ANGLE * Ppad + l] = x.ph_angle; ext[CX_PH_INC * Ppad + l] = x.ph_inc; ext[CX_PH_ALIAS * Ppad + l] = x.ph_alias;
+  ext[CX_NZ_INDEX * Ppad + l] = (double)x.nz;
   b.car_noteid[(size_t)s * Ppad + l] = noteid;
   if (l == 0 && dropped) b.car_dropped[s] += dropped;
 }
@@ -482,7 +510,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_render_kernel(RaPa
   Chan c;
   CarX x;
   chan_init(c);
-  x.ph_angle = 0; x.ph_inc = 0; x.ph_alias = 1;
+  x.ph_angle = 0; x.ph_inc = 0; x.ph_alias = 1; x.nz = -1;
   const int len = info.z;
   if (len > 0 && ch < P) {
     car_load_seg(c, x, b.car_seg_d + (size_t)seg * CS_COUNT * CH, b.car_seg_i + (size_t)seg * SI_COUNT * CH, CH, ch);
@@ -493,6 +521,9 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_render_kernel(RaPa
     c.mre = cs; c.mim = sn;
   }
   const RaEnvParams ep = {p.envA, p.envH, p.envD, p.envR, p.SMinusOne};
+  const double *nzb = b.car_noise; // null: noise volume 0
+  const int nzn = b.car_noise_len;
+  const double v_noise = nzb ? (double)p.car_vol[0] : 0.0;
   const double v_saw = (double)p.car_vol[1], v_tri = (double)p.car_vol[2], v_sq = (double)p.car_vol[3],
                v_sine = (double)p.car_vol[4], v_pulse = (double)p.car_vol[5];
   double pw = (double)p.car_pulse_width;
@@ -506,6 +537,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_render_kernel(RaPa
                        c.fres == c.to && c.inc == c.to && (c.flags & FL_HAS_VOL) && c.vol == c.target;
     if (__all(!act || holds)) { // every sounding channel of the wave just holds its note: oscillators and mix only
       double ang = x.ph_angle, cre = c.cre, cim = c.cim;
+      int nz = x.nz;
       const double inc = x.ph_inc, al = x.ph_alias, mre = c.mre, mim = c.mim, sal = c.alias, vol = c.vol, val = c.value;
       auto one = [&](int i) {
         ang += inc;                                                // Phased::step :1452-1470
@@ -514,6 +546,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_render_kernel(RaPa
         const double gn = 0.5 * (3.0 - (re * re + im * im));
         cre = re * gn; cim = im * gn;
         double sum = 0.f;                                          // UnityGainMix::imag
+        if (v_noise != 0.) { nz = (nz + 1 >= nzn) ? 0 : nz + 1; sum += v_noise * nzb[nz]; } // soundBufferWrapperAlgo::step / imag :1563-1574
         if (v_saw != 0.) sum += v_saw * (al * wave_saw(ang));
         if (v_tri != 0.) sum += v_tri * (al * wave_triangle(ang));
         if (v_sq != 0.) sum += v_sq * (al * wave_square(ang));
@@ -528,7 +561,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_render_kernel(RaPa
         } else {
           for (int i = 0; i < m; ++i) one(i);
         }
-        x.ph_angle = ang; c.cre = cre; c.cim = cim;
+        x.ph_angle = ang; c.cre = cre; c.cim = cim; x.nz = nz;
         c.counter += m;
         if (c.reldelay >= 0) c.reldelay -= m;
       } else {
@@ -545,6 +578,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_render_kernel(RaPa
             x.ph_inc = phase_to_normal_form(f); x.ph_alias = alias_mult(f);
             osc_set_inc(c, f);
           }
+          if (v_noise != 0.) x.nz = (x.nz + 1 >= nzn) ? 0 : x.nz + 1;
           x.ph_angle += x.ph_inc;
           if (x.ph_angle > 2.0) x.ph_angle -= 2.0;
           {
@@ -566,6 +600,7 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_render_kernel(RaPa
           }
           if (rt_active(c)) {
             double sum = 0.f;
+            if (v_noise != 0.) sum += v_noise * nzb[x.nz];
             if (v_saw != 0.) sum += v_saw * (x.ph_alias * wave_saw(x.ph_angle));
             if (v_tri != 0.) sum += v_tri * (x.ph_alias * wave_triangle(x.ph_angle));
             if (v_sq != 0.) sum += v_sq * (x.ph_alias * wave_square(x.ph_angle));

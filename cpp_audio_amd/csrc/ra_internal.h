@@ -154,7 +154,9 @@ struct RaBuffers {
   // ---- vocoder carrier synth (only with carrier_n_channels > 0 and a vocoder volume non-zero) ----
   double *car_sd;           // [n_streams][SD_COUNT][car_Ppad] envelope / control / sine oscillator / outer volume, like sd
   int32_t *car_si;          // [n_streams][SI_COUNT][car_Ppad]
-  double *car_ext;          // [n_streams][CX_COUNT][car_Ppad] the phase-controlled oscillators
+  double *car_ext;          // [n_streams][CX_COUNT][car_Ppad] the phase-controlled oscillators, the noise voice's index
+  double *car_noise;        // [car_noise_len] the white-noise sound buffer (getWhiteNoise, source/sound.cpp:3-21), null while the noise volume is 0
+  int32_t car_noise_len;
   int64_t *car_noteid;      // [n_streams][car_Ppad] note id each channel last played (-1 = never used), gen.crtp.h:419
   int32_t *car_dropped;     // [n_streams] note-ons dropped for want of a free channel
   struct RaCarEv *car_ev;   // the block's note events, stream after stream, in queue order
@@ -298,7 +300,7 @@ struct RaCarEv {
   int32_t delay;   // frames handed to onKeyPressed / onKeyReleased
   float freq, vel;
 };
-enum { CX_PH_ANGLE, CX_PH_INC, CX_PH_ALIAS, CX_COUNT };
+enum { CX_PH_ANGLE, CX_PH_INC, CX_PH_ALIAS, CX_NZ_INDEX /* the noise voice's buffer index, an integer held as a double */, CX_COUNT };
 void ra_launch_limiter(const RaParams &p, const RaBuffers &b, int64_t r0, int64_t r1, int64_t n, float *d_out, hipStream_t st);
 void ra_launch_carrier_synth(const RaParams &p, const RaBuffers &b, int64_t t0, int64_t n, int64_t total_segs, hipStream_t st);
 int ra_carrier_seg_doubles(); // doubles of channel state per (segment, channel slot) in car_seg_d

@@ -115,8 +115,10 @@ typedef struct ra_config {
    * The vocoder carrier synth (SynthVocoderCarier, lib.cpp:212-221: VocoderCarrierElement, :21-52, initialised by
    * VocoderCarrierElementInitializer, :137-196).  carrier_n_channels = 2 * nVoices (reference: 254), 0 = no synth.  The vocoder takes its
    * carrier from the synth when ra_process_* is given no carrier buffer (the reference: realtime mode the synth, offline job the file,
-   * lib.cpp:1405-1412); notes come from ra_carrier_events.  The noise voice reads a sound buffer of the absent cpp.algorithms:
-   * vocoder_carrier_noise_volume must be 0 (ra_create refuses anything else).
+   * lib.cpp:1405-1412); notes come from ra_carrier_events.  The noise voice (soundBufferWrapperAlgo<Sound::NOISE>, audioelement.h:1507-1583)
+   * plays the white-noise sound buffer of source/sound.cpp:3-21 — int(sample_rate / .05f) frames of white_gaussian_noise (include/noise.h:3-5),
+   * one buffer for all streams like the reference's process-wide static; the draws behind it (std::normal_distribution<float> over an
+   * OS-seeded engine) are this build's declared policy, DESIGN.md §5.  The buffer exists only while vocoder_carrier_noise_volume != 0.
    */
   int32_t carrier_n_channels; /* 0..256 */
   float vocoder_carrier_noise_volume, vocoder_carrier_saw_volume, vocoder_carrier_triangle_volume, vocoder_carrier_square_volume,

@@ -38,6 +38,12 @@ void ora_det_math(const double *x, int64_t n, int which, double *out) {
   for (int64_t i = 0; i < n; ++i) out[i] = which == 0 ? det_log2(x[i]) : which == 1 ? det_log10(x[i]) : which == 2 ? det_exp10(x[i]) : Midi().midi_pitch_to_freq_event(x[i]);
 }
 float ora_equal_loudness_volume_db(double pitch, int level) { return loudness::equal_loudness_volume_db(pitch, level); }
+// the white-noise sound buffer of the carrier's noise voice (oracle_carrier.hpp): returns its length, copies the first min(cap, length) samples
+int64_t ora_white_noise(int32_t sample_rate, double *out, int64_t cap) {
+  auto const &b = getWhiteNoise(sample_rate);
+  for (int64_t i = 0; i < cap && i < static_cast<int64_t>(b.size()); ++i) out[i] = b[i];
+  return static_cast<int64_t>(b.size());
+}
 void ora_stereo(double pan, double *l, double *r) { auto g = stereo(pan); *l = g.gains[0]; *r = g.gains[1]; }
 float ora_hash_uniform_pm1(uint64_t seed, uint64_t noteid, uint64_t salt) { return hash_uniform_pm1(seed, noteid, salt); }
 

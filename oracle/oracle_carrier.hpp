@@ -6,15 +6,19 @@
  *      Restated from include/audioelement.h: Phased (:1395-1477), FOscillatorAlgo_ (:1651-1676), PulseTrainAlgo_ (:1691-1748),
  *      soundBufferWrapperAlgo (:1507-1583), UnityGainMix (:1882-1982), BaseVolumeAdjusted / VolumeAdjusted (:1110-1265),
  *      Enveloped (:181-291), FreqCtrl_ (:3055-3155), InterpolatedFreq (:2705-2817), and include/sound.functions.h:86-138.
- *      The noise voice reads an L0 sound buffer (getWhiteNoise, absent): it is stepped like the reference's (an index), its samples
- *      are unknown, and a configuration with a non-zero noise volume is refused — with volume 0 its contribution is 0 * sample = 0,
- *      and its constant angleIncrements() (0.5f, include/sound.h:256-258) still takes part in UnityGainMix::angleIncrements().
+ *      The noise voice plays the process-wide white-noise sound buffer (getWhiteNoise, source/sound.cpp:3-21 -> soundBuffer::soundBuffer
+ *      :134-147 -> generate :84-100 over white_gaussian_noise, include/noise.h:3-5; the buffer's length from include/sound.h:53-60 and
+ *      include/sound.functions.h:45-50), all of it in the reference; the only thing outside it is the unseeded mersenne<SEEDED::No>()
+ *      engine behind std::normal_distribution<float> — implementation-defined twice over — for which white_noise_sample() below is this
+ *      build's DECLARED policy (parity unpinned like the other draws).  Its constant angleIncrements() (0.5f,
+ *      include/sound.h:256-258) takes part in UnityGainMix::angleIncrements().
  *  (b) the band-pass bank the author replaced by FFTs (source/rt.resynth.lib.vocoder.cpp:46-79 BandPass / EnvelopeFollower,
  *      :310-394 Modulator, :667-732 Carrier; orders 1, :737-738).  Its L0 filters are PARITY UNPINNED like every Filter<> on this
  *      path; decisions below.
  */
 #pragma once
 #include "oracle_synth.hpp"
+#include <mutex>
 #include <unordered_map>
 
 namespace ora {
@@ -72,16 +76,56 @@ struct PulseTrainAlgo_ { // audioelement.h:1691-1748
   void onForgetPastSignals() { used_pulse_width.reset(); }
   void onNewPeriod() { used_pulse_width = pulse_width; used_high = high; used_low = low; }
 };
-// soundBufferWrapperAlgo<Sound::NOISE> audioelement.h:1507-1583: an index into an L0 buffer whose samples are not available here
-struct NoiseStub {
+// ---- the white-noise sound buffer: getWhiteNoise(sample_rate), source/sound.cpp:3-21 ---------------------------------------------
+// soundId{sample_rate, Sound::NOISE, noise_duration = .05f}: the constant is consumed as a FREQUENCY (include/sound.h:53-60), so the buffer
+// holds freq_to_period_in_samples(.05f, sample_rate) = int(float(sample_rate) / .05f) frames (include/sound.functions.h:45-50): 960 000 at
+// 48 kHz.  soundBuffer::soundBuffer (sound.cpp:134-147) -> generate(period, white_gaussian_noise) (:84-100): values[i] = the float draw,
+// widened to the buffer's double.  (The period is >= 20: the centring / maximising of :196-219 does not apply.)
+inline int white_noise_period(int sample_rate) {
+  float const freq_hz = .05f, sr = static_cast<float>(sample_rate);
+  return static_cast<int>(sr / freq_hz);
+}
+// DECLARED POLICY for `std::normal_distribution<float>{0.f, 1.f}(mersenne<SEEDED::No>())` (include/noise.h:3-5): the reference draws the
+// buffer once per process from an engine seeded by the OS, so no two runs of it agree; here sample i is, once and for all, the Box-Muller
+// transform of two 24-bit uniforms taken from the counter hash of (a fixed key, i): u1 in (0, 1], u2 in [0, 1),
+// z = sqrt(-2 ln u1) cos(2 pi u2) evaluated in double and rounded to the float the reference's draw is.
+inline float white_noise_sample(uint64_t i) {
+  uint64_t const h = splitmix64(0x77686974656e6f69ull ^ splitmix64(i * 2 + 7)); // key: "whitenoi"; salt 7
+  double const u1 = (static_cast<double>(h >> 40) + 1.0) * (1.0 / 16777216.0);
+  double const u2 = static_cast<double>((h >> 16) & 0xffffffull) * (1.0 / 16777216.0);
+  return static_cast<float>(std::sqrt(-2.0 * std::log(u1)) * std::cos(2.0 * M_PI * u2));
+}
+inline std::vector<double> const &getWhiteNoise(int sample_rate) { // one buffer per sample rate and process, like the reference's static
+  static std::mutex mu;
+  static std::unordered_map<int, std::vector<double>> bufs;
+  std::lock_guard<std::mutex> g(mu);
+  auto it = bufs.find(sample_rate);
+  if (it == bufs.end()) {
+    std::vector<double> v(static_cast<size_t>(std::max(1, white_noise_period(sample_rate))));
+    for (size_t i = 0; i < v.size(); ++i) v[i] = white_noise_sample(i);
+    it = bufs.emplace(sample_rate, std::move(v)).first;
+  }
+  return it->second;
+}
+// soundBufferWrapperAlgo<Sound::NOISE> audioelement.h:1507-1583
+struct NoiseVoice {
   int index = -1;
+  std::vector<double> const *sb = nullptr;
+  void set_sample_rate(int s) { sb = &getWhiteNoise(s); } // :1524-1527
   void forgetPastSignals() {}
-  void synchronizeAngles(NoiseStub const &o) { index = o.index; }
-  void setStartAngle(double) {} // the index it derives needs the buffer's size (L0); irrelevant at volume 0
+  void synchronizeAngles(NoiseVoice const &o) { index = o.index; } // :1532-1537
+  void setStartAngle(double a) { // :1544-1557: a in [-1, 1]
+    index = static_cast<int>(((a + 1.) * sb->size() * 0.5) + 0.5);
+    if (index < 0) index = 0;
+    --index; // "because index will be incremented in step before being used"
+  }
   void setAngleIncrements(double) {}
   double angleIncrements() const { return 0.5f; } // FGetBuffer<NOISE>::getAngleIncrements, include/sound.h:256-258
-  void step() { ++index; }
-  double imag() const { return 0.0; } // times a volume that is required to be 0
+  void step() { // :1568-1574
+    ++index;
+    if (index >= static_cast<int>(sb->size())) index = 0;
+  }
+  double imag() const { return (*sb)[index]; } // :1563-1566
 };
 // SineOscillatorAlgo needs the same three entry points under VolumeAdjusted
 struct SineVoice : SineOsc {
@@ -119,7 +163,7 @@ struct VolAdj {
 
 // UnityGainMix<VolumeAdjusted<noise>, VolumeAdjusted<saw>, <triangle>, <square>, <sine>, <pulse>> audioelement.h:1882-1982
 struct CarrierMix {
-  VolAdj<NoiseStub> noise;
+  VolAdj<NoiseVoice> noise;
   VolAdj<Phased<SawAlgo>> saw;
   VolAdj<Phased<TriangleAlgo>> triangle;
   VolAdj<Phased<SquareAlgo>> square;
@@ -127,6 +171,7 @@ struct CarrierMix {
   VolAdj<Phased<PulseTrainAlgo_>> pulse;
   template <typename F> void each(F f) { f(noise); f(saw); f(triangle); f(square); f(sine); f(pulse); }
   template <typename F> void each(F f) const { f(noise); f(saw); f(triangle); f(square); f(sine); f(pulse); }
+  void set_sample_rate(int s) { noise.osc.set_sample_rate(s); } // UnityGainMix:1915-1919; the other voices' are empty (:1416, :2016-2018 -> no-op)
   void forgetPastSignals() { each([](auto &ae) { ae.forgetPastSignals(); }); }
   void step() { each([](auto &ae) { ae.step(); }); }
   void setAngleIncrements(double v) { each([v](auto &ae) { ae.setAngleIncrements(v); }); }
@@ -173,6 +218,7 @@ struct CarrierElement {
     volume_target.reset();
   }
   void setVolumeTarget(double v) { volume_target = v; }
+  void set_sample_rate(int s) { mix.set_sample_rate(s); } // BaseVolumeAdjusted:1155 -> Enveloped:276-279 -> FreqCtrl_ -> UnityGainMix
   void synchronizeAnglesFrom(CarrierElement const &o) { mix.synchronizeAngles(o.mix); }
   void setStartAngle(double a) { mix.setStartAngle(a); }
   void setAngleIncrements(double a) { // VolumeAdjusted:1251 -> Enveloped:218-225 -> FreqCtrl_:3103-3108

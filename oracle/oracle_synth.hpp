@@ -263,6 +263,7 @@ struct ResynthElement {
     volume_target.reset();
   }
   void setVolumeTarget(double v) { volume_target = v; }
+  void set_sample_rate(int) {} // StereoPanned:1350 -> ... -> SineOscillatorAlgo: nothing on this element depends on it
   // what setPhase reaches through getOsc() (gen.crtp.h:141,148-152)
   void synchronizeAnglesFrom(ResynthElement const &o) { osc.synchronizeAngles(o.osc); }
   void setStartAngle(double a) { osc.setStartAngle(a); }
@@ -435,6 +436,7 @@ struct SynthT {
         auto &c = *channel;
         c.noteid = e.noteid;
         c.elem.forgetPastSignals();
+        c.elem.set_sample_rate(sample_rate);                     // :424
         c.elem.setVolumeTarget(Traits::baseVolume * e.velocity); // Element::baseVolume * velocity(float), :425
         if (initializer) (*initializer)(c.elem, true, e.noteid);
         // SynthImpl::setupAudioElement gen.sine.h:9-21

@@ -280,6 +280,7 @@ struct VoicePlayed { int64_t step; int32_t ramp, spec; };
 
 // VolumeAdjusted<SoundEngine<MODE, 2, ...>>
 struct VoiceElement {
+  void set_sample_rate(int s) { sample_rate = s; for (auto &r : ramps) r.sample_rate = s; } // gen.crtp.h:424 (the initializer sets the same value again)
   std::array<VoiceRamp, 3> ramps;
   // SoundEngine
   int mode = VOICE_SWEEP;

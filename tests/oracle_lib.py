@@ -131,6 +131,17 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def white_noise(sample_rate):
+    """The white-noise sound buffer of the carrier's noise voice (getWhiteNoise, source/sound.cpp:3-21; draws: the declared policy)."""
+    L = lib()
+    L.ora_white_noise.argtypes = [C.c_int32, C.c_void_p, C.c_int64]
+    L.ora_white_noise.restype = C.c_int64
+    n = L.ora_white_noise(int(sample_rate), None, 0)
+    out = np.zeros(n, np.float64)
+    L.ora_white_noise(int(sample_rate), _p(out), n)
+    return out
+
+
 def half_window(kind, n):
     out = np.empty(n, np.float64)
     lib().ora_half_window(C.c_int(kind), C.c_int(n), _p(out))

@@ -91,11 +91,19 @@ VOICES = dict(vocoder_carrier_saw_volume=0.3, vocoder_carrier_triangle_volume=0.
               vocoder_carrier_sine_volume=0.0, vocoder_carrier_pulse_volume=0.4, vocoder_carrier_pulse_width=0.3)
 
 
-@pytest.mark.parametrize("case", ["phased", "all_voices", "few_channels", "delays", "envelope"])
+@pytest.mark.parametrize("case", ["phased", "all_voices", "few_channels", "delays", "envelope", "noise", "noise_only", "noise_all"])
 def test_carrier_synth_matches_oracle(api, oracle, case):
     n, S = 40000, 3
     kw = dict(BASE, carrier_n_channels=16, carrier_volume=1.0, voice_volume=0.0, vocoder_volume=0.0, **VOICES)
     n_notes, max_delay = 12, 0
+    if case == "noise":        # the mix's first voice (lib.cpp:21-29,160): white-noise sound buffer + the phase-controlled voices: still bit for bit
+        kw.update(vocoder_carrier_noise_volume=0.35)
+    elif case == "noise_only":  # the classic vocoder carrier
+        kw.update(vocoder_carrier_noise_volume=0.5, vocoder_carrier_saw_volume=0.0, vocoder_carrier_triangle_volume=0.0, vocoder_carrier_square_volume=0.0,
+                  vocoder_carrier_pulse_volume=0.0)
+    elif case == "noise_all":
+        kw.update(vocoder_carrier_noise_volume=0.2, vocoder_carrier_sine_volume=0.5, env_attack_seconds=0.01, env_release_seconds=0.03)
+        max_delay = 100
     if case == "all_voices":
         kw.update(vocoder_carrier_sine_volume=0.5)
     elif case == "few_channels":
@@ -106,7 +114,7 @@ def test_carrier_synth_matches_oracle(api, oracle, case):
     elif case == "envelope":
         kw.update(env_attack_seconds=0.01, env_hold_seconds=0.005, env_decay_seconds=0.02, env_release_seconds=0.03, env_sustain_level=0.6,
                   vocoder_carrier_sine_volume=0.5)
-    rng = np.random.default_rng({"phased": 1, "all_voices": 2, "few_channels": 3, "delays": 4, "envelope": 5}[case])
+    rng = np.random.default_rng({"phased": 1, "all_voices": 2, "few_channels": 3, "delays": 4, "envelope": 5, "noise": 6, "noise_only": 7, "noise_all": 8}[case])
     rows = []
     for s in range(S):
         rows += chord_events(n, s, rng, n_notes=n_notes, max_delay=max_delay)
@@ -136,15 +144,15 @@ def test_carrier_synth_matches_oracle(api, oracle, case):
         assert dropped > 0, "the case is meant to exhaust the channels"
 
 
-@pytest.mark.parametrize("sine,channels", [(0.0, 6), (0.5, 6), (0.0, 1), (0.0, 100), (0.4, 256)])
-def test_carrier_synth_time_parallel_equals_sample_serial(api, sine, channels):
+@pytest.mark.parametrize("sine,channels,noise", [(0.0, 6, 0.0), (0.5, 6, 0.0), (0.0, 1, 0.0), (0.0, 100, 0.0), (0.4, 256, 0.0), (0.0, 6, 0.3), (0.0, 1, 0.5), (0.4, 100, 0.2)])
+def test_carrier_synth_time_parallel_equals_sample_serial(api, sine, channels, noise):
     # the default carrier synth walks the events, stores the channels' states every 256 samples and at every event, and renders the
     # segments in parallel; reference_order 1 runs the one sample-serial kernel.  The phase-controlled voices are the same operation
     # sequences in both (equal bit for bit); the sine restarts each segment from sincospi(theta).
     n, S = 50000, 4
     # (1 channel: 64 segments share a wave of the render; 100 / 256: two / four waves per segment)
-    kw = dict(BASE, carrier_n_channels=channels, carrier_volume=1.0, voice_volume=0.0, vocoder_volume=0.0, **dict(VOICES, vocoder_carrier_sine_volume=sine),
-              env_attack_seconds=0.01, env_hold_seconds=0.002, env_decay_seconds=0.03, env_release_seconds=0.05, env_sustain_level=0.5)
+    kw = dict(BASE, carrier_n_channels=channels, carrier_volume=1.0, voice_volume=0.0, vocoder_volume=0.0,
+              **dict(VOICES, vocoder_carrier_sine_volume=sine, vocoder_carrier_noise_volume=noise), env_attack_seconds=0.01, env_hold_seconds=0.002, env_decay_seconds=0.03, env_release_seconds=0.05, env_sustain_level=0.5)
     rng = np.random.default_rng(8)
     rows = []
     for s in range(S):
@@ -169,13 +177,15 @@ def test_carrier_synth_time_parallel_equals_sample_serial(api, sine, channels):
         assert np.max(np.abs(got[0][0] - got[1][0])) < 1e-11
 
 
-@pytest.mark.parametrize("kind", [0, 1])
-def test_carrier_synth_feeds_the_vocoder(api, oracle, sig, kind):
-    # BASELINE configs[2] wording: 32 bands, carrier from the synth ("gen.sine") — FFT vocoder (kind 0) and band-pass bank (kind 1)
+@pytest.mark.parametrize("kind,noise", [(0, 0.0), (1, 0.0), (0, 0.5), (1, 0.5)])
+def test_carrier_synth_feeds_the_vocoder(api, oracle, sig, kind, noise):
+    # BASELINE configs[2] wording: 32 bands, carrier from the synth ("gen.sine") — FFT vocoder (kind 0) and band-pass bank (kind 1); with
+    # noise > 0 the carrier is mostly the noise voice: the classic noise-excited vocoder
     n, S = 30000, 2
     x = sig.make_streams(S, n, base_seed=99)
     kw = dict(BASE, vocoder_kind=kind, carrier_n_channels=8, voice_volume=0.1, carrier_volume=0.05, vocoder_volume=2.0,
-              vocoder_carrier_square_volume=0.0, vocoder_carrier_sine_volume=0.6, vocoder_carrier_saw_volume=0.4)
+              vocoder_carrier_square_volume=0.0, vocoder_carrier_sine_volume=0.6 if noise == 0.0 else 0.1, vocoder_carrier_saw_volume=0.4 if noise == 0.0 else 0.0,
+              vocoder_carrier_noise_volume=noise)
     rng = np.random.default_rng(3)
     rows = []
     for s in range(S):
@@ -240,10 +250,29 @@ def test_configs2_shape_256_streams_bank_and_carrier_synth(api, oracle, sig):
         assert rms(out[s], ref) <= RMS_TOL, f"stream {s}: {rms(out[s], ref):.3g}"
 
 
+def test_carrier_noise_voice_wraps_its_buffer_and_synchronises(api, oracle):
+    # soundBufferWrapperAlgo (audioelement.h:1507-1583): the index wraps at the buffer's end — at 4 kHz the buffer holds int(4000 / .05f) =
+    # 80 000 frames, so every note that lasts 100 000 frames passes the end — and a note whose increment equals a sounding note's takes that
+    # note's index (synchronizeAngles) instead of a start angle: then both read the same samples.
+    n, sr = 100000, 4000
+    kw = dict(BASE, sample_rate=sr, vocoder_min_freq=50.0, vocoder_max_freq=1900.0, carrier_n_channels=4, carrier_volume=1.0, voice_volume=0.0, vocoder_volume=0.0,
+              vocoder_carrier_noise_volume=0.5, vocoder_carrier_saw_volume=0.25, vocoder_carrier_square_volume=0.0)
+    rows = [(10, 0, 0, 60, 0, 220.0, 0.9), (5000, 0, 0, 61, 0, 220.0, 0.5), (7000, 0, 0, 62, 0, 330.0, 0.7), (90000, 0, 1, 60, 0, 0.0, 0.0), (95000, 0, 1, 61, 0, 0.0, 0.0)]
+    with api.Context(api.default_config(**kw), 1, 0) as ctx:
+        ctx.carrier_events(rows)
+        parts = []
+        for m in (30000, 1, 69999):   # (cuts inside a note: the index is part of the carried state)
+            ctx.process_host(None, None, n_frames=m)
+            parts.append(ctx.carrier(m, 0))
+        assert ctx.stats().error_flags == 0
+    got = np.concatenate(parts)
+    _, car, _, _ = oracle.run_offline_ex(oracle.default_config(**kw), None, None, oracle_events(oracle, rows, 0), n_frames=n, want_carrier=True)
+    assert oracle.white_noise(sr).shape == (80000,)
+    assert np.sqrt(np.mean(car ** 2)) > 0.1
+    assert np.array_equal(got, car), f"max diff {np.max(np.abs(got - car)):.3g} at {np.argmax(np.abs(got - car))}"
+
+
 def test_f2_argument_errors(api):
-    with pytest.raises(api.RaError) as e:
-        api.Context(api.default_config(**dict(BASE, carrier_n_channels=4, vocoder_carrier_noise_volume=0.1)), 1, 0)
-    assert e.value.code == -1 and "noise" in str(e.value)
     with pytest.raises(api.RaError):
         api.Context(api.default_config(**dict(BASE, vocoder_kind=7)), 1, 0)
     with api.Context(api.default_config(**dict(BASE, carrier_n_channels=4, carrier_volume=1.0)), 2, 0) as ctx:

@@ -87,3 +87,49 @@ def test_note_off_releases_the_earliest_note_on_of_its_key(oracle):
     f = np.fft.rfftfreq(len(tail), 1 / SR)
     assert abs(f[np.argmax(spec)] - 3000.0) < 60.0
     assert abs(np.max(np.abs(tail)) - 0.5) < 0.01
+
+
+def test_white_noise_buffer_length_and_law(oracle):
+    # getWhiteNoise (source/sound.cpp:3-21): soundId{sample_rate, NOISE, .05f} holds int(float(sample_rate) / .05f) frames
+    # (include/sound.h:53-60, include/sound.functions.h:45-50) of white_gaussian_noise (include/noise.h:3-5).  The draws are the declared
+    # policy; what can be held against mathematics is their law: mean 0, variance 1, normal quantiles, no correlation between samples.
+    from scipy import stats
+    for sr in (48000, 44100, 4000):
+        assert len(oracle.white_noise(sr)) == int(np.float32(sr) / np.float32(0.05))
+    b = oracle.white_noise(48000)
+    assert len(b) == 960000
+    assert np.array_equal(b, b.astype(np.float32).astype(np.float64)), "every sample is a float draw widened to the buffer's double"
+    assert abs(b.mean()) < 4.0 / np.sqrt(len(b)) and abs(b.var() - 1.0) < 4.0 * np.sqrt(2.0 / len(b))
+    assert stats.kstest(b[::7], "norm").pvalue > 1e-3
+    assert abs(stats.kurtosis(b)) < 0.03 and abs(stats.skew(b)) < 0.015
+    # whiteness: the normalised autocorrelation at lags 1 .. 64 stays inside 4.5 sigma = 4.5 / sqrt(n)
+    f = np.fft.rfft(b - b.mean(), 2 * len(b))
+    ac = np.fft.irfft(f * np.conj(f))[:65]
+    assert np.max(np.abs(ac[1:] / ac[0])) < 4.5 / np.sqrt(len(b))
+    # ... and a flat spectrum: the power in 16 equal bands agrees within 2 %
+    p = (np.abs(np.fft.rfft(b)) ** 2)[1:]
+    bands = p[:len(p) // 16 * 16].reshape(16, -1).sum(axis=1)
+    assert np.max(np.abs(bands / bands.mean() - 1.0)) < 0.02
+    assert np.array_equal(oracle.white_noise(48000), b)   # one buffer per sample rate and process, like the reference's static
+
+
+def test_carrier_noise_voice_closed_form(oracle):
+    # soundBufferWrapperAlgo<NOISE> under VolumeAdjusted, UnityGainMix, Enveloped and the outer volume (lib.cpp:21-52): with phase policy zero
+    # the start angle is 0 -> setStartAngle: index = int((0 + 1) size / 2 + .5) - 1, and step k (1-based) of the note reads buffer[index + k] mod size
+    n, on, off = 9000, 100, 6000
+    cfg = oracle.default_config(carrier_n_channels=4, carrier_volume=1.0, voice_volume=0.0, vocoder_volume=0.0, analysis_volume=0.0, phase_policy=1,
+                                vocoder_carrier_square_volume=0.0, vocoder_carrier_noise_volume=0.25)
+    ev = oracle.carrier_events([(on, 0, 69, 0, 0.0, 0.5), (off, 1, 69)])
+    _, car, _, dr = oracle.run_offline_ex(cfg, None, None, ev, n_frames=n, want_carrier=True)
+    assert dr == (0, 0)
+    b = oracle.white_noise(SR)
+    start = int((0.0 + 1.0) * len(b) * 0.5 + 0.5) - 1
+    inc = np.float32(2) * np.float32(440.0) / np.float32(SR)
+    A = max(SR // 1000, int(0.5 + 2.5 * (2.0 / float(inc))))
+    k = np.arange(n)
+    steps = k - on + 1                                  # the note-on's one-shot runs before frame `on`'s step
+    env = np.clip(steps / A, 0.0, 1.0)
+    m = (k >= on) & (k < off)
+    want = 0.5 * ((0.25 * b[(start + steps[m]) % len(b)]) * env[m])   # volume (velocity * 1) * (mix * envelope), the mix = noise volume * sample
+    assert np.array_equal(car[m], want)
+    assert np.all(car[:on] == 0) and np.all(car[off + A + 20:] == 0)
