@@ -2036,6 +2036,9 @@ struct ra_voice {
   int64_t launches[2] = {0, 0};
   double host_ms[6] = {0, 0, 0, 0, 0, 0}; // RA_VOICE_PROFILE: jobs, prefix, staging wait, emit, grow + copies, launches
   int64_t host_blocks = 0;
+  // a block failed after its events had been consumed and channel / live-note state changed (a size limit, a staging or device allocation, a
+  // HIP call before the launches): the object is then neither at the block's start nor at its end; every later block returns RA_EINTERNAL
+  bool poisoned = false;
 };
 
 namespace {
@@ -2417,9 +2420,10 @@ void *voice_stage(ra_voice *v, size_t bytes, int &err) { // the pinned staging b
   return sg.h;
 }
 
-int voice_block(ra_voice *v, int64_t n, float *d_out) {
+int voice_block_impl(ra_voice *v, int64_t n, float *d_out, bool &started) {
   HIP_TRY(hipSetDevice(v->device));
   if (n > INT32_MAX / 4) return fail(RA_EINVAL, "a block must have fewer than 2^29 frames");
+  started = true; // from here on the streams' queues, channels and live notes are being advanced
   const int S = v->n_streams, L = ra_voice::kTile;
   const int64_t t0 = v->t, t1 = v->t + n;
   auto clk = [] { return std::chrono::steady_clock::now(); };
@@ -2436,7 +2440,7 @@ int voice_block(ra_voice *v, int64_t n, float *d_out) {
   }
   if (n_states > INT32_MAX - 2 || n_jobs > INT32_MAX - 2) return fail(RA_EINVAL, "the block has too many ramps: process it in shorter pieces");
   const int g_log2 = pow2_ceil_log2(g_needed), g = 1 << g_log2;
-  if (g > 1024) return fail(RA_EINTERNAL, "more than 1024 overlapping ramps in a stream");
+  if (g > 1024) return fail(RA_EINTERNAL, "more than 1024 overlapping ramps in a stream"); // (not reachable: <= 256 channels of three ramps each)
   // ---- staging image: jobs sorted by (stream, slot, begin), the slots' offsets, the jobs the pre-pass works on ----
   const int64_t n_slots = (int64_t)S * g + 1;
   const size_t bytes_jobs = sizeof(RaVoiceJob) * (size_t)n_jobs, bytes_slots = sizeof(int32_t) * (size_t)n_slots, bytes_order = sizeof(int32_t) * (size_t)n_work;
@@ -2503,6 +2507,16 @@ int voice_block(ra_voice *v, int64_t n, float *d_out) {
   v->state_idx = (v->state_idx + 1) % 3;
   v->t += n;
   return RA_OK;
+}
+// A block either completes, or fails before it touched anything (a bad size: the call can be repeated), or fails midway: then the object is
+// poisoned (ra_context's rule, include/resynth_amd.h) — its events are consumed, t / parity / state slots are not advanced — and refuses
+// every later block; the caller recreates it.
+int voice_block(ra_voice *v, int64_t n, float *d_out) {
+  if (v->poisoned) return fail(RA_EINTERNAL, "an earlier block failed midway: the voice object is in an undefined state; destroy and recreate it");
+  bool started = false;
+  const int r = voice_block_impl(v, n, d_out, started);
+  if (r && started) v->poisoned = true;
+  return r;
 }
 } // namespace
 

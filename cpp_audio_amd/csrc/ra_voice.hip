@@ -448,11 +448,14 @@ int ra_voice_launch_render(const RaVoiceParams &p, const RaVoiceJob *jobs, const
                        d_out);
     return 0;
   }
-  static bool attr_set = false; // more than 64 ramps of a stream at once (n_channels > 21): one unit per workgroup of g lanes
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voice_render_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ra_voice_render_lds(1024)) != hipSuccess) return -1;
-    attr_set = true;
-  }
+  // more than 64 ramps of a stream at once (n_channels > 21): one unit per workgroup of g lanes.  Function attributes are per device and a
+  // process may hold voices on several GPUs from several host threads: once per device, under the site's lock
+  static unsigned long long attr_done = 0;
+  static int attr_failed = 0;
+  ra_once_per_device(attr_done, [] {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voice_render_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ra_voice_render_lds(1024)) != hipSuccess) attr_failed = 1;
+  });
+  if (attr_failed) return -1;
   hipLaunchKernelGGL(ra_voice_render_kernel<1024>, dim3((unsigned)((units + U - 1) / U)), dim3((unsigned)threads), lds, st, p, jobs, slot_begin, st_prev, st_cur, n_streams, (int)n, L,
                      n_tiles, g_log2, d_out);
   return 0;

@@ -417,7 +417,9 @@ int ra_voice_create(const ra_voice_config *cfg, int32_t n_streams, int32_t devic
 void ra_voice_destroy(ra_voice *v);
 /* queue events (HOST pointer; per stream in non-decreasing sample order, not before the frames already processed) */
 int ra_voice_events(ra_voice *v, const ra_voice_event *h_events, int64_t n_events);
-/* Impl_::doProcessing over n_frames for every stream: h_out [n_streams][n_frames][2] float32 (HOST pointer); consecutive calls continue */
+/* Impl_::doProcessing over n_frames for every stream: h_out [n_streams][n_frames][2] float32 (HOST pointer); consecutive calls continue.
+ * A block that fails after it has started to consume the queued events (a staging or device allocation, a HIP call) leaves the object
+ * poisoned, like ra_context: every later ra_voice_process_* returns RA_EINTERNAL and the caller recreates the object. */
 int ra_voice_process_host(ra_voice *v, int64_t n_frames, float *h_out);
 /* the same with the output resident in HBM: d_out [n_streams][n_frames][2] float32 (DEVICE pointer); returns when the block is done */
 int ra_voice_process_device(ra_voice *v, int64_t n_frames, float *d_out);
