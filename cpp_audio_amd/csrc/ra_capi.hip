@@ -351,7 +351,17 @@ int build_vocoder_tables(ra_context *c) {
       k[64 + i] = coeff(freqs[i + 1]);
       k[128 + i] = coeff(freqs[i] * cfg.vocoder_env_follower_cutoff_ratio);
     }
-    return upload(c, &b.bank_k, k);
+    if ((r = upload(c, &b.bank_k, k))) return r;
+    // the ratios of the time-parallel bank's scans: a lane's chunk is 16 samples, so (1 - k)^16 carries a state from one lane to the next, its
+    // repeated squares over 2, 4, ... 32 lanes
+    std::vector<double> pw(3 * 8 * 64, 0.0);
+    for (int t = 0; t < 3; ++t)
+      for (int i = 0; i < 64; ++i) {
+        double a = 1.0 - k[t * 64 + i];
+        for (int q = 0; q < 4; ++q) a *= a; // ^16
+        for (int e = 0; e < 8; ++e) { pw[(t * 8 + e) * 64 + i] = a; a *= a; }
+      }
+    return upload(c, &b.bank_pow, pw);
   }
   if ((r = upload(c, &b.voc_half_window, make_half_window(RA_WINDOW_GAUSSIAN4, Wm / 2)))) return r;
   if ((r = upload_fft_tables(c, p.voc_Lm, &b.vm_tw_half, &b.vm_tw_full, &b.vm_bitrev))) return r;

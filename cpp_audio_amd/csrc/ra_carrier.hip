@@ -826,6 +826,162 @@ __global__ void __launch_bounds__(384) ra_voc_bank_pipe_kernel(RaParams p, RaBuf
   if (w < 5) st[w * 64 + l] = y;
 }
 
+
+// K7, time-parallel (the default since r04).  Every stage of the bank is a constant-coefficient one-pole, y[n] = y[n-1] + k (x[n] - y[n-1]):
+// an affine map of its state per sample, so a run of samples composes into one affine map (a^len, zero-state response) and the state at
+// every chunk boundary of a tile follows from a prefix scan over the chunks.  A tile is 1024 samples of one stream; lane = a chunk of 16
+// consecutive samples; wave w of the workgroup's eight takes bands w * bpw ... (bpw = ceil(bands / 8)) one after the other.  Per band and
+// stage: (1) the chunk's zero-state response by the recurrence itself from 0, (2) a weighted inclusive scan over the 64 lanes with the
+// constant ratio a^16 (Kogge-Stone with the host's table a^16, a^32, ..., a^512; the tile's carry-in folded into lane 0) gives every
+// chunk its true start state, (3) the recurrence again from that state produces the samples — within a chunk the very operation sequence of
+// the reference's loop; only the chunk's start value differs from the sample-serial run, at rounding level.  The `abs` between the band-pass
+// and the follower, the high-pass `x - lp(x)` and the product with the envelope are elementwise between two scans.  The band sum runs over a
+// lane's bands in band order, then over the eight waves in wave order through LDS.  A block's last, ragged tile takes the same path with
+// per-lane lengths (a general affine scan over (a^len, response) pairs).  480 k samples of a stream are 469 tiles instead of 480 k
+// dependent steps: the pipeline kernel above (bit-identical to the reference's loop; reference_order = 1) needed 30.8 ms per configs[2] step.
+constexpr int SC = 16;              // samples per lane
+constexpr int STILE = 64 * SC;      // samples per tile
+constexpr int SROW = 65;            // LDS row stride in doubles: sample (lane, j) of a tile lives at j * SROW + lane
+
+// inclusive scan over the wave's lanes of y_l = P y_(l-1) + z_l with the constant ratio P: pw[s] = P^(2^s)
+__device__ inline double bank_scan_const(double z, const double *__restrict__ pw, int lane) {
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    const double t = __shfl_up(z, 1 << s);
+    if (lane >= (1 << s)) z = fma(pw[s], t, z);
+  }
+  return z;
+}
+// the same for per-lane ratios (a ragged tile): the scan composes the affine maps (al, z)
+__device__ inline double bank_scan_affine(double al, double z, int lane) {
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    const double zt = __shfl_up(z, 1 << s), at = __shfl_up(al, 1 << s);
+    if (lane >= (1 << s)) { z = fma(al, zt, z); al *= at; }
+  }
+  return z;
+}
+// One one-pole stage over the lane's chunk x[0 .. cnt): returns the tile's carry-out (wave-uniform), leaves the stage's samples in y[].
+// k: the coefficient; pw: a^16, a^32, ... (a = 1 - k); y_in: the state before the tile's first sample (wave-uniform).
+template <bool RAGGED>
+__device__ inline double bank_stage(const double (&x)[SC], double (&y)[SC], double k, const double *__restrict__ pw, double y_in, int cnt, int lane) {
+  double z = 0.0, al = 1.0;
+  const double a = 1.0 - k;
+#pragma unroll
+  for (int j = 0; j < SC; ++j) {
+    if (!RAGGED || j < cnt) { z = z + k * (x[j] - z); if (RAGGED) al *= a; }
+  }
+  double Y;
+  if (RAGGED) {
+    if (lane == 0) z = fma(al, y_in, z);
+    Y = bank_scan_affine(al, z, lane);
+  } else {
+    if (lane == 0) z = fma(pw[0], y_in, z);
+    Y = bank_scan_const(z, pw, lane);
+  }
+  double yy = __shfl_up(Y, 1);
+  if (lane == 0) yy = y_in;
+#pragma unroll
+  for (int j = 0; j < SC; ++j) {
+    if (!RAGGED || j < cnt) yy = yy + k * (x[j] - yy);
+    y[j] = yy;
+  }
+  return readlane_f64(Y, 63); // (lanes past a ragged tile's end hold the identity map: the last lane carries the state after the last sample)
+}
+
+template <bool RAGGED>
+__device__ inline void bank_band(const double (&m)[SC], const double (&c)[SC], double (&out)[SC], double kA, double kB, double kE, const double *__restrict__ pwA,
+                                 const double *__restrict__ pwB, const double *__restrict__ pwE, double *__restrict__ st, int cnt, int lane) {
+  double t[SC], e[SC];
+  // Modulator::feed (vocoder.cpp:358-380): BandPass::feed (:54-58) = high-pass (input - low-pass) then low-pass; EnvelopeFollower::feed (:71-74) of |.|
+  st[0] = bank_stage<RAGGED>(m, t, kA, pwA, st[0], cnt, lane);
+#pragma unroll
+  for (int j = 0; j < SC; ++j) t[j] = m[j] - t[j];
+  st[1] = bank_stage<RAGGED>(t, e, kB, pwB, st[1], cnt, lane);
+#pragma unroll
+  for (int j = 0; j < SC; ++j) t[j] = fabs(e[j]);
+  st[2] = bank_stage<RAGGED>(t, e, kE, pwE, st[2], cnt, lane);
+  // Carrier::feed (:698-718): the same band-pass; times the envelope
+  double d[SC];
+  st[3] = bank_stage<RAGGED>(c, t, kA, pwA, st[3], cnt, lane);
+#pragma unroll
+  for (int j = 0; j < SC; ++j) t[j] = c[j] - t[j];
+  st[4] = bank_stage<RAGGED>(t, d, kB, pwB, st[4], cnt, lane);
+#pragma unroll
+  for (int j = 0; j < SC; ++j) out[j] += e[j] * d[j]; // res += ponderation[i] * filtered, in band order
+}
+
+__global__ void __launch_bounds__(512) ra_voc_bank_scan_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, const float *__restrict__ carrier_f,
+                                                             const double *__restrict__ carrier_d, int64_t n) {
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, B = p.voc_bands;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bpw = (B + 7) >> 3;
+  double *lds = reinterpret_cast<double *>(ra_smem_car);
+  double *in_m = lds, *in_c = lds + SC * SROW, *part = lds + 2 * SC * SROW; // [SC][SROW] each; part: [8][SC][SROW]
+  double *st_lds = part + 8 * SC * SROW;                                     // [64][5] the bands' filter states
+  double *gst = b.bank_state + (size_t)s * 5 * 64;
+  for (int q = tid; q < 5 * 64; q += 512) st_lds[(q & 63) * 5 + (q >> 6)] = gst[q]; // global layout [5][64]
+  const float *vs = voice ? voice + (size_t)s * n : nullptr;
+  const float *cf = carrier_f ? carrier_f + (size_t)s * n : nullptr;
+  const double *cd = carrier_d ? carrier_d + (size_t)s * n : nullptr;
+  double *mix = b.voc_mix + (size_t)s * n;
+  const double *pow_tab = b.bank_pow; // [3][8][64]: coefficient (band's lower edge, upper edge, follower), a^(16 * 2^e), band
+  auto sample_pos = [](int i) { return (i & (SC - 1)) * SROW + (i >> 4); };
+  for (int64_t tb = 0; tb < n; tb += STILE) {
+    const int cnt_tile = (int)min((int64_t)STILE, n - tb);
+    // stage the tile's inputs (the modulator as the double read_direct_input widens it to, lib.cpp:1073-1079): coalesced loads, transposed in LDS
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int i = tid + 512 * h;
+      double mv = 0.0, cv = 0.0;
+      if (i < cnt_tile) {
+        if (vs) mv = (double)vs[tb + i];
+        if (cd) cv = cd[tb + i]; else if (cf) cv = (double)cf[tb + i];
+      }
+      in_m[sample_pos(i)] = mv; in_c[sample_pos(i)] = cv;
+    }
+    __syncthreads();
+    double m[SC], c[SC], out[SC];
+#pragma unroll
+    for (int j = 0; j < SC; ++j) { m[j] = in_m[j * SROW + lane]; c[j] = in_c[j * SROW + lane]; out[j] = 0.0; }
+    const int cnt = max(0, min(SC, cnt_tile - SC * lane));
+    for (int bi = 0; bi < bpw; ++bi) {
+      const int band = w * bpw + bi;
+      if (band >= B) break; // wave-uniform
+      const double kA = b.bank_k[band], kB = b.bank_k[64 + band], kE = b.bank_k[128 + band];
+      double pwA[6], pwB[6], pwE[6], st[5];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) { pwA[e] = pow_tab[(0 * 8 + e) * 64 + band]; pwB[e] = pow_tab[(1 * 8 + e) * 64 + band]; pwE[e] = pow_tab[(2 * 8 + e) * 64 + band]; }
+#pragma unroll
+      for (int q = 0; q < 5; ++q) st[q] = st_lds[band * 5 + q];
+      if (cnt_tile == STILE) bank_band<false>(m, c, out, kA, kB, kE, pwA, pwB, pwE, st, cnt, lane);
+      else bank_band<true>(m, c, out, kA, kB, kE, pwA, pwB, pwE, st, cnt, lane);
+      if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) st_lds[band * 5 + q] = st[q];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < SC; ++j) part[(w * SC + j) * SROW + lane] = out[j];
+    __syncthreads();
+    // the band sum across the waves, in wave (= band) order, and the mix (vocoder.cpp:799-803)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int i = tid + 512 * h;
+      if (i < cnt_tile) {
+        const int at = sample_pos(i);
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += part[q * SC * SROW + at];
+        mix[tb + i] = (double)p.vol_mod * in_m[at] + (double)p.vol_car * in_c[at] + (double)p.vol_voc * acc;
+      }
+    }
+    // (the next tile's staging writes only this thread's own two input slots; its partials are written behind the next barrier)
+  }
+  __syncthreads();
+  for (int q = tid; q < 5 * 64; q += 512) gst[q] = st_lds[(q & 63) * 5 + (q >> 6)];
+}
+
 } // namespace
 
 int ra_carrier_seg_doubles() { return CS_COUNT; }
@@ -847,6 +1003,16 @@ void ra_launch_voc_bank(const RaParams &p, const RaBuffers &b, const float *d_vo
                         hipStream_t st) {
   if (n <= 0) return;
   (void)t0;
+  static const bool force_pipe = std::getenv("RA_BANK_PIPE") != nullptr; // tuning aid: the bit-identical pipeline kernel whatever reference_order says
+  if (!p.car_serial && !force_pipe && !std::getenv("RA_BANK_SINGLE_WAVE")) { // the default: time-parallel (results equal the reference's loop to rounding)
+    static unsigned long long scan_attr_done = 0;
+    const size_t lds = ((size_t)(2 + 8) * SC * SROW + 5 * 64) * sizeof(double);
+    ra_once_per_device(scan_attr_done, [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_bank_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RA_LDS_LIMIT_BYTES);
+    });
+    hipLaunchKernelGGL(ra_voc_bank_scan_kernel, dim3((unsigned)p.n_streams), dim3(512), lds, st, p, b, d_voice, d_carrier, carrier_d, n);
+    return;
+  }
   static const bool single_wave = std::getenv("RA_BANK_SINGLE_WAVE") != nullptr; // tuning aid: the one-wave kernel (same bits, ~3x the time)
   if (single_wave) {
     hipLaunchKernelGGL(ra_voc_bank_kernel, dim3((unsigned)p.n_streams), dim3(64), (size_t)BT * 65 * sizeof(double), st, p, b, d_voice, d_carrier, carrier_d, n);

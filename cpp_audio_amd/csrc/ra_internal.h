@@ -173,6 +173,7 @@ struct RaBuffers {
   // ---- band-pass bank (vocoder_kind = RA_VOCODER_BANDPASS) ----
   double *bank_k;           // [3][64] one-pole coefficients per band: high-pass (band's lower edge), low-pass (upper edge), envelope follower
   double *bank_state;       // [n_streams][5][64] filter states: modulator hp / lp, envelope follower, carrier hp / lp
+  double *bank_pow;         // [3][8][64] per coefficient of bank_k and band: (1 - k)^(16 * 2^e), e = 0..5 — the ratios of the time-parallel bank's scans (ra_voc_bank_scan_kernel)
   // ---- vocoder (only allocated when a vocoder volume is non-zero) ----
   double2 *voc_big;         // transform buffers in HBM for frames that do not fit LDS: [RA_VOC_BIG_WORKGROUPS + n_streams][voc_big_slot], else null
   int64_t voc_big_slot;

@@ -1,8 +1,9 @@
 """GPU parity tests for SURVEY.md §8 f2: the band-pass bank vocoder (K7) and the vocoder carrier synth (K6) against the CPU oracle.
 
-Bars: the carrier's phase-controlled voices (saw / triangle / square / pulse) and the bank's vocoded signal are the same IEEE operation
-sequences on both sides -> equal bit for bit; the sine voice differs by libm ulps (sincos of the start angle / increment); the final
-float32 output within 1e-5 RMS per sample (BASELINE.json north_star).
+Bars: the carrier's phase-controlled voices (saw / triangle / square / pulse) and, with reference_order = 1 (the sample-serial pipeline
+kernel), the bank's vocoded signal are the same IEEE operation sequences on both sides -> equal bit for bit; the default bank (r04: every
+one-pole stage as a prefix scan over 16-sample chunks, ra_voc_bank_scan_kernel) equals them to rounding; the sine voice differs by libm
+ulps (sincos of the start angle / increment); the final float32 output within 1e-5 RMS per sample (BASELINE.json north_star).
 """
 import numpy as np
 import pytest
@@ -50,14 +51,15 @@ def oracle_events(oracle, rows, stream):
     return oracle.carrier_events([(r[0], r[2], r[3], r[4], r[5], r[6]) for r in rows if r[1] == stream])
 
 
-@pytest.mark.parametrize("bands,ratio", [(32, 1.0 / 20.0), (5, 0.2), (50, 0.05)])
-def test_bank_vocoder_matches_oracle(api, oracle, sig, bands, ratio):
-    n, S = 36000, 3
+@pytest.mark.parametrize("ro", [0, 1])
+@pytest.mark.parametrize("bands,ratio", [(32, 1.0 / 20.0), (5, 0.2), (50, 0.05), (1, 0.1), (9, 0.05)])
+def test_bank_vocoder_matches_oracle(api, oracle, sig, bands, ratio, ro):
+    n, S = 36000 + 17 * bands, 3   # (never a multiple of the scan kernel's 1024-sample tile: the ragged last tile is always exercised)
     x = sig.make_streams(S, n, base_seed=4000 + bands)
     car = np.stack([sig.carrier_stream(n, freq=110.0 * (s + 1), kind="saw" if s != 1 else "sine") for s in range(S)])
     kw = dict(BASE, vocoder_kind=1, vocoder_count_bands=bands, vocoder_env_follower_cutoff_ratio=ratio, voice_volume=0.25, carrier_volume=0.125,
               vocoder_volume=4.0)
-    with api.Context(api.default_config(**kw), S, 0) as ctx:
+    with api.Context(api.default_config(reference_order=ro, **kw), S, 0) as ctx:
         out = ctx.process_host(x, car)
         assert ctx.stats().error_flags == 0
     for s in range(S):
@@ -65,14 +67,18 @@ def test_bank_vocoder_matches_oracle(api, oracle, sig, bands, ratio):
         assert np.sqrt(np.mean(ref.astype(np.float64) ** 2)) > 1e-3
         only_dry = 0.25 * x[s].astype(np.float64) + 0.125 * car[s]
         assert rms(ref[:, 0], only_dry) > 1e-4, "the vocoded term is audible in the reference output: the test is not vacuous"
-        assert np.array_equal(out[s], ref), f"stream {s}: same operation sequence on both sides, rms {rms(out[s], ref):.3g}"
+        if ro == 1:
+            assert np.array_equal(out[s], ref), f"stream {s}: same operation sequence on both sides, rms {rms(out[s], ref):.3g}"
+        else:  # the scans associate the recurrences differently: the double signal agrees to ~1e-15, its float32 image flips a last bit now and then
+            assert rms(out[s], ref) <= 1e-8 and np.max(np.abs(out[s].astype(np.float64) - ref)) <= 1e-6, f"stream {s}: rms {rms(out[s], ref):.3g}"
 
 
-def test_bank_vocoder_block_cut_invariance(api, sig):
+@pytest.mark.parametrize("ro", [0, 1])
+def test_bank_vocoder_block_cut_invariance(api, sig, ro):
     n, S = 30000, 2
     x = sig.make_streams(S, n, base_seed=5)
     car = np.stack([sig.carrier_stream(n, freq=98.0), sig.carrier_stream(n, freq=131.0)])
-    kw = dict(BASE, vocoder_kind=1, voice_volume=0.0, carrier_volume=0.0, vocoder_volume=3.0)
+    kw = dict(BASE, vocoder_kind=1, voice_volume=0.0, carrier_volume=0.0, vocoder_volume=3.0, reference_order=ro)
     with api.Context(api.default_config(**kw), S, 0) as ctx:
         whole = ctx.process_host(x, car)
     with api.Context(api.default_config(**kw), S, 0) as ctx:
@@ -84,7 +90,12 @@ def test_bank_vocoder_block_cut_invariance(api, sig):
             parts.append(ctx.process_host(x[:, t:t + m], car[:, t:t + m]))
             t += m
     assert t == n
-    assert np.array_equal(np.concatenate(parts, axis=1), whole)
+    got = np.concatenate(parts, axis=1)
+    assert np.sqrt(np.mean(whole.astype(np.float64) ** 2)) > 1e-3
+    if ro == 1:
+        assert np.array_equal(got, whole)
+    else:  # another cut puts the scan's tiles elsewhere: equal to rounding (reference order: bit for bit)
+        assert rms(got, whole) <= 1e-9 and np.max(np.abs(got.astype(np.float64) - whole)) <= 1e-6
 
 
 VOICES = dict(vocoder_carrier_saw_volume=0.3, vocoder_carrier_triangle_volume=0.2, vocoder_carrier_square_volume=0.25,
