@@ -375,6 +375,14 @@ int build_vocoder_tables(ra_context *c) {
       if (s0 >= 0) { range[2 * bi] = s0; range[2 * bi + 1] = s0 + cnt; }
     }
     if ((r = upload(c, &b.voc_mod_band_start, range))) return r;
+    // the same as a per-bin table for the fused modulator kernel: non-decreasing, -1 below the bands, `bands` above them and for bin M
+    std::vector<int> bb(p.voc_Mm + 1, p.voc_bands);
+    bool seen = false; // (the bands tile [min, max]: a bin without a band lies below the first one or above the last one)
+    for (int i = 0; i < p.voc_Mm; ++i) {
+      if (band[i] >= 0) { bb[i] = band[i]; seen = true; }
+      else bb[i] = seen ? p.voc_bands : -1;
+    }
+    if ((r = upload(c, &b.voc_mod_bin_band, bb))) return r;
   }
   if ((r = upload(c, &b.voc_car_band, band_of_bins(freqs, p.voc_Mc + 1, static_cast<double>(cfg.sample_rate) / p.voc_Lc)))) return r;
   { // EqualGainXFade::set(S-1, Sinusoidal).get(idx+1) — decision of DESIGN.md §5: new = (1 - cos(pi i / (len+1))) / 2

@@ -843,14 +843,30 @@ constexpr int SC = 16;              // samples per lane
 constexpr int STILE = 64 * SC;      // samples per tile
 constexpr int SROW = 65;            // LDS row stride in doubles: sample (lane, j) of a tile lives at j * SROW + lane
 
-// inclusive scan over the wave's lanes of y_l = P y_(l-1) + z_l with the constant ratio P: pw[s] = P^(2^s)
-__device__ inline double bank_scan_const(double z, const double *__restrict__ pw, int lane) {
-#pragma unroll
-  for (int s = 0; s < 6; ++s) {
-    const double t = __shfl_up(z, 1 << s);
-    if (lane >= (1 << s)) z = fma(pw[s], t, z);
-  }
-  return z;
+__device__ inline double uniform_f64(double v) { return readlane_f64(v, 0); } // a wave-uniform value into scalar registers
+// Lane moves on the VALU (DPP): a ds_bpermute round trip costs ~100 cycles, and six of them in a row per stage were what a tile waited for.
+template <int CTRL, bool ZERO>
+__device__ inline double dpp_f64(double old, double v) { // ZERO: lanes without a source read 0; otherwise they keep `old`
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, 0xf, 0xf, ZERO);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, 0xf, 0xf, ZERO);
+  return __hiloint2double(hi, lo);
+}
+// Inclusive scan over the wave's lanes of y_l = P y_(l-1) + z_l with the constant ratio P: pw[s] = P^(2^s) (s = 0 .. 5), q = P^((lane mod 16) + 1).
+// Rows of 16 lanes scan themselves with row_shr moves (lanes short of a source add 0); the four row ends are chained through scalar registers
+// (E_r = R_r + P^16 E_(r-1)) and every later row adds q times its predecessor's end.  y_in (the state before lane 0) enters through lane 0's z.
+// Returns the scan; carry = the value at lane 63.
+__device__ inline double bank_scan_const(double z, const double *__restrict__ pw, double q, int lane, double &carry) {
+  z = fma(pw[0], dpp_f64<0x111, true>(0.0, z), z);
+  z = fma(pw[1], dpp_f64<0x112, true>(0.0, z), z);
+  z = fma(pw[2], dpp_f64<0x114, true>(0.0, z), z);
+  z = fma(pw[3], dpp_f64<0x118, true>(0.0, z), z);
+  const double r0 = readlane_f64(z, 15), r1 = readlane_f64(z, 31), r2 = readlane_f64(z, 47), r3 = readlane_f64(z, 63);
+  const double e1 = fma(pw[4], r0, r1), e2 = fma(pw[4], e1, r2);
+  carry = fma(pw[4], e2, r3);
+  double ep = r0;
+  ep = lane >= 32 ? e1 : ep;
+  ep = lane >= 48 ? e2 : ep;
+  return lane >= 16 ? fma(q, ep, z) : z;
 }
 // the same for per-lane ratios (a ragged tile): the scan composes the affine maps (al, z)
 __device__ inline double bank_scan_affine(double al, double z, int lane) {
@@ -861,57 +877,75 @@ __device__ inline double bank_scan_affine(double al, double z, int lane) {
   }
   return z;
 }
-// One one-pole stage over the lane's chunk x[0 .. cnt): returns the tile's carry-out (wave-uniform), leaves the stage's samples in y[].
-// k: the coefficient; pw: a^16, a^32, ... (a = 1 - k); y_in: the state before the tile's first sample (wave-uniform).
-template <bool RAGGED>
-__device__ inline double bank_stage(const double (&x)[SC], double (&y)[SC], double k, const double *__restrict__ pw, double y_in, int cnt, int lane) {
+// One one-pole stage over the lane's chunk x[0 .. cnt), IN PLACE: x[j] becomes the stage's output sample — the low-pass y (OUT_LP), the
+// high-pass x - y (OUT_HP).  Returns the tile's carry-out
+// (wave-uniform).  k: the coefficient; with P = (1 - k)^16, the factor a state decays by over one lane's chunk: pw[s] = P^(2^s), s = 0 .. 5
+// (pw[0] carries a state over one lane, pw[4] over a row of 16), q = P^((lane mod 16) + 1); y_in: the state before the tile's first sample (wave-uniform).
+enum { OUT_LP, OUT_HP };
+template <bool RAGGED, int OUT, bool IN_ABS>
+__device__ inline double bank_stage(double (&x)[SC], double k, const double *__restrict__ pw, double q, double y_in, int cnt, int lane) {
+  // IN_ABS: the stage is fed |x| (the envelope follower after the band-pass): a source modifier of the instructions that read x, no instruction
+  // (1) the chunk's zero-state response z = k sum_j a^(len-1-j) x[j], by Horner's rule: one fused multiply-add per sample (it only feeds the
+  // scan: its rounding is the carry's, not the samples')
   double z = 0.0, al = 1.0;
   const double a = 1.0 - k;
 #pragma unroll
   for (int j = 0; j < SC; ++j) {
-    if (!RAGGED || j < cnt) { z = z + k * (x[j] - z); if (RAGGED) al *= a; }
+    if (!RAGGED || j < cnt) { z = fma(z, a, IN_ABS ? fabs(x[j]) : x[j]); if (RAGGED) al *= a; }
   }
-  double Y;
+  z *= k;
+  // (2) the state at the end of every chunk, and from it every chunk's start state
+  double Y, carry;
   if (RAGGED) {
     if (lane == 0) z = fma(al, y_in, z);
     Y = bank_scan_affine(al, z, lane);
+    carry = readlane_f64(Y, 63); // (lanes past the ragged tile's end hold the identity map: the last lane carries the state after the last sample)
   } else {
     if (lane == 0) z = fma(pw[0], y_in, z);
-    Y = bank_scan_const(z, pw, lane);
+    Y = bank_scan_const(z, pw, q, lane, carry);
   }
-  double yy = __shfl_up(Y, 1);
-  if (lane == 0) yy = y_in;
+  double yy = dpp_f64<0x138, false>(y_in, Y); // wave_shr:1 — lane l takes lane l - 1's end state, lane 0 keeps y_in
+  // (3) the recurrence y += k (x - y) from the chunk's true start state, the multiply-add fused (the library is built without contraction)
 #pragma unroll
   for (int j = 0; j < SC; ++j) {
-    if (!RAGGED || j < cnt) yy = yy + k * (x[j] - yy);
-    y[j] = yy;
+    const double xin = IN_ABS ? fabs(x[j]) : x[j];
+    if (!RAGGED || j < cnt) yy = fma(k, xin - yy, yy);
+    x[j] = OUT == OUT_HP ? xin - yy : yy;
   }
-  return readlane_f64(Y, 63); // (lanes past a ragged tile's end hold the identity map: the last lane carries the state after the last sample)
+  return carry;
 }
 
+// one band of a tile for this lane's chunk.  in_m / in_c: the tile's inputs in LDS (sample (lane, j) at j * SROW + lane), read again for every
+// band; out: the wave's running band sum, in its own slice of LDS.  Two 16-sample arrays are all the registers hold: with the inputs and the sum
+// in registers too the kernel needed 239 VGPRs, which left the carrier synth's kernels it runs beside (next block's walk — 249 VGPRs — and render,
+// on their own queue) no room on a SIMD: measured, both stretched three-fold.
 template <bool RAGGED>
-__device__ inline void bank_band(const double (&m)[SC], const double (&c)[SC], double (&out)[SC], double kA, double kB, double kE, const double *__restrict__ pwA,
-                                 const double *__restrict__ pwB, const double *__restrict__ pwE, double *__restrict__ st, int cnt, int lane) {
-  double t[SC], e[SC];
+__device__ inline void bank_band(const double *__restrict__ in_m, const double *__restrict__ in_c, double *__restrict__ out, bool first, const double *__restrict__ qtab, double kA, double kB, double kE,
+                                 const double *__restrict__ pwA, const double *__restrict__ pwB, const double *__restrict__ pwE, double *__restrict__ st, int cnt, int lane) {
+  double v[SC], u[SC];
+  // P^((lane mod 16) + 1) for the three coefficients: what a later row's lane owes its predecessor row's end state (bank_scan_const)
+  const double qA = qtab[lane & 15], qB = qtab[16 + (lane & 15)], qE = qtab[32 + (lane & 15)];
   // Modulator::feed (vocoder.cpp:358-380): BandPass::feed (:54-58) = high-pass (input - low-pass) then low-pass; EnvelopeFollower::feed (:71-74) of |.|
-  st[0] = bank_stage<RAGGED>(m, t, kA, pwA, st[0], cnt, lane);
 #pragma unroll
-  for (int j = 0; j < SC; ++j) t[j] = m[j] - t[j];
-  st[1] = bank_stage<RAGGED>(t, e, kB, pwB, st[1], cnt, lane);
-#pragma unroll
-  for (int j = 0; j < SC; ++j) t[j] = fabs(e[j]);
-  st[2] = bank_stage<RAGGED>(t, e, kE, pwE, st[2], cnt, lane);
+  for (int j = 0; j < SC; ++j) v[j] = in_m[j * SROW + lane];
+  st[0] = bank_stage<RAGGED, OUT_HP, false>(v, kA, pwA, qA, st[0], cnt, lane);
+  st[1] = bank_stage<RAGGED, OUT_LP, false>(v, kB, pwB, qB, st[1], cnt, lane);
+  st[2] = bank_stage<RAGGED, OUT_LP, true>(v, kE, pwE, qE, st[2], cnt, lane);
   // Carrier::feed (:698-718): the same band-pass; times the envelope
-  double d[SC];
-  st[3] = bank_stage<RAGGED>(c, t, kA, pwA, st[3], cnt, lane);
 #pragma unroll
-  for (int j = 0; j < SC; ++j) t[j] = c[j] - t[j];
-  st[4] = bank_stage<RAGGED>(t, d, kB, pwB, st[4], cnt, lane);
+  for (int j = 0; j < SC; ++j) u[j] = in_c[j * SROW + lane];
+  st[3] = bank_stage<RAGGED, OUT_HP, false>(u, kA, pwA, qA, st[3], cnt, lane);
+  st[4] = bank_stage<RAGGED, OUT_LP, false>(u, kB, pwB, qB, st[4], cnt, lane);
+  if (first) { // (wave-uniform) res += ponderation[i] * filtered, in band order
 #pragma unroll
-  for (int j = 0; j < SC; ++j) out[j] += e[j] * d[j]; // res += ponderation[i] * filtered, in band order
+    for (int j = 0; j < SC; ++j) out[j * SROW + lane] = v[j] * u[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < SC; ++j) out[j * SROW + lane] = fma(v[j], u[j], out[j * SROW + lane]);
+  }
 }
 
-__global__ void __launch_bounds__(512) ra_voc_bank_scan_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, const float *__restrict__ carrier_f,
+__global__ void __launch_bounds__(512, 4) ra_voc_bank_scan_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, const float *__restrict__ carrier_f,
                                                              const double *__restrict__ carrier_d, int64_t n) {
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, B = p.voc_bands;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -919,6 +953,7 @@ __global__ void __launch_bounds__(512) ra_voc_bank_scan_kernel(RaParams p, RaBuf
   double *lds = reinterpret_cast<double *>(ra_smem_car);
   double *in_m = lds, *in_c = lds + SC * SROW, *part = lds + 2 * SC * SROW; // [SC][SROW] each; part: [8][SC][SROW]
   double *st_lds = part + 8 * SC * SROW;                                     // [64][5] the bands' filter states
+  double *q_lds = st_lds + 5 * 64;                                           // [bands][3][16] P^(i + 1) per band and coefficient, P = (1 - k)^16
   double *gst = b.bank_state + (size_t)s * 5 * 64;
   for (int q = tid; q < 5 * 64; q += 512) st_lds[(q & 63) * 5 + (q >> 6)] = gst[q]; // global layout [5][64]
   const float *vs = voice ? voice + (size_t)s * n : nullptr;
@@ -926,6 +961,12 @@ __global__ void __launch_bounds__(512) ra_voc_bank_scan_kernel(RaParams p, RaBuf
   const double *cd = carrier_d ? carrier_d + (size_t)s * n : nullptr;
   double *mix = b.voc_mix + (size_t)s * n;
   const double *pow_tab = b.bank_pow; // [3][8][64]: coefficient (band's lower edge, upper edge, follower), a^(16 * 2^e), band
+  for (int q = tid; q < B * 3; q += 512) { // this entry's row powers P, P^2, ... P^16 by repeated multiplication (once per launch)
+    const int band = q / 3, t = q - band * 3;
+    const double P = pow_tab[(t * 8 + 0) * 64 + band];
+    double acc = P;
+    for (int i = 0; i < 16; ++i) { q_lds[(band * 3 + t) * 16 + i] = acc; acc *= P; }
+  }
   auto sample_pos = [](int i) { return (i & (SC - 1)) * SROW + (i >> 4); };
   for (int64_t tb = 0; tb < n; tb += STILE) {
     const int cnt_tile = (int)min((int64_t)STILE, n - tb);
@@ -941,28 +982,31 @@ __global__ void __launch_bounds__(512) ra_voc_bank_scan_kernel(RaParams p, RaBuf
       in_m[sample_pos(i)] = mv; in_c[sample_pos(i)] = cv;
     }
     __syncthreads();
-    double m[SC], c[SC], out[SC];
+    double *out = part + (size_t)w * SC * SROW;
+    if (w * bpw >= B) { // a wave without bands (fewer than eight bands' worth): its slice adds zeros
 #pragma unroll
-    for (int j = 0; j < SC; ++j) { m[j] = in_m[j * SROW + lane]; c[j] = in_c[j * SROW + lane]; out[j] = 0.0; }
+      for (int j = 0; j < SC; ++j) out[j * SROW + lane] = 0.0;
+    }
     const int cnt = max(0, min(SC, cnt_tile - SC * lane));
     for (int bi = 0; bi < bpw; ++bi) {
       const int band = w * bpw + bi;
       if (band >= B) break; // wave-uniform
-      const double kA = b.bank_k[band], kB = b.bank_k[64 + band], kE = b.bank_k[128 + band];
+      // (everything per band is wave-uniform: kept in scalar registers, the vector registers belong to the two sample arrays)
+      const double kA = uniform_f64(b.bank_k[band]), kB = uniform_f64(b.bank_k[64 + band]), kE = uniform_f64(b.bank_k[128 + band]);
       double pwA[6], pwB[6], pwE[6], st[5];
 #pragma unroll
-      for (int e = 0; e < 6; ++e) { pwA[e] = pow_tab[(0 * 8 + e) * 64 + band]; pwB[e] = pow_tab[(1 * 8 + e) * 64 + band]; pwE[e] = pow_tab[(2 * 8 + e) * 64 + band]; }
+      for (int e = 0; e < 6; ++e) {
+        pwA[e] = uniform_f64(pow_tab[(0 * 8 + e) * 64 + band]); pwB[e] = uniform_f64(pow_tab[(1 * 8 + e) * 64 + band]); pwE[e] = uniform_f64(pow_tab[(2 * 8 + e) * 64 + band]);
+      }
 #pragma unroll
-      for (int q = 0; q < 5; ++q) st[q] = st_lds[band * 5 + q];
-      if (cnt_tile == STILE) bank_band<false>(m, c, out, kA, kB, kE, pwA, pwB, pwE, st, cnt, lane);
-      else bank_band<true>(m, c, out, kA, kB, kE, pwA, pwB, pwE, st, cnt, lane);
+      for (int q = 0; q < 5; ++q) st[q] = uniform_f64(st_lds[band * 5 + q]);
+      if (cnt_tile == STILE) bank_band<false>(in_m, in_c, out, bi == 0, q_lds + band * 48, kA, kB, kE, pwA, pwB, pwE, st, cnt, lane);
+      else bank_band<true>(in_m, in_c, out, bi == 0, q_lds + band * 48, kA, kB, kE, pwA, pwB, pwE, st, cnt, lane);
       if (lane == 0) {
 #pragma unroll
         for (int q = 0; q < 5; ++q) st_lds[band * 5 + q] = st[q];
       }
     }
-#pragma unroll
-    for (int j = 0; j < SC; ++j) part[(w * SC + j) * SROW + lane] = out[j];
     __syncthreads();
     // the band sum across the waves, in wave (= band) order, and the mix (vocoder.cpp:799-803)
 #pragma unroll
@@ -1006,7 +1050,7 @@ void ra_launch_voc_bank(const RaParams &p, const RaBuffers &b, const float *d_vo
   static const bool force_pipe = std::getenv("RA_BANK_PIPE") != nullptr; // tuning aid: the bit-identical pipeline kernel whatever reference_order says
   if (!p.car_serial && !force_pipe && !std::getenv("RA_BANK_SINGLE_WAVE")) { // the default: time-parallel (results equal the reference's loop to rounding)
     static unsigned long long scan_attr_done = 0;
-    const size_t lds = ((size_t)(2 + 8) * SC * SROW + 5 * 64) * sizeof(double);
+    const size_t lds = ((size_t)(2 + 8) * SC * SROW + 5 * 64 + 3 * 16 * 64) * sizeof(double);
     ra_once_per_device(scan_attr_done, [] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_bank_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RA_LDS_LIMIT_BYTES);
     });

@@ -25,7 +25,19 @@ __host__ __device__ inline int ra_zsize(int M) { return M < 16 ? 16 : M; }
 
 // S fused stages starting at half = 1 << log2h.  FIRST: the group's inputs come from load(packed index) (bit-reversed order is
 // resolved here: slot i of the DIT input holds packed element bitrev(i)) instead of from z.
-template <int S, bool FIRST, typename LoadFn>
+// FMA (the vocoder's transforms only: nothing is decided on them, their bar is 1e-5 RMS): the twiddle product's multiply-adds are fused — two
+// roundings fewer per butterfly, 8 instead of 10 instructions; the analysis keeps the unfused network whose bits the CPU restatement shares.
+template <bool FMA>
+__device__ inline void ra_butterfly(double2 &u_io, double2 &y_io, const double2 ww) {
+  const double2 u = u_io, y = y_io;
+  double vr, vi;
+  if (FMA) { vr = fma(y.x, ww.x, -(y.y * ww.y)); vi = fma(y.x, ww.y, y.y * ww.x); }
+  else { vr = y.x * ww.x - y.y * ww.y; vi = y.x * ww.y + y.y * ww.x; }
+  u_io = make_double2(u.x + vr, u.y + vi);
+  y_io = make_double2(u.x - vr, u.y - vi);
+}
+
+template <int S, bool FIRST, typename LoadFn, bool FMA = false>
 __device__ inline void ra_fft_pass(double2 *z, int M, int log2M, int log2h, const double2 *__restrict__ tw_half, int tid, int T, LoadFn load) {
   constexpr int R = 1 << S;
   const int groups = M >> S, h = 1 << log2h, zs = ra_zshift(log2M);
@@ -54,12 +66,7 @@ __device__ inline void ra_fft_pass(double2 *z, int M, int log2M, int log2h, cons
 #pragma unroll
       for (int k = 0; k < R; ++k) {
         if (k & (1 << s)) continue;
-        const double2 ww = w[(1 << s) - 1 + (k & ((1 << s) - 1))];
-        const double2 u = x[k], y = x[k | (1 << s)];
-        const double vr = y.x * ww.x - y.y * ww.y;
-        const double vi = y.x * ww.y + y.y * ww.x;
-        x[k] = make_double2(u.x + vr, u.y + vi);
-        x[k | (1 << s)] = make_double2(u.x - vr, u.y - vi);
+        ra_butterfly<FMA>(x[k], x[k | (1 << s)], w[(1 << s) - 1 + (k & ((1 << s) - 1))]);
       }
     }
 #pragma unroll
@@ -81,7 +88,7 @@ __device__ inline void ra_fft_load_tw(double2 (&w)[8], int M, int log2M, int log
     for (int q = 0; q < (1 << s); ++q) w[(1 << s) - 1 + q] = tw_half[(r + q * h) << (log2M - 1 - s - log2h)];
   }
 }
-template <int S>
+template <int S, bool FMA = false>
 __device__ inline void ra_fft_pass_w(double2 *z, int M, int log2M, int log2h, int g, const double2 (&w)[8]) {
   constexpr int R = 1 << S;
   const int h = 1 << log2h, zs = ra_zshift(log2M);
@@ -96,12 +103,7 @@ __device__ inline void ra_fft_pass_w(double2 *z, int M, int log2M, int log2h, in
 #pragma unroll
       for (int k = 0; k < R; ++k) {
         if (k & (1 << s)) continue;
-        const double2 ww = w[(1 << s) - 1 + (k & ((1 << s) - 1))];
-        const double2 u = x[k], y = x[k | (1 << s)];
-        const double vr = y.x * ww.x - y.y * ww.y;
-        const double vi = y.x * ww.y + y.y * ww.x;
-        x[k] = make_double2(u.x + vr, u.y + vi);
-        x[k | (1 << s)] = make_double2(u.x - vr, u.y - vi);
+        ra_butterfly<FMA>(x[k], x[k | (1 << s)], w[(1 << s) - 1 + (k & ((1 << s) - 1))]);
       }
     }
 #pragma unroll
@@ -154,6 +156,74 @@ __device__ inline void ra_fft_fused(double2 *z, int M, int log2M, const double2 
   while (log2M - done >= 3) { ra_fft_pass<3, false>(z, M, log2M, done, tw_half, tid, T, none); done += 3; }
   if (log2M - done == 2) ra_fft_pass<2, false>(z, M, log2M, done, tw_half, tid, T, none);
   else if (log2M - done == 1) ra_fft_pass<1, false>(z, M, log2M, done, tw_half, tid, T, none);
+}
+
+// ---- the vocoder modulator's transform (r04): same network, same LDS layout, but -------------------------------------------------------
+//  * the first pass is what it is when its twiddles are exact — an 8-point DFT with the constants 1, -i, (+-1 - i) / sqrt 2 — and its inputs
+//    that lie in the zero padding are never loaded or added: a window of W samples in a transform of L = 2 M leaves the packed elements from
+//    W / 2 on zero, and input rk of group gi is element rk M / 8 + gi, so only the first NZ = ceil(W / 2 / (M / 8)) of the 8 inputs can be
+//    non-zero (NZ >= 5 because L < 2 W; 4800 samples in 8192: NZ = 5, the pass's first stage shrinks from four butterflies to one);
+//  * the later passes fuse their multiply-adds (ra_butterfly<true>).
+// Requires log2M >= 3 and M / 8 <= T (one group per thread in every three-stage pass).  load(i): packed element i < NZ M / 8.
+template <int NZ, typename LoadFn>
+__device__ inline void ra_fft_first_pass_pruned(double2 *z, int M, int log2M, int tid, LoadFn load) {
+  const int G = M >> 3, zs = ra_zshift(log2M);
+  if (tid < G) {
+    const int gi = tid;
+    const int g = log2M > 3 ? (int)(__brev((unsigned)gi) >> (32 - (log2M - 3))) : 0; // consecutive lanes load consecutive packed elements
+    double2 a[8];
+#pragma unroll
+    for (int rk = 0; rk < 8; ++rk) a[rk] = rk < NZ ? load(rk * G + gi) : make_double2(0.0, 0.0);
+    auto add = [](double2 p, double2 q) { return make_double2(p.x + q.x, p.y + q.y); };
+    auto sub = [](double2 p, double2 q) { return make_double2(p.x - q.x, p.y - q.y); };
+    auto add_mi = [](double2 p, double2 q) { return make_double2(p.x + q.y, p.y - q.x); }; // p - i q
+    auto sub_mi = [](double2 p, double2 q) { return make_double2(p.x - q.y, p.y + q.x); }; // p + i q
+    // stage 1 (pairs 4 apart): a missing partner leaves sum and difference equal to the input
+    const double2 b0 = NZ > 4 ? add(a[0], a[4]) : a[0], b1 = NZ > 4 ? sub(a[0], a[4]) : a[0];
+    const double2 b2 = NZ > 6 ? add(a[2], a[6]) : a[2], b3 = NZ > 6 ? sub(a[2], a[6]) : a[2];
+    const double2 b4 = NZ > 5 ? add(a[1], a[5]) : a[1], b5 = NZ > 5 ? sub(a[1], a[5]) : a[1];
+    const double2 b6 = NZ > 7 ? add(a[3], a[7]) : a[3], b7 = NZ > 7 ? sub(a[3], a[7]) : a[3];
+    // stage 2 (twiddles 1, -i)
+    const double2 c0 = add(b0, b2), c2 = sub(b0, b2), c1 = add_mi(b1, b3), c3 = sub_mi(b1, b3);
+    const double2 c4 = add(b4, b6), c6 = sub(b4, b6), c5 = add_mi(b5, b7), c7 = sub_mi(b5, b7);
+    // stage 3 (twiddles 1, (1 - i) / sqrt 2, -i, (-1 - i) / sqrt 2)
+    const double r = 0.70710678118654752440;
+    const double2 t5 = make_double2((c5.x + c5.y) * r, (c5.y - c5.x) * r);    // c5 (1 - i) / sqrt 2
+    const double2 t7 = make_double2((c7.y - c7.x) * r, -(c7.x + c7.y) * r);   // c7 (-1 - i) / sqrt 2
+    double2 y[8];
+    y[0] = add(c0, c4); y[4] = sub(c0, c4);
+    y[1] = add(c1, t5); y[5] = sub(c1, t5);
+    y[2] = add_mi(c2, c6); y[6] = sub_mi(c2, c6);
+    y[3] = add(c3, t7); y[7] = sub(c3, t7);
+    const int sb = ra_zslot(g << 3, zs);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) z[sb ^ ra_zslot(k, zs)] = y[k];
+  }
+  __syncthreads();
+}
+template <int NZ, typename LoadFn>
+__device__ inline void ra_fft_fused_fast(double2 *z, int M, int log2M, const double2 *__restrict__ tw_half, int tid, int T, LoadFn load) {
+  auto none = [](int) { return make_double2(0.0, 0.0); };
+  double2 wn[8], w[8];
+  int done = 3;
+  int Sn = min(3, log2M - done);
+  if (Sn == 3) ra_fft_load_tw<3>(wn, M, log2M, done, tw_half, tid);
+  else if (Sn == 2) ra_fft_load_tw<2>(wn, M, log2M, done, tw_half, tid);
+  else if (Sn == 1) ra_fft_load_tw<1>(wn, M, log2M, done, tw_half, tid);
+  ra_fft_first_pass_pruned<NZ>(z, M, log2M, tid, load);
+  while (done < log2M) {
+    const int S = Sn, next = done + S;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) w[q] = wn[q];
+    Sn = min(3, log2M - next);
+    if (Sn == 3) ra_fft_load_tw<3>(wn, M, log2M, next, tw_half, tid);
+    else if (Sn == 2) ra_fft_load_tw<2>(wn, M, log2M, next, tw_half, tid);
+    else if (Sn == 1) ra_fft_load_tw<1>(wn, M, log2M, next, tw_half, tid);
+    if (S == 3) ra_fft_pass_w<3, true>(z, M, log2M, done, tid, w);
+    else if (S == 2) { if ((M >> 2) <= T) ra_fft_pass_w<2, true>(z, M, log2M, done, tid, w); else ra_fft_pass<2, false, decltype(none), true>(z, M, log2M, done, tw_half, tid, T, none); }
+    else { if ((M >> 1) <= T) ra_fft_pass_w<1, true>(z, M, log2M, done, tid, w); else ra_fft_pass<1, false, decltype(none), true>(z, M, log2M, done, tw_half, tid, T, none); }
+    done = next;
+  }
 }
 
 // One bin of the real spectrum from the packed transform: X[k] = E[k] + W^k O[k],

@@ -183,6 +183,7 @@ struct RaBuffers {
   double2 *vm_tw_half, *vm_tw_full; int *vm_bitrev;   // modulator FFT, length Lm
   double2 *vc_tw_half, *vc_tw_full; int *vc_bitrev;   // carrier FFT, length Lc
   int *voc_mod_band_start;  // [2*bands] modulator bins of band b are [v[2b], v[2b+1])
+  int *voc_mod_bin_band;    // [Mm + 1] band of every modulator bin: -1 below the first band, `bands` above the last one and for the Nyquist bin (non-decreasing)
   int *voc_car_band;        // [Lc/2+1] band of each carrier bin, -1 = outside every band
   double *voc_xf_new;       // [S] EqualGainXFade new-signal gain for new_signal_idx = 0..S-1
   float *voc_mod_hist;      // [n_streams][Wm] last Wm voice samples

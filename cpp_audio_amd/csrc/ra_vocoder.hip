@@ -125,6 +125,108 @@ __global__ void __launch_bounds__(T, 4) ra_voc_modulator_kernel(RaParams p, RaBu
   }
 }
 
+// ---- K4a, the product path (r04) --------------------------------------------------------------------
+// The modulator's spectrum decides nothing (its bar is the vocoded signal's 1e-5 RMS), so its transform need not share the analysis' unfused
+// network: ra_fft_fused_fast — a first pass with exact constants that never touches the zero padding, fused multiply-adds after it — and
+//  * the real-spectrum split works on the pair (k, M - k) at once: with E = (Z[k] + conj Z[M-k]) / 2, O = -i (Z[k] - conj Z[M-k]) / 2 and
+//    P = W^k O the two bins are E + P and conj(E - P) (W^(M-k) = -conj W^k): one twiddle, one complex product, |E + P|^2 and |E - P|^2;
+//  * |X|^2 never goes back to LDS: a wave's 64 bins of a trip are consecutive, so they belong to one band or to a few; per band present
+//    in the wave the lanes' values are folded on the VALU (wave_sum_row0) and lane 0 adds the total to the wave's own row of partial sums;
+//    the rows are added in wave order at the end.  (r03 wrote 4096 doubles back, gave every band to one wave and waited for the wave with
+//    the widest bands: 34 % of the frame for split + sums.)
+// The order of the additions inside a band differs from r03's (and from the reference's bin order) by rounding: ~1e-16 of an amplitude.
+// bin_band: [M + 1] band of every bin, -1 below the first band's lower edge, `bands` above the last band's upper edge (and for the Nyquist
+// bin M, which the reference drops): non-decreasing in the bin index.
+template <int T, int NZ>
+__global__ void __launch_bounds__(T, 4) ra_voc_modulator_fast_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int64_t t0, int64_t n, int64_t j_lo,
+                                                                 int n_mod, int fpw) {
+  const int s = blockIdx.y;
+  constexpr int NW = T / 64;
+  for (int jb = blockIdx.x * fpw, jb_end = min(jb + fpw, n_mod); jb < jb_end; ++jb) {
+  int tid = threadIdx.x, M = p.voc_Mm;
+  asm volatile("" : "+v"(tid), "+s"(M)); // (as in the kernel above: nothing computed from them is hoisted out of the frame loop)
+  const int W = p.voc_Wm, S = p.voc_S, log2M = ilog2(M), B = p.voc_bands;
+  double2 *z = reinterpret_cast<double2 *>(ra_smem_voc);
+  double *part = reinterpret_cast<double *>(z + ra_zsize(M)); // [NW][64] the waves' band sums of this frame
+  const int zs = ra_zshift(log2M);
+  auto Z = [&](int i) -> double2 & { return z[ra_zslot(i, zs)]; };
+  const int Mh1 = M >> 1, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid < NW * 64) part[tid] = 0.0; // (read after the transform's barriers)
+  double2 sw0 = make_double2(0, 0);
+  if (tid <= Mh1) sw0 = b.vm_tw_full[tid];
+  {
+    const int64_t start = (j_lo + jb) * (int64_t)S;
+    const float *hist = b.voc_mod_hist + (size_t)s * W;
+    const float *vs = voice ? voice + (size_t)s * n : nullptr;
+    const int h = W / 2;
+    const bool plain = vs && start >= t0; // workgroup-uniform (W is a multiple of 4 on this path)
+    if (plain) {
+      const float *w0 = vs + (start - t0);
+      const double2 *hw2 = reinterpret_cast<const double2 *>(b.voc_half_window);
+      ra_fft_fused_fast<NZ>(z, M, log2M, b.vm_tw_half, tid, T, [&](int k) {
+        // (only the last of the NZ inputs of a group can lie in the padding: a clamped load times 0, so that the loads stay unconditional)
+        const bool in = 2 * k < W;
+        const int i0 = in ? 2 * k : W - 2;
+        const float v0 = w0[i0], v1 = w0[i0 + 1];
+        const bool upper = i0 >= h;
+        const double2 ww = hw2[upper ? (i0 - h) >> 1 : (h - 2 - i0) >> 1];
+        const double keep = in ? 1.0 : 0.0;
+        return make_double2((double)v0 * (upper ? ww.x : ww.y) * keep, (double)v1 * (upper ? ww.y : ww.x) * keep);
+      });
+    } else { // the block's first frames look back into the history: the same values from two places
+      auto sample = [&](int i) -> double {
+        if (i >= W) return 0.0;
+        int64_t a = start + i;
+        float v = (a < t0) ? hist[W - (t0 - a)] : (vs ? vs[a - t0] : 0.f);
+        int j = (i >= h) ? (i - h) : (h - 1 - i);
+        return (double)v * b.voc_half_window[j] * 1.0;
+      };
+      ra_fft_fused_fast<NZ>(z, M, log2M, b.vm_tw_half, tid, T, [&](int k) { return make_double2(sample(2 * k), sample(2 * k + 1)); });
+    }
+  }
+  // split + |X|^2 + band sums, one pair of bins per lane and trip
+  for (int k0 = wv * 64; k0 <= Mh1; k0 += T) { // wave-uniform trip: bins k0 .. k0 + 63 and M - k0 - 63 .. M - k0
+    const int k = k0 + lane;
+    const bool on = k <= Mh1;
+    const int kc = on ? k : Mh1, km = M - kc; // km in M/2 .. M
+    const double2 zk = Z(kc), zm = Z(km & (M - 1));
+    const double2 w = sw0;
+    if (k + T <= Mh1) sw0 = b.vm_tw_full[k + T];
+    const double ex = zk.x + zm.x, ey = zk.y - zm.y;      // 2 E
+    const double ox = zk.y + zm.y, oy = zm.x - zk.x;      // 2 O = -i (Z[k] - conj Z[M-k])
+    const double px = fma(w.x, ox, -(w.y * oy)), py = fma(w.x, oy, w.y * ox); // 2 W^k O
+    const double ax = ex + px, ay = ey + py, bx = ex - px, by = ey - py;
+    double sk = 0.25 * fma(ax, ax, ay * ay), sm = 0.25 * fma(bx, bx, by * by);
+    int bk = on ? b.voc_mod_bin_band[kc] : B, bm = (on && km != kc) ? b.voc_mod_bin_band[km] : B; // (k = M/2 pairs with itself: counted once)
+    if (bk < 0 || bk >= B) sk = 0.0;
+    if (bm < 0 || bm >= B) sm = 0.0;
+    auto fold = [&](double v, int band, int b_first, int b_last) { // bands b_first <= ... <= b_last are the ones present in the wave (clamped to 0 .. B - 1)
+      for (int q = b_first; q <= b_last; ++q) {
+        const double tot = wave_sum_row0(band == q ? v : 0.0);
+        if (lane == 0) part[wv * 64 + q] += tot;
+      }
+    };
+    // ascending bins k0 .. k0 + 63: lane 0 holds the lowest band, lane 63 the highest; the mirrored bins descend
+    {
+      const int lo = max(__builtin_amdgcn_readlane(bk, 0), 0), hi = min(__builtin_amdgcn_readlane(bk, 63), B - 1);
+      fold(sk, bk, lo, hi);
+    }
+    {
+      const int lo = max(__builtin_amdgcn_readlane(bm, 63), 0), hi = min(__builtin_amdgcn_readlane(bm, 0), B - 1);
+      fold(sm, bm, lo, hi);
+    }
+  }
+  __syncthreads();
+  if (tid < B) {
+    double tot = 0.0;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) tot += part[q * 64 + tid];
+    b.voc_amp[((size_t)s * b.voc_mod_cap + jb) * B + tid] = sqrt(tot);
+  }
+  __syncthreads(); // the buffer and the partial sums are reused by the next frame
+  }
+}
+
 // ---- K4b ------------------------------------------------------------------------------------------
 // T threads per frame: one wavefront for the usual short carrier frames (L = 512: 32 radix-8 groups per pass), 256 for long ones.
 template <int T, bool BIG>
@@ -297,6 +399,9 @@ void ra_launch_vocoder(const RaParams &p, const RaBuffers &b, const float *d_voi
   ra_once_per_device(attr_done, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_modulator_kernel<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_modulator_kernel<512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define RA_FAST_ATTR(TT, NZ) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_modulator_fast_kernel<TT, NZ>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+    RA_FAST_ATTR(512, 5); RA_FAST_ATTR(512, 6); RA_FAST_ATTR(512, 7); RA_FAST_ATTR(512, 8); RA_FAST_ATTR(256, 5); RA_FAST_ATTR(256, 6); RA_FAST_ATTR(256, 7); RA_FAST_ATTR(256, 8);
+#undef RA_FAST_ATTR
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_carrier_kernel<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_carrier_kernel<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_voc_roll_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -312,6 +417,17 @@ void ra_launch_vocoder(const RaParams &p, const RaBuffers &b, const float *d_voi
     const bool big = lds > (size_t)RA_LDS_LIMIT_BYTES;
     if (big) fpw = (int)std::max<int64_t>(1, (mod.count * (int64_t)p.n_streams + RA_VOC_BIG_WORKGROUPS - 1) / RA_VOC_BIG_WORKGROUPS); // <= RA_VOC_BIG_WORKGROUPS + n_streams buffers
     const dim3 grid((unsigned)((mod.count + fpw - 1) / fpw), (unsigned)p.n_streams);
+    // the product path: the pruned / fused transform (needs one radix-8 group per thread: M / 8 <= T, whole pairs in both window halves)
+    static const bool slow_env = getenv("RA_VOC_UNFUSED") != nullptr; // tuning aid: r03's kernel (the analysis' unfused network)
+    const int Tm = p.voc_Mm >= 4096 ? 512 : 256;
+    if (!big && !slow_env && (p.voc_Wm & 3) == 0 && p.voc_Mm >= 128 && (p.voc_Mm >> 3) <= Tm && p.voc_bands <= 64) {
+      const int G = p.voc_Mm >> 3, nz = (p.voc_Wm / 2 + G - 1) / G; // non-zero inputs of a first-pass group (5 .. 8: L < 2 W)
+      const size_t lds_fast = lds + (size_t)(Tm / 64) * 64 * sizeof(double);
+#define RA_FAST_MOD(TT, NZ) hipLaunchKernelGGL((ra_voc_modulator_fast_kernel<TT, NZ>), grid, dim3(TT), lds_fast, st, p, b, d_voice, t0, n, mod.lo, (int)mod.count, fpw)
+      if (Tm == 512) { if (nz <= 5) RA_FAST_MOD(512, 5); else if (nz == 6) RA_FAST_MOD(512, 6); else if (nz == 7) RA_FAST_MOD(512, 7); else RA_FAST_MOD(512, 8); }
+      else { if (nz <= 5) RA_FAST_MOD(256, 5); else if (nz == 6) RA_FAST_MOD(256, 6); else if (nz == 7) RA_FAST_MOD(256, 7); else RA_FAST_MOD(256, 8); }
+#undef RA_FAST_MOD
+    } else
     if (big) hipLaunchKernelGGL((ra_voc_modulator_kernel<512, true>), grid, dim3(512), 0, st, p, b, d_voice, t0, n, mod.lo, (int)mod.count, fpw);
     else if (p.voc_Mm >= 4096) hipLaunchKernelGGL((ra_voc_modulator_kernel<512, false>), grid, dim3(512), lds, st, p, b, d_voice, t0, n, mod.lo, (int)mod.count, fpw);
     else hipLaunchKernelGGL((ra_voc_modulator_kernel<256, false>), grid, dim3(256), lds, st, p, b, d_voice, t0, n, mod.lo, (int)mod.count, fpw);
