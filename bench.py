@@ -432,13 +432,14 @@ def compact_line(result, details_path=None):
             others[o["workload"]] = o["ms_per_step"]
             if o["workload"] == "north_star":
                 c["north_star"] = {"ms_per_step": o["ms_per_step"], "x_realtime": o.get("x_realtime_per_stream"), "streams": o.get("streams"),
-                                   "pcie_inclusive_ms_per_step": (o.get("pcie_inclusive") or {}).get("ms_per_step")}
+                                   "pcie_inclusive_ms_per_step": (o.get("pcie_inclusive") or {}).get("ms_per_step"),
+                                   "pcie_inclusive_pinned_ms_per_step": (o.get("pcie_inclusive") or {}).get("pinned_ms_per_step")}
         elif "error" in o:
             others["error"] = str(o["error"])[:120]
     if others:
         c["other_ms_per_step"] = others
     if "pcie_inclusive" in result:
-        c["pcie_inclusive"] = _pick(result["pcie_inclusive"], ("ms_per_step", "streams", "GBs_host_link"))
+        c["pcie_inclusive"] = _pick(result["pcie_inclusive"], ("ms_per_step", "pinned_ms_per_step", "streams", "GBs_host_link", "pinned_GBs_host_link"))
     if result.get("retimed"):
         c["retimed"] = _pick(result["retimed"], ("first_ms_per_step", "busiest_queue_ms_per_step"))
     c["checks"] = result.get("checks")
@@ -475,10 +476,14 @@ def emit(result, details_path, out=None):
 
 
 def pcie_inclusive(api, torch, cfg, S, n, local_rank):
-    """The PCIe-inclusive rate DESIGN.md quotes beside `value` (never value itself): one block of S streams through ra_process_host — pageable
-    host buffers up, the block, float32 stereo down, synchronised — on a fresh context (its second block: the first sizes the staging)."""
+    """The PCIe-inclusive rate DESIGN.md quotes beside `value` (never value itself): one block of S streams through ra_process_host — the block's
+    input up, the block, float32 stereo down, synchronised — on a fresh context (its third block: the first two size the staging), from pageable
+    memory (numpy) and from page-locked memory (ra_host_alloc)."""
     import numpy as np
     hv = (np.random.default_rng(7).standard_normal((S, n), dtype=np.float32) * 0.05)
+    res = {"streams": S, "frames_per_stream": n,
+           "how": "ra_process_host: H2D of [S][n] float32, the block, D2H of [S][n][2] float32, synchronised; ms_per_step from pageable host memory, "
+                  "pinned_ms_per_step from ra_host_alloc memory"}
     with api.Context(cfg, S, local_rank) as c:
         c.process_host(hv[:, :min(n, SR)])
         c.reset()
@@ -486,8 +491,18 @@ def pcie_inclusive(api, torch, cfg, S, n, local_rank):
         t0 = time.perf_counter()
         c.process_host(hv)
         dt = time.perf_counter() - t0
-    return {"ms_per_step": dt * 1e3, "streams": S, "frames_per_stream": n, "GBs_host_link": 12.0 * S * n / dt / 1e9,
-            "how": "ra_process_host: H2D of [S][n] float32 from pageable memory, the block, D2H of [S][n][2] float32, synchronised"}
+        res.update({"ms_per_step": dt * 1e3, "GBs_host_link": 12.0 * S * n / dt / 1e9})
+        try:
+            with api.PinnedArray((S, n), np.float32) as pin_in, api.PinnedArray((S, n, 2), np.float32) as pin_out:
+                pin_in.array[...] = hv
+                c.process_host(pin_in.array, out=pin_out.array)
+                t0 = time.perf_counter()
+                c.process_host(pin_in.array, out=pin_out.array)
+                dtp = time.perf_counter() - t0
+            res.update({"pinned_ms_per_step": dtp * 1e3, "pinned_GBs_host_link": 12.0 * S * n / dtp / 1e9})
+        except Exception as e:
+            res["pinned_error"] = repr(e)
+    return res
 
 
 def main():

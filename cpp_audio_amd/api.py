@@ -79,7 +79,7 @@ EXPORTED_SYMBOLS = [
     "ra_create", "ra_destroy", "ra_reset", "ra_set_hip_stream", "ra_process_device", "ra_process_device_async", "ra_join", "ra_process_host",
     "ra_synchronize",
     "ra_feed", "ra_compute", "ra_get_stats", "ra_get_events", "ra_get_frame_pitches", "ra_resynth_notes", "ra_sqmag",
-    "ra_set_profiling", "ra_get_kernel_ms", "ra_get_kernel_launches", "ra_get_stage_timing", "ra_set_clock_stamps", "ra_get_clock_stamps", "ra_render_note",
+    "ra_host_alloc", "ra_host_free", "ra_set_profiling", "ra_get_kernel_ms", "ra_get_kernel_launches", "ra_get_stage_timing", "ra_set_clock_stamps", "ra_get_clock_stamps", "ra_render_note",
     "ra_carrier_events", "ra_get_carrier", "ra_set_pipeline_serial", "ra_deduce_notes", "ra_deduce_notes_batch",
     "ra_voice_default_config", "ra_voice_program", "ra_voice_expand_note", "ra_voice_create", "ra_voice_destroy", "ra_voice_events", "ra_voice_process_host", "ra_voice_process_device",
     "ra_voice_process_device_async", "ra_voice_set_hip_stream", "ra_voice_synchronize", "ra_voice_get_kernel_ms", "ra_voice_dropped_note_ons",
@@ -125,6 +125,10 @@ def lib():
         L.ra_get_kernel_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
         L.ra_get_kernel_launches.argtypes = [C.c_void_p, C.c_void_p]
         L.ra_get_stage_timing.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+        L.ra_host_alloc.argtypes = [C.c_int64]
+        L.ra_host_alloc.restype = C.c_void_p
+        L.ra_host_free.argtypes = [C.c_void_p]
+        L.ra_host_free.restype = None
         L.ra_set_clock_stamps.argtypes = [C.c_void_p, C.c_int32]
         L.ra_get_clock_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.ra_carrier_events.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
@@ -187,8 +191,8 @@ class Context:
     def set_hip_stream(self, stream_handle):
         _check(lib().ra_set_hip_stream(self._h, C.c_void_p(stream_handle)))
 
-    def process_host(self, voice, carrier=None, n_frames=None):
-        """voice/carrier: [n_streams, n] float32 (or None). Returns out [n_streams, n, 2] float32."""
+    def process_host(self, voice, carrier=None, n_frames=None, out=None):
+        """voice/carrier: [n_streams, n] float32 (or None). Returns out [n_streams, n, 2] float32 (`out`: a caller's buffer, e.g. a PinnedArray's)."""
         a = voice if voice is not None else carrier
         if a is None:
             S, n = self.n_streams, int(n_frames)
@@ -197,7 +201,9 @@ class Context:
         assert S == self.n_streams
         v = np.ascontiguousarray(voice, np.float32) if voice is not None else None
         c = np.ascontiguousarray(carrier, np.float32) if carrier is not None else None
-        out = np.empty((S, n, 2), np.float32)
+        if out is None:
+            out = np.empty((S, n, 2), np.float32)
+        assert out.shape == (S, n, 2) and out.dtype == np.float32 and out.flags.c_contiguous
         _check(lib().ra_process_host(self._h, _p(v), _p(c), n, _p(out)))
         return out
 
@@ -303,6 +309,29 @@ class Context:
         nf = _check(lib().ra_get_frame_pitches(self._h, stream, _p(fire), _p(offs), frame_cap, _p(pitch), _p(vol), item_cap))
         assert nf <= frame_cap and offs[nf] <= item_cap
         return fire[:nf], offs[:nf + 1], pitch[:offs[nf]], vol[:offs[nf]]
+
+
+class PinnedArray:
+    """A numpy array over page-locked host memory (ra_host_alloc): `with PinnedArray((S, n), np.float32) as a: a.array[...]`."""
+
+    def __init__(self, shape, dtype):
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._p = lib().ra_host_alloc(self.nbytes)
+        if not self._p:
+            raise RaError(-3, lib().ra_last_error().decode())
+        self.array = np.frombuffer((C.c_char * self.nbytes).from_address(self._p), dtype=dtype).reshape(shape)
+
+    def close(self):
+        if self._p:
+            self.array = None
+            lib().ra_host_free(self._p)
+            self._p = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 def sqmag(windows, window_kind=0, device=0):

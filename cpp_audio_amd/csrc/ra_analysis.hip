@@ -356,7 +356,7 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   // the FFT buffer, the unused .x half of the peak's own slot (8 bytes: the pointer and the mark)
   const int area_ints = max(8 * cap, T + 32);
   int *jump = scan + T + 32, *mark = jump + K;
-  const bool par = K > 0 && K <= 4 * T && (lists_in_z || T + 32 + 2 * K <= area_ints);
+  const bool par = K > 0 && K <= 4 * T && (lists_in_z || T + 32 + 3 * K <= area_ints);
   auto JP = [&](int i) -> int & { return lists_in_z ? reinterpret_cast<int *>(&Z(i).x)[0] : jump[i]; };
   auto MK = [&](int i) -> int & { return lists_in_z ? reinterpret_cast<int *>(&Z(i).x)[1] : mark[i]; };
   for (int i = tid; i < K; i += T) {
@@ -373,22 +373,25 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   if (par) {
     // 5b by pointer jumping.  Before round r: jump = nxt^(2^r), and the first 2^r interval starts are marked.  A marked peak marks
     // where its pointer leads (marks only ever land on interval starts, so marks seen within the same round are harmless), then every
-    // pointer doubles.  Done when 2^(r+1) hops from peak 0 leave the list.
+    // pointer doubles.  Done when 2^(r+1) hops from peak 0 leave the list.  The pointers exist twice — a round reads one copy and writes the
+    // other — so a round costs ONE barrier (r04; the second copy is the unused .x half of the peak's volume slot Mh + i, or a third int array
+    // beside the scan area): these ~log2(intervals) rounds of barriers were 20 % of a configs[3] frame.
+    auto JQ = [&](int i) -> int & { return lists_in_z ? reinterpret_cast<int *>(&Z(Mh + i).x)[0] : mark[K + i]; };
+    bool flip = false;
     while (true) {
-      int jn[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int i = tid + T * q;
         if (i < K) {
-          const int j = JP(i);
-          if (j < K) { if (MK(i)) MK(j) = 1; jn[q] = JP(j); } else jn[q] = K;
+          const int j = flip ? JQ(i) : JP(i);
+          int jn = K;
+          if (j < K) { if (MK(i)) MK(j) = 1; jn = flip ? JQ(j) : JP(j); }
+          if (flip) JP(i) = jn; else JQ(i) = jn;
         }
       }
       __syncthreads();
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { const int i = tid + T * q; if (i < K) JP(i) = jn[q]; }
-      __syncthreads();
-      if (JP(0) >= K) break; // the same LDS word for every thread: uniform
+      flip = !flip;
+      if ((flip ? JQ(0) : JP(0)) >= K) break; // the same LDS word for every thread: uniform
     }
     // the marked peaks, in index order, are the interval starts
     const int c = (K + T - 1) / T;
@@ -416,27 +419,31 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
     sumV = 0; sumPV = 0;
     for (int i = i0; i < i1; ++i) { double pt = Z(i).y, v = Z(Mh + i).y; sumV += v; sumPV += pt * v; }
   };
+  // (with the lists in the FFT buffer a thread owns at most four intervals: they are summed ONCE, into registers, before the scan that gives
+  // them their places — r03 summed every interval twice, once to count and once to store)
+  double2 item[4];
+  unsigned have = 0; // (static indices only: a dynamically indexed private array would live in scratch memory)
   {
     int kept = 0;
-    for (int r = r0; r < r1; ++r) { double sv, spv; interval(r, sv, spv); kept += !(sv < p.min_volume) ? 1 : 0; }
+    if (lists_in_z) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = r0 + j;
+        item[j] = make_double2(0.0, 0.0);
+        if (r < r1) {
+          double sv, spv;
+          interval(r, sv, spv);
+          if (!(sv < p.min_volume)) { item[j] = make_double2(spv / sv, sv); have |= 1u << j; ++kept; }
+        }
+      }
+    } else {
+      for (int r = r0; r < r1; ++r) { double sv, spv; interval(r, sv, spv); kept += !(sv < p.min_volume) ? 1 : 0; }
+    }
     block_exclusive_scan<T>(scan, kept, tid);
   }
   int pos = scan[tid];
   const int Rk = scan[T];
-  if (lists_in_z) { // the list overwrites what `interval` reads: the thread's items (chunkR <= 4) wait in registers for everybody's last read
-    double2 item[4];
-    unsigned have = 0; // (static indices only: a dynamically indexed private array would live in scratch memory)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = r0 + j;
-      item[j] = make_double2(0.0, 0.0);
-      if (r < r1) {
-        double sv, spv;
-        interval(r, sv, spv);
-        if (!(sv < p.min_volume)) { item[j] = make_double2(spv / sv, sv); have |= 1u << j; }
-      }
-    }
-    __syncthreads();
+  if (lists_in_z) { // the list overwrites what `interval` read: everybody's last read is behind the scan's barriers
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (have & (1u << j)) { if (pos < cap) listA[pos] = item[j]; ++pos; }

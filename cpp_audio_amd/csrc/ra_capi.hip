@@ -1367,6 +1367,13 @@ int ra_process_host(ra_context *c, const float *h_voice, const float *h_carrier,
   return ra_synchronize(c);
 }
 
+void *ra_host_alloc(int64_t bytes) {
+  void *p = nullptr;
+  if (bytes <= 0 || hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) { fail(RA_EHIP, "ra_host_alloc: hipHostMalloc failed"); return nullptr; }
+  return p;
+}
+void ra_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
 int ra_carrier_events(ra_context *c, const ra_carrier_event *ev, int64_t n) {
   if (!c) return fail(RA_EINVAL, "null context");
   if (n < 0 || (n > 0 && !ev)) return fail(RA_EINVAL, "bad events");

@@ -210,6 +210,14 @@ int ra_process_device(ra_context *ctx, const float *d_voice, const float *d_carr
 /* same with HOST buffers (does H2D, process, D2H, synchronises) */
 int ra_process_host(ra_context *ctx, const float *h_voice, const float *h_carrier, int64_t n_frames, float *h_out);
 int ra_synchronize(ra_context *ctx);
+/*
+ * Page-locked host memory for the buffers handed to ra_process_host (hipHostMalloc / hipHostFree): from pageable memory the runtime stages
+ * every copy through its own pinned bounce buffers (~12 GB/s measured on the test box), from these the copies run at the link's rate.  Where the
+ * streams come from the host — BASELINE configs[4]: 1000 streams per GPU — the link, not the kernels, paces a block.
+ * The reference has no counterpart (its job reads and writes WAV files frame by frame, rt.resynth.lib.params.cpp:291-324).
+ */
+void *ra_host_alloc(int64_t bytes);
+void ra_host_free(void *p);
 
 /*
  * Streaming variant for back-to-back blocks: like ra_process_device, but the caller's stream is NOT made to wait for the block.

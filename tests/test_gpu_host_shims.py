@@ -58,3 +58,40 @@ def test_offline_job_file_runs_end_to_end(oracle, tmp_path, run_program):
     ref, _, _ = oracle.run_offline(cfg, voice)
     assert np.sqrt(np.mean(ref.astype(np.float64) ** 2)) > 1e-4
     assert np.sqrt(np.mean((out.astype(np.float64) - ref) ** 2)) <= 1e-5
+
+
+def test_one_host_thread_and_one_hip_stream_per_device_in_one_process(tmp_path, run_program):
+    """SURVEY.md section 8(e)'s wording: the C++ example tests/host/device_threads.cpp drives one context per host thread, each on a HIP stream of
+    its own (device t mod the device count: both on device 0 of this one-GPU box), on contiguous shards with seeds = seed + global stream index;
+    every thread's output equals the same shard run from a single thread bit for bit (2 and 3 threads), and the union equals one context over
+    all streams up to the rounding of the block cut."""
+    from cpp_audio_amd import api, signals
+    lib_dir = os.path.join(ROOT, "cpp_audio_amd")
+    exe = tmp_path / "device_threads"
+    rc, so, se = run_program(["g++", "-std=c++17", "-O1", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "host", "device_threads.cpp"),
+                              "-o", str(exe), "-L", lib_dir, "-lresynth_amd", "-L/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"])
+    assert rc == 0, so + se
+    S, n = 7, 40000
+    x = signals.make_streams(S, n, base_seed=41)
+    x.tofile(tmp_path / "voice.f32")
+    kw = dict(window_size=1024, stride=256, n_channels=32, analysis_volume=1.0, stereo_spread=0.0, carrier_volume=0.0)
+    for threads in (2, 3):
+        rc, so, se = run_program([str(exe), str(tmp_path), S, n, threads])
+        assert rc == 0, so + se
+        per = (S + threads - 1) // threads
+        for t in range(threads):
+            lo, hi = min(S, t * per), min(S, (t + 1) * per)
+            if hi <= lo:
+                continue
+            got = np.fromfile(tmp_path / f"out_{t}.f32", np.float32).reshape(hi - lo, n, 2)
+            # the same shard, the same two ragged blocks, from this (single) thread: what a thread of the example computes does not depend on its neighbours
+            cut = n // 3 + 7 * t
+            with api.Context(api.default_config(seed=1234 + lo, **kw), hi - lo, 0) as ctx:
+                ref = np.concatenate([ctx.process_host(x[lo:hi, :cut]), ctx.process_host(x[lo:hi, cut:])], axis=1)
+            assert np.sqrt(np.mean(ref.astype(np.float64) ** 2)) > 1e-3
+            assert np.array_equal(got, ref), f"{threads} threads, thread {t}"
+            # ... and equals the streams' results in one context over all of them, up to the block cut's rounding
+            if t == 0:
+                with api.Context(api.default_config(seed=1234, **kw), S, 0) as ctx:
+                    whole = ctx.process_host(x)
+            assert np.max(np.abs(got.astype(np.float64) - whole[lo:hi])) < 1e-6
