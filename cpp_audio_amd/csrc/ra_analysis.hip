@@ -11,6 +11,7 @@
 // peaks are compacted in bin order and only the short autotuned pitch list goes back to HBM.
 #include "ra_fft.cuh"
 #include "ra_math.cuh"
+#include "ra_lane.cuh"
 #include <algorithm>
 #include <cstdlib>
 
@@ -186,13 +187,14 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
 
   RaPhaseClock clk(b.dbg_clk, tid == 0);
   RaClockStamp stamp(b.dbg_stamp, tid == 0);
-  // twiddles W^k, W^(M-k) of the real-spectrum split (step 3) for the pairs k0, k0 + T: fetched one trip ahead, the first trip's before the FFT
-  double2 sw[4] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
+  // twiddles W^k of the real-spectrum split (step 3) for the pairs k0, k0 + T: fetched one trip ahead, the first trip's before the FFT
+  // (W^(M-k) is the mirror image of W^k by the table's definition: ra_real_split_pair)
+  double2 sw[2] = {make_double2(0, 0), make_double2(0, 0)};
   auto split_twiddles = [&](int k0) {
     const int Mh1 = M >> 1;
     if (k0 > Mh1) return;
     const int k1 = k0 + T, kb = (k1 <= Mh1) ? k1 : k0;
-    sw[0] = b.tw_full[k0]; sw[1] = b.tw_full[(M - k0) % M]; sw[2] = b.tw_full[kb]; sw[3] = b.tw_full[(M - kb) % M];
+    sw[0] = b.tw_full[k0]; sw[1] = b.tw_full[kb];
   };
   split_twiddles(tid);
   // ---- 1 + 2. weighted window -> M point complex FFT of the packed sequence (x[2k], x[2k+1]) ------------------------
@@ -266,10 +268,7 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   // ---- 3. split into the real spectrum, |X|^2 written over .x of the same slots -------------------
   // X[k] = E[k] + W^k O[k],  E = (Z[k] + conj Z[M-k]) / 2,  O = -i/2 (Z[k] - conj Z[M-k]);  bins 0..M-1 kept
   {
-    auto bin = [&](double2 a, double2 c, double2 w) -> double { // a = Z[kk], c = Z[M-kk] (conjugated inside), w = W^kk
-      double2 x = ra_real_split_bin(a, c, w);
-      return x.x * x.x + x.y * x.y;
-    };
+    auto sq = [](double2 x) -> double { return x.x * x.x + x.y * x.y; };
     const int Mh1 = M >> 1;
     for (int k0 = tid; k0 <= Mh1; k0 += 2 * T) { // two pairs per trip, their loads in flight together; the twiddles were fetched a trip ahead
       const int k1 = k0 + T;
@@ -277,10 +276,14 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
       const int ka = k0, kb = has1 ? k1 : k0;
       const int kma = (M - ka) % M, kmb = (M - kb) % M; // partner (k = 0 pairs with itself, k = M/2 too)
       const double2 za = Z(ka), zma = Z(kma), zb = Z(kb), zmb = Z(kmb);
-      const double2 wa = sw[0], wma = sw[1], wb = sw[2], wmb = sw[3];
+      const double2 wa = sw[0], wb = sw[1];
       split_twiddles(k0 + 2 * T);
-      const double sa = bin(za, zma, wa), sma = bin(zma, za, wma);
-      const double sb = bin(zb, zmb, wb), smb = bin(zmb, zb, wmb);
+      // bins k and M - k from one twiddle product (ra_real_split_pair: bit-identical to two separate ra_real_split_bin evaluations);
+      // the self-paired bins 0 and M / 2 take the first result only
+      double2 xa, xma, xb, xmb;
+      ra_real_split_pair(za, zma, wa, xa, xma);
+      ra_real_split_pair(zb, zmb, wb, xb, xmb);
+      const double sa = sq(xa), sma = sq(xma), sb = sq(xb), smb = sq(xmb);
       // the slots of a pair are private to this thread: safe to overwrite now
       Z(ka).x = sa;
       if (kma != ka) Z(kma).x = sma;
@@ -347,66 +350,38 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   RA_STOP_AFTER(4);
 
   // ---- 5. aggregate_pitches + reduce_pitches (algo.cpp:124-184, PonderateByVolume / SumVolumes) -------------------
-  // Pitches ascend, so an interval opened at peak i0 runs up to the first peak j with pitch[j] - pitch[i0] > nearby:
-  //  5a every peak finds that j by binary search (nxt, kept in the now unused .x half of its slot)
-  //  5b the nxt chain from peak 0 lists the interval starts (tens to a few hundred hops): pointer jumping, ~log2 rounds
-  //  5c each interval is summed by one thread in index order (the reference's summation order) and kept if its volume
-  //     reaches min_volume; kept intervals are compacted in order with a block scan
-  // pointer jumping needs two ints per peak: beside the scan area inside the list region, which is idle until 5c — or, when the lists live in
-  // the FFT buffer, the unused .x half of the peak's own slot (8 bytes: the pointer and the mark)
-  const int area_ints = max(8 * cap, T + 32);
-  int *jump = scan + T + 32, *mark = jump + K;
-  const bool par = K > 0 && K <= 4 * T && (lists_in_z || T + 32 + 3 * K <= area_ints);
-  auto JP = [&](int i) -> int & { return lists_in_z ? reinterpret_cast<int *>(&Z(i).x)[0] : jump[i]; };
-  auto MK = [&](int i) -> int & { return lists_in_z ? reinterpret_cast<int *>(&Z(i).x)[1] : mark[i]; };
-  for (int i = tid; i < K; i += T) {
-    const double pi0 = Z(i).y;
-    int lo = i + 1, hi = K;
-    while (lo < hi) {
-      int mid = (lo + hi) >> 1;
-      if (Z(mid).y - pi0 > p.nearby) hi = mid; else lo = mid + 1;
-    }
-    if (par) { JP(i) = lo; MK(i) = (i == 0) ? 1 : 0; } else Z(i).x = (double)lo;
-  }
-  __syncthreads();
-  clk.mark(5);
-  if (par) {
-    // 5b by pointer jumping.  Before round r: jump = nxt^(2^r), and the first 2^r interval starts are marked.  A marked peak marks
-    // where its pointer leads (marks only ever land on interval starts, so marks seen within the same round are harmless), then every
-    // pointer doubles.  Done when 2^(r+1) hops from peak 0 leave the list.  The pointers exist twice — a round reads one copy and writes the
-    // other — so a round costs ONE barrier (r04; the second copy is the unused .x half of the peak's volume slot Mh + i, or a third int array
-    // beside the scan area): these ~log2(intervals) rounds of barriers were 20 % of a configs[3] frame.
-    auto JQ = [&](int i) -> int & { return lists_in_z ? reinterpret_cast<int *>(&Z(Mh + i).x)[0] : mark[K + i]; };
-    bool flip = false;
-    while (true) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = tid + T * q;
-        if (i < K) {
-          const int j = flip ? JQ(i) : JP(i);
-          int jn = K;
-          if (j < K) { if (MK(i)) MK(j) = 1; jn = flip ? JQ(j) : JP(j); }
-          if (flip) JP(i) = jn; else JQ(i) = jn;
-        }
+  // Pitches ascend, so an interval opened at peak s runs up to the first peak j with pitch[j] - pitch[s] > nearby, which opens the next one.
+  //  5ab the interval starts, by ONE wavefront walking the chain with 64 peaks in registers: the lanes hold a window of 64 consecutive
+  //      pitches; the start's pitch comes by v_readlane, one compare over all lanes and the first set bit of the ballot give the next start —
+  //      six vector instructions per interval and no LDS round trip on the chain, the window moving on when the chain leaves it.  (r01 - r03:
+  //      every peak binary-searched its successor and log2(intervals) rounds of pointer jumping marked the chain — 4.6 k wave-instructions per
+  //      8192-point frame, a fifth of the kernel, where this walk issues ~2 k on one wave while the other waves wait at the barrier.)
+  //  5c  each interval is summed by one thread in index order (the reference's summation order) and kept if its volume
+  //      reaches min_volume; kept intervals are compacted in order with a block scan
+  // The starts go to the .x halves of the slots Mh + r (r <= K <= Mh - 1), closed by K itself.
+  if (tid < 64) {
+    const int lane = tid;
+    int s0 = 0, R = 0, wbase = 0; // current start, intervals so far, index of lane 0's peak (all wave-uniform)
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    double pw = (lane < K) ? Z(lane).y : inf; // a peak past the end compares as "far away": the chain ends there
+    while (s0 < K) {
+      if (lane == 0) Z(Mh + R).x = (double)s0;
+      ++R;
+      const double ps = readlane_f64(pw, s0 - wbase);
+      int nxt = K;
+      while (true) {
+        const unsigned long long far = __ballot((wbase + lane > s0) && (pw - ps > p.nearby));
+        if (far) { nxt = wbase + (int)__builtin_ctzll(far); break; }
+        wbase += 64; // the whole window belongs to this interval: next 64 peaks (s0's pitch stays in ps)
+        if (wbase >= K) break;
+        pw = (wbase + lane < K) ? Z(wbase + lane).y : inf;
       }
-      __syncthreads();
-      flip = !flip;
-      if ((flip ? JQ(0) : JP(0)) >= K) break; // the same LDS word for every thread: uniform
+      if (nxt >= K) break;
+      // keep the new start inside the window (the window only moves forwards)
+      if (nxt - wbase >= 64) { wbase = nxt; pw = (wbase + lane < K) ? Z(wbase + lane).y : inf; }
+      s0 = nxt;
     }
-    // the marked peaks, in index order, are the interval starts
-    const int c = (K + T - 1) / T;
-    const int a0 = min(K, tid * c), a1 = min(K, a0 + c);
-    int cntm = 0;
-    for (int i = a0; i < a1; ++i) cntm += MK(i);
-    block_exclusive_scan<T>(scan, cntm, tid);
-    int posm = scan[tid];
-    for (int i = a0; i < a1; ++i) if (MK(i)) Z(Mh + posm++).x = (double)i;
-    if (tid == 0) Z(Mh + scan[T]).x = (double)K; // R <= K <= Mh - 1, so slot Mh + R exists; scan[T] = R stays for 5c
-  } else if (tid == 0) {
-    int R = 0;
-    for (int i = 0; i < K; i = (int)Z(i).x) Z(Mh + R++).x = (double)i;
-    Z(Mh + R).x = (double)K;
-    scan[T] = R;
+    if (lane == 0) { Z(Mh + R).x = (double)K; scan[T] = R; }
   }
   __syncthreads();
   clk.mark(6);

@@ -267,8 +267,11 @@ int upload_fft_tables(ra_context *c, int L, double2 **tw_half, double2 **tw_full
   auto twiddle = [](double a) { volatile double a_again = a; const double cs = std::cos(a); const double sn = std::sin(a_again); return make_double2(cs, sn); };
   for (int k = 0; k < M / 2; ++k) tw[k] = twiddle(-2.0 * M_PI * k / M);
   if ((r = upload(c, tw_half, tw))) return r;
+  // the split's table e^{-2 pi i k / L}, k <= M: the lower half from cos / sin, the upper half DEFINED as its mirror image W^(M - k) = -conj(W^k)
+  // (the CPU restatement builds the same table): bins k and M - k then share one twiddle product (ra_real_split_pair)
   std::vector<double2> tf(M + 1);
-  for (int k = 0; k <= M; ++k) tf[k] = twiddle(-2.0 * M_PI * k / L);
+  for (int k = 0; k <= M / 2; ++k) tf[k] = twiddle(-2.0 * M_PI * k / L);
+  for (int k = M / 2 + 1; k <= M; ++k) tf[k] = make_double2(-tf[M - k].x, tf[M - k].y);
   if ((r = upload(c, tw_full, tf))) return r;
   std::vector<int> rev(std::max(M, 1), 0);
   for (int i = 0; i < M; ++i) {

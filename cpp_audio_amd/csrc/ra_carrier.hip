@@ -22,6 +22,7 @@
 //    `res += ponderation[i] * filtered` runs in band order, like the reference's loop, on a transposed 64-sample tile.
 //    Same operations in the same order as the CPU restatement (no contraction): the vocoded signal is equal bit for bit.
 #include "ra_chan.cuh"
+#include "ra_lane.cuh"
 #include <algorithm>
 #include <cstdlib>
 
@@ -632,12 +633,6 @@ __global__ void __launch_bounds__(RA_MAX_CHANNELS) ra_carrier_render_kernel(RaPa
 
 // ---- K7 -------------------------------------------------------------------------------------------------------------------
 constexpr int BT = 64; // samples per tile = lanes
-__device__ inline double readlane_f64(double v, int lane) { // lane is wave-uniform
-  const long long u = __double_as_longlong(v);
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u & 0xffffffffll), lane);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)u >> 32), lane);
-  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
 __global__ void __launch_bounds__(64) ra_voc_bank_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, const float *__restrict__ carrier_f,
                                                         const double *__restrict__ carrier_d, int64_t n) {
   const int s = blockIdx.x, l = threadIdx.x, B = p.voc_bands;

@@ -234,3 +234,17 @@ __device__ inline double2 ra_real_split_bin(double2 a, double2 c, double2 w) {
   double o_r = 0.5 * di, o_i = -0.5 * dr;
   return make_double2(er + (w.x * o_r - w.y * o_i), ei + (w.x * o_i + w.y * o_r));
 }
+
+// Bins k and M - k of the real spectrum at once, for 0 < k < M / 2: a = Z[k], c = Z[M - k], w = W^k.  The split's table is mirrored by
+// definition, W^(M - k) = (-w.x, w.y), and E[M - k] = conj E[k], O[M - k] = conj O[k], so bin M - k evaluated by ra_real_split_bin(c, a, W^(M-k))
+// is (er - pr, pi - ei) where bin k is (er + pr, ei + pi): every product and sum of the two separate evaluations appears here once, with the
+// same operands in the same order (a sign change of an operand changes the sign of a correctly rounded result and nothing else) — the two
+// bins are bit-identical to the separate evaluations, at 24 instead of 38 operations.
+__device__ inline void ra_real_split_pair(double2 a, double2 c, double2 w, double2 &xk, double2 &xm) {
+  const double er = 0.5 * (a.x + c.x), ei = 0.5 * (a.y - c.y);
+  const double dr = a.x - c.x, di = a.y + c.y;
+  const double o_r = 0.5 * di, o_i = -0.5 * dr;
+  const double pr = w.x * o_r - w.y * o_i, pi = w.x * o_i + w.y * o_r;
+  xk = make_double2(er + pr, ei + pi);
+  xm = make_double2(er - pr, pi - ei);
+}

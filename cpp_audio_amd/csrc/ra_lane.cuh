@@ -2,6 +2,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+__device__ inline double readlane_f64(double v, int lane) { // lane is wave-uniform; the result lives in scalar registers
+  const long long u = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u & 0xffffffffll), lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)u >> 32), lane);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 __device__ inline double lane_xor32_low(double x) { // value of lane ^ 32, valid in lanes 0..31
   const unsigned lo = __double2loint(x), hi = __double2hiint(x);
   const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);

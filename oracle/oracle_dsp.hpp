@@ -92,7 +92,11 @@ struct RealFft {
     L = L_;
     half.init(L / 2);
     tw.resize(L / 2 + 1);
-    for (int k = 0; k <= L / 2; ++k) tw[k] = twiddle(-2.0 * M_PI * k / L);
+    // e^{-2 pi i k / L} for k <= L/4 from cos / sin; the upper half of the table is its mirror image, W^(L/2 - k) = -conj(W^k), taken as the
+    // definition (not as a property a libm may or may not deliver to the last bit): bins k and L/2 - k of the split then share one twiddle
+    // product, which the product's kernels use (ra_real_split_pair) and which leaves every bin's operations as written in forward() below
+    for (int k = 0; k <= L / 4; ++k) tw[k] = twiddle(-2.0 * M_PI * k / L);
+    for (int k = L / 4 + 1; k <= L / 2; ++k) tw[k] = {-tw[L / 2 - k].real(), tw[L / 2 - k].imag()};
     z.resize(L / 2);
   }
   void forward(const double *x, std::complex<double> *X) {
