@@ -350,38 +350,69 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   RA_STOP_AFTER(4);
 
   // ---- 5. aggregate_pitches + reduce_pitches (algo.cpp:124-184, PonderateByVolume / SumVolumes) -------------------
-  // Pitches ascend, so an interval opened at peak s runs up to the first peak j with pitch[j] - pitch[s] > nearby, which opens the next one.
-  //  5ab the interval starts, by ONE wavefront walking the chain with 64 peaks in registers: the lanes hold a window of 64 consecutive
-  //      pitches; the start's pitch comes by v_readlane, one compare over all lanes and the first set bit of the ballot give the next start —
-  //      six vector instructions per interval and no LDS round trip on the chain, the window moving on when the chain leaves it.  (r01 - r03:
-  //      every peak binary-searched its successor and log2(intervals) rounds of pointer jumping marked the chain — 4.6 k wave-instructions per
-  //      8192-point frame, a fifth of the kernel, where this walk issues ~2 k on one wave while the other waves wait at the barrier.)
-  //  5c  each interval is summed by one thread in index order (the reference's summation order) and kept if its volume
-  //      reaches min_volume; kept intervals are compacted in order with a block scan
-  // The starts go to the .x halves of the slots Mh + r (r <= K <= Mh - 1), closed by K itself.
-  if (tid < 64) {
-    const int lane = tid;
-    int s0 = 0, R = 0, wbase = 0; // current start, intervals so far, index of lane 0's peak (all wave-uniform)
-    const double inf = __longlong_as_double(0x7ff0000000000000ll);
-    double pw = (lane < K) ? Z(lane).y : inf; // a peak past the end compares as "far away": the chain ends there
-    while (s0 < K) {
-      if (lane == 0) Z(Mh + R).x = (double)s0;
-      ++R;
-      const double ps = readlane_f64(pw, s0 - wbase);
-      int nxt = K;
-      while (true) {
-        const unsigned long long far = __ballot((wbase + lane > s0) && (pw - ps > p.nearby));
-        if (far) { nxt = wbase + (int)__builtin_ctzll(far); break; }
-        wbase += 64; // the whole window belongs to this interval: next 64 peaks (s0's pitch stays in ps)
-        if (wbase >= K) break;
-        pw = (wbase + lane < K) ? Z(wbase + lane).y : inf;
-      }
-      if (nxt >= K) break;
-      // keep the new start inside the window (the window only moves forwards)
-      if (nxt - wbase >= 64) { wbase = nxt; pw = (wbase + lane < K) ? Z(wbase + lane).y : inf; }
-      s0 = nxt;
+  // Pitches ascend, so an interval opened at peak i0 runs up to the first peak j with pitch[j] - pitch[i0] > nearby:
+  //  5a every peak finds that j by binary search (nxt, kept in the now unused .x half of its slot)
+  //  5b the nxt chain from peak 0 lists the interval starts (tens to a few hundred hops): pointer jumping, ~log2 rounds
+  //  5c each interval is summed by one thread in index order (the reference's summation order) and kept if its volume
+  //     reaches min_volume; kept intervals are compacted in order with a block scan
+  // (r04, measured and not kept: the interval starts by ONE wavefront walking the chain with 64 pitches in registers — readlane of the start's
+  // pitch, one compare over all lanes, the ballot's first set bit: 15 % fewer instructions for the kernel, but ~300 dependent hops per frame on
+  // one wave while the workgroup's other waves hold their registers and LDS at the barrier: configs[3]'s analysis 30.8 -> 48.3 ms.)
+  // pointer jumping needs two ints per peak: beside the scan area inside the list region, which is idle until 5c — or, when the lists live in
+  // the FFT buffer, the unused .x half of the peak's own slot (8 bytes: the pointer and the mark)
+  const int area_ints = max(8 * cap, T + 32);
+  int *jump = scan + T + 32, *mark = jump + K;
+  const bool par = K > 0 && K <= 4 * T && (lists_in_z || T + 32 + 3 * K <= area_ints);
+  auto JP = [&](int i) -> int & { return lists_in_z ? reinterpret_cast<int *>(&Z(i).x)[0] : jump[i]; };
+  auto MK = [&](int i) -> int & { return lists_in_z ? reinterpret_cast<int *>(&Z(i).x)[1] : mark[i]; };
+  for (int i = tid; i < K; i += T) {
+    const double pi0 = Z(i).y;
+    int lo = i + 1, hi = K;
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      if (Z(mid).y - pi0 > p.nearby) hi = mid; else lo = mid + 1;
     }
-    if (lane == 0) { Z(Mh + R).x = (double)K; scan[T] = R; }
+    if (par) { JP(i) = lo; MK(i) = (i == 0) ? 1 : 0; } else Z(i).x = (double)lo;
+  }
+  __syncthreads();
+  clk.mark(5);
+  if (par) {
+    // 5b by pointer jumping.  Before round r: jump = nxt^(2^r), and the first 2^r interval starts are marked.  A marked peak marks
+    // where its pointer leads (marks only ever land on interval starts, so marks seen within the same round are harmless), then every
+    // pointer doubles.  Done when 2^(r+1) hops from peak 0 leave the list.  The pointers exist twice — a round reads one copy and writes the
+    // other — so a round costs ONE barrier (r04; the second copy is the unused .x half of the peak's volume slot Mh + i, or a third int array
+    // beside the scan area): these ~log2(intervals) rounds of barriers were 20 % of a configs[3] frame.
+    auto JQ = [&](int i) -> int & { return lists_in_z ? reinterpret_cast<int *>(&Z(Mh + i).x)[0] : mark[K + i]; };
+    bool flip = false;
+    while (true) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = tid + T * q;
+        if (i < K) {
+          const int j = flip ? JQ(i) : JP(i);
+          int jn = K;
+          if (j < K) { if (MK(i)) MK(j) = 1; jn = flip ? JQ(j) : JP(j); }
+          if (flip) JP(i) = jn; else JQ(i) = jn;
+        }
+      }
+      __syncthreads();
+      flip = !flip;
+      if ((flip ? JQ(0) : JP(0)) >= K) break; // the same LDS word for every thread: uniform
+    }
+    // the marked peaks, in index order, are the interval starts
+    const int c = (K + T - 1) / T;
+    const int a0 = min(K, tid * c), a1 = min(K, a0 + c);
+    int cntm = 0;
+    for (int i = a0; i < a1; ++i) cntm += MK(i);
+    block_exclusive_scan<T>(scan, cntm, tid);
+    int posm = scan[tid];
+    for (int i = a0; i < a1; ++i) if (MK(i)) Z(Mh + posm++).x = (double)i;
+    if (tid == 0) Z(Mh + scan[T]).x = (double)K; // R <= K <= Mh - 1, so slot Mh + R exists; scan[T] = R stays for 5c
+  } else if (tid == 0) {
+    int R = 0;
+    for (int i = 0; i < K; i = (int)Z(i).x) Z(Mh + R++).x = (double)i;
+    Z(Mh + R).x = (double)K;
+    scan[T] = R;
   }
   __syncthreads();
   clk.mark(6);
