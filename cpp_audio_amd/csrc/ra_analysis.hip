@@ -367,7 +367,14 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
   auto MK = [&](int i) -> int & { return lists_in_z ? reinterpret_cast<int *>(&Z(i).x)[1] : mark[i]; };
   for (int i = tid; i < K; i += T) {
     const double pi0 = Z(i).y;
-    int lo = i + 1, hi = K;
+    // the successor is a few peaks away (an interval holds ~3 peaks): gallop 1, 2, 4, ... peaks ahead, then bisect the last stretch —
+    // 3 - 5 probes where the plain bisection of [i + 1, K) took log2 K = 10 (r04)
+    int lo = i + 1, hi = K, st = 1;
+    while (lo < hi) {
+      const int probe = min(lo + st - 1, hi - 1);
+      if (Z(probe).y - pi0 > p.nearby) { hi = probe; break; }
+      lo = probe + 1; st <<= 1;
+    }
     while (lo < hi) {
       int mid = (lo + hi) >> 1;
       if (Z(mid).y - pi0 > p.nearby) hi = mid; else lo = mid + 1;
@@ -383,7 +390,24 @@ ra_analysis_kernel(RaParams p, RaBuffers b, const float *__restrict__ voice, int
     // other — so a round costs ONE barrier (r04; the second copy is the unused .x half of the peak's volume slot Mh + i, or a third int array
     // beside the scan area): these ~log2(intervals) rounds of barriers were 20 % of a configs[3] frame.
     auto JQ = [&](int i) -> int & { return lists_in_z ? reinterpret_cast<int *>(&Z(Mh + i).x)[0] : mark[K + i]; };
-    bool flip = false;
+    // the rounds start from nxt^4 instead of nxt: every peak follows its pointer three more times on its own (dependent LDS reads, but no
+    // barrier between them), peak 0 marks the three starts it passes: two rounds fewer
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = tid + T * q;
+      if (i < K) {
+        int j = JP(i);
+#pragma unroll
+        for (int hop = 0; hop < 3; ++hop) j = (j < K) ? JP(j) : K;
+        JQ(i) = j;
+      }
+    }
+    if (tid == 0) {
+      int j = JP(0);
+      for (int hop = 0; hop < 3 && j < K; ++hop) { MK(j) = 1; j = JP(j); }
+    }
+    __syncthreads();
+    bool flip = true;
     while (true) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
