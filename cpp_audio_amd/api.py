@@ -79,7 +79,7 @@ EXPORTED_SYMBOLS = [
     "ra_create", "ra_destroy", "ra_reset", "ra_set_hip_stream", "ra_process_device", "ra_process_device_async", "ra_join", "ra_process_host",
     "ra_synchronize",
     "ra_feed", "ra_compute", "ra_get_stats", "ra_get_events", "ra_get_frame_pitches", "ra_resynth_notes", "ra_sqmag",
-    "ra_host_alloc", "ra_host_free", "ra_set_profiling", "ra_get_kernel_ms", "ra_get_kernel_launches", "ra_get_stage_timing", "ra_set_clock_stamps", "ra_get_clock_stamps", "ra_render_note",
+    "ra_host_alloc", "ra_host_free", "ra_process_host_pipelined", "ra_set_profiling", "ra_get_kernel_ms", "ra_get_kernel_launches", "ra_get_stage_timing", "ra_set_clock_stamps", "ra_get_clock_stamps", "ra_render_note",
     "ra_carrier_events", "ra_get_carrier", "ra_set_pipeline_serial", "ra_deduce_notes", "ra_deduce_notes_batch",
     "ra_voice_default_config", "ra_voice_program", "ra_voice_expand_note", "ra_voice_create", "ra_voice_destroy", "ra_voice_events", "ra_voice_process_host", "ra_voice_process_device",
     "ra_voice_process_device_async", "ra_voice_set_hip_stream", "ra_voice_synchronize", "ra_voice_get_kernel_ms", "ra_voice_dropped_note_ons",
@@ -125,6 +125,7 @@ def lib():
         L.ra_get_kernel_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
         L.ra_get_kernel_launches.argtypes = [C.c_void_p, C.c_void_p]
         L.ra_get_stage_timing.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+        L.ra_process_host_pipelined.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
         L.ra_host_alloc.argtypes = [C.c_int64]
         L.ra_host_alloc.restype = C.c_void_p
         L.ra_host_free.argtypes = [C.c_void_p]
@@ -191,8 +192,9 @@ class Context:
     def set_hip_stream(self, stream_handle):
         _check(lib().ra_set_hip_stream(self._h, C.c_void_p(stream_handle)))
 
-    def process_host(self, voice, carrier=None, n_frames=None, out=None):
-        """voice/carrier: [n_streams, n] float32 (or None). Returns out [n_streams, n, 2] float32 (`out`: a caller's buffer, e.g. a PinnedArray's)."""
+    def process_host(self, voice, carrier=None, n_frames=None, out=None, chunk_frames=0):
+        """voice/carrier: [n_streams, n] float32 (or None). Returns out [n_streams, n, 2] float32 (`out`: a caller's buffer, e.g. a PinnedArray's).
+        chunk_frames > 0: ra_process_host_pipelined (copies and kernels of consecutive chunks overlap)."""
         a = voice if voice is not None else carrier
         if a is None:
             S, n = self.n_streams, int(n_frames)
@@ -204,7 +206,10 @@ class Context:
         if out is None:
             out = np.empty((S, n, 2), np.float32)
         assert out.shape == (S, n, 2) and out.dtype == np.float32 and out.flags.c_contiguous
-        _check(lib().ra_process_host(self._h, _p(v), _p(c), n, _p(out)))
+        if chunk_frames > 0:
+            _check(lib().ra_process_host_pipelined(self._h, _p(v), _p(c), n, _p(out), int(chunk_frames)))
+        else:
+            _check(lib().ra_process_host(self._h, _p(v), _p(c), n, _p(out)))
         return out
 
     def process_device(self, d_voice, d_carrier, n_frames, d_out, overlap=False):

@@ -110,6 +110,13 @@ struct ra_context {
   // block's start nor at its end, and every entry point returns RA_EINTERNAL until ra_reset
   bool poisoned = false;
   bool pending_join = false; // asynchronous blocks are in flight on the internal streams; the caller's stream has not been made to wait yet
+  // ra_process_host_pipelined: two copy queues, two sets of chunk-sized staging buffers and the events that order copy-in -> block -> copy-out
+  struct HostPipe {
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    float *voice[2] = {nullptr, nullptr}, *carrier[2] = {nullptr, nullptr}, *out[2] = {nullptr, nullptr};
+    int64_t cap = 0;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_out_done[2] = {nullptr, nullptr}, ev_user[2] = {nullptr, nullptr}, ev_pipe[2][6] = {};
+  } hp;
 };
 
 namespace {
@@ -1222,6 +1229,13 @@ void ra_destroy(ra_context *c) {
     for (auto &row : c->ev_chunk) for (auto e : row) if (e) (void)hipEventDestroy(e);
   }
   for (auto &sc : c->scr) for (hipEvent_t e : {sc.ev_track_done, sc.ev_prop_done, sc.ev_render_done, sc.ev_voc_done}) if (e) (void)hipEventDestroy(e);
+  if (c->hp.s_in) {
+    (void)hipStreamDestroy(c->hp.s_in); (void)hipStreamDestroy(c->hp.s_out);
+    for (int q = 0; q < 2; ++q) {
+      (void)hipEventDestroy(c->hp.ev_in[q]); (void)hipEventDestroy(c->hp.ev_out_done[q]); (void)hipEventDestroy(c->hp.ev_user[q]);
+      for (int i = 0; i < 6; ++i) (void)hipEventDestroy(c->hp.ev_pipe[q][i]);
+    }
+  }
   delete c;
 }
 
@@ -1367,6 +1381,70 @@ int ra_process_host(ra_context *c, const float *h_voice, const float *h_carrier,
   r = process_block(c, h_voice ? c->st_voice : nullptr, h_carrier ? c->st_carrier : nullptr, n, c->st_out, nullptr);
   if (r) return r;
   HIP_TRY(hipMemcpyAsync(h_out, c->st_out, S * n * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  return ra_synchronize(c);
+}
+
+// The same block, cut into chunks of `chunk_frames` that are copied in, processed and copied out on three queues: chunk k + 1's input travels
+// and chunk k - 1's output returns while chunk k runs (and, blocks being issued asynchronously, chunk k + 1's analysis overlaps chunk k's render).
+int ra_process_host_pipelined(ra_context *c, const float *h_voice, const float *h_carrier, int64_t n, float *h_out, int64_t chunk) {
+  if (!c) return fail(RA_EINVAL, "null context");
+  if (n < 0 || chunk < 1) return fail(RA_EINVAL, "bad n_frames / chunk_frames");
+  if (n == 0) return RA_OK;
+  if (!h_out) return fail(RA_EINVAL, "null output");
+  if (c->poisoned) return fail(RA_EINTERNAL, "an earlier block failed midway: the streams are in an undefined state until ra_reset");
+  if (c->p.fb_gain != 0.f) return ra_process_host(c, h_voice, h_carrier, n, h_out); // (feedback blocks run in sequential pieces anyway)
+  HIP_TRY(hipSetDevice(c->device));
+  { int jr = join_streams(c); if (jr) return jr; }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  chunk = std::min(chunk, n);
+  ra_context::HostPipe &hp = c->hp;
+  const size_t S = c->p.n_streams;
+  if (!hp.s_in) {
+    HIP_TRY(hipStreamCreateWithFlags(&hp.s_in, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&hp.s_out, hipStreamNonBlocking));
+    for (int q = 0; q < 2; ++q) {
+      HIP_TRY(hipEventCreateWithFlags(&hp.ev_in[q], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&hp.ev_out_done[q], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&hp.ev_user[q], hipEventDisableTiming));
+      for (int i = 0; i < 6; ++i) HIP_TRY(hipEventCreateWithFlags(&hp.ev_pipe[q][i], hipEventDisableTiming));
+    }
+  }
+  if (chunk > hp.cap) {
+    HIP_TRY(hipDeviceSynchronize());
+    for (int q = 0; q < 2; ++q) { dev_free(c, hp.voice[q]); dev_free(c, hp.carrier[q]); dev_free(c, hp.out[q]); }
+    hp.cap = 0;
+    for (int q = 0; q < 2; ++q) {
+      RA_TRY(dev_alloc(c, &hp.voice[q], S * chunk, false));
+      RA_TRY(dev_alloc(c, &hp.carrier[q], S * chunk, false));
+      RA_TRY(dev_alloc(c, &hp.out[q], S * chunk * 2, false));
+    }
+    hp.cap = chunk;
+  }
+  int k = 0;
+  bool used[2] = {false, false};
+  for (int64_t t = 0; t < n; t += chunk, ++k) {
+    const int q = k & 1;
+    const int64_t m = std::min(chunk, n - t);
+    // copy-in: the set's previous chunk must have left it (its output copied out = all of its work done)
+    if (used[q]) HIP_TRY(hipStreamWaitEvent(hp.s_in, hp.ev_out_done[q], 0));
+    if (h_voice) HIP_TRY(hipMemcpy2DAsync(hp.voice[q], (size_t)m * sizeof(float), h_voice + t, (size_t)n * sizeof(float), (size_t)m * sizeof(float), S, hipMemcpyHostToDevice, hp.s_in));
+    if (h_carrier) HIP_TRY(hipMemcpy2DAsync(hp.carrier[q], (size_t)m * sizeof(float), h_carrier + t, (size_t)n * sizeof(float), (size_t)m * sizeof(float), S, hipMemcpyHostToDevice, hp.s_in));
+    HIP_TRY(hipEventRecord(hp.ev_in[q], hp.s_in));
+    HIP_TRY(hipStreamWaitEvent(c->stream, hp.ev_in[q], 0));
+    RA_TRY(process_block(c, h_voice ? hp.voice[q] : nullptr, h_carrier ? hp.carrier[q] : nullptr, m, hp.out[q], nullptr, true));
+    // copy-out: behind everything the block put on the caller's stream and on the internal queues (without making the caller's stream wait)
+    HIP_TRY(hipEventRecord(hp.ev_user[q], c->stream));
+    HIP_TRY(hipStreamWaitEvent(hp.s_out, hp.ev_user[q], 0));
+    if (c->pipe_ready)
+      for (int i = 0; i < 6; ++i) {
+        HIP_TRY(hipEventRecord(hp.ev_pipe[q][i], c->pipe_stream[i]));
+        HIP_TRY(hipStreamWaitEvent(hp.s_out, hp.ev_pipe[q][i], 0));
+      }
+    HIP_TRY(hipMemcpy2DAsync(h_out + 2 * t, (size_t)n * 2 * sizeof(float), hp.out[q], (size_t)m * 2 * sizeof(float), (size_t)m * 2 * sizeof(float), S, hipMemcpyDeviceToHost, hp.s_out));
+    HIP_TRY(hipEventRecord(hp.ev_out_done[q], hp.s_out));
+    used[q] = true;
+  }
+  HIP_TRY(hipStreamSynchronize(hp.s_out));
   return ra_synchronize(c);
 }
 

@@ -211,6 +211,14 @@ int ra_process_device(ra_context *ctx, const float *d_voice, const float *d_carr
 int ra_process_host(ra_context *ctx, const float *h_voice, const float *h_carrier, int64_t n_frames, float *h_out);
 int ra_synchronize(ra_context *ctx);
 /*
+ * ra_process_host for long blocks fed from the host: the block is cut into chunks of chunk_frames (e.g. one second); chunk k + 1's input is
+ * copied in and chunk k - 1's output copied out while chunk k runs — three queues, two sets of chunk-sized device buffers — so that a block
+ * costs max(link, kernels) instead of their sum.  The chunks are ordinary consecutive blocks: results equal ra_process_host's up to the
+ * rounding of a block cut (bit for bit with reference_order = 1).  Worth it from page-locked buffers (ra_host_alloc): pageable copies are
+ * staged by the runtime and do not overlap.  With an output feedback the call is ra_process_host.
+ */
+int ra_process_host_pipelined(ra_context *ctx, const float *h_voice, const float *h_carrier, int64_t n_frames, float *h_out, int64_t chunk_frames);
+/*
  * Page-locked host memory for the buffers handed to ra_process_host (hipHostMalloc / hipHostFree): from pageable memory the runtime stages
  * every copy through its own pinned bounce buffers (~12 GB/s measured on the test box), from these the copies run at the link's rate.  Where the
  * streams come from the host — BASELINE configs[4]: 1000 streams per GPU — the link, not the kernels, paces a block.
