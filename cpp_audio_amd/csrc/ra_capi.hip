@@ -1635,8 +1635,9 @@ int ra_feed(ra_context *c, int32_t stream, const float *h_voice, const float *h_
     sh.in_carrier[stream].resize(sh.in_voice[stream].size(), 0.f);
     sh.carrier_given[stream] = 1;
   }
-  for (int i = 0; i < n; ++i) sh.in_voice[stream].push_back(h_voice ? h_voice[i] : 0.f);
-  if (h_carrier) for (int i = 0; i < n; ++i) sh.in_carrier[stream].push_back(h_carrier[i]);
+  if (h_voice) sh.in_voice[stream].insert(sh.in_voice[stream].end(), h_voice, h_voice + n);
+  else sh.in_voice[stream].insert(sh.in_voice[stream].end(), (size_t)n, 0.f);
+  if (h_carrier) sh.in_carrier[stream].insert(sh.in_carrier[stream].end(), h_carrier, h_carrier + n);
   return RA_OK;
 }
 

@@ -826,14 +826,17 @@ __global__ void __launch_bounds__(384) ra_voc_bank_pipe_kernel(RaParams p, RaBuf
 // an affine map of its state per sample, so a run of samples composes into one affine map (a^len, zero-state response) and the state at
 // every chunk boundary of a tile follows from a prefix scan over the chunks.  A tile is 1024 samples of one stream; lane = a chunk of 16
 // consecutive samples; wave w of the workgroup's eight takes bands w * bpw ... (bpw = ceil(bands / 8)) one after the other.  Per band and
-// stage: (1) the chunk's zero-state response by the recurrence itself from 0, (2) a weighted inclusive scan over the 64 lanes with the
-// constant ratio a^16 (Kogge-Stone with the host's table a^16, a^32, ..., a^512; the tile's carry-in folded into lane 0) gives every
-// chunk its true start state, (3) the recurrence again from that state produces the samples — within a chunk the very operation sequence of
-// the reference's loop; only the chunk's start value differs from the sample-serial run, at rounding level.  The `abs` between the band-pass
-// and the follower, the high-pass `x - lp(x)` and the product with the envelope are elementwise between two scans.  The band sum runs over a
-// lane's bands in band order, then over the eight waves in wave order through LDS.  A block's last, ragged tile takes the same path with
-// per-lane lengths (a general affine scan over (a^len, response) pairs).  480 k samples of a stream are 469 tiles instead of 480 k
-// dependent steps: the pipeline kernel above (bit-identical to the reference's loop; reference_order = 1) needed 30.8 ms per configs[2] step.
+// stage: (1) the chunk's zero-state response by Horner's rule, (2) a weighted inclusive scan over the 64 lanes with the constant ratio
+// P = a^16 — rows of 16 lanes by DPP row shifts, the four row ends chained through scalar registers, P^((lane mod 16) + 1) from a small LDS
+// table; the tile's carry-in folded into lane 0 — gives every chunk its true start state, (3) the recurrence itself from that state, its
+// multiply-add fused, produces the samples.  The `abs` between the band-pass and the follower is a source modifier of the follower's
+// instructions, the high-pass `x - lp(x)` and the product with the envelope are elementwise between two scans.  The band sum runs over a
+// wave's bands in band order (in the wave's own LDS slice), then over the eight waves in wave order.  A block's last, ragged tile takes the
+// same path with per-lane lengths (a general affine scan over (a^len, response) pairs, by ds_bpermute: once per block).  Results equal the
+// sample-serial recurrence to rounding (measured against the CPU restatement: <= 1e-8 RMS on the float output, tests/test_gpu_vocoder_bank.py).
+// 480 k samples of a stream are 469 tiles instead of 480 k dependent steps: the pipeline kernel above (bit-identical to the reference's loop;
+// reference_order = 1) needed 30.8 ms per configs[2] step at 27 % of the issue rate; this one 7.6 ms at 55 %, in 128 VGPRs (two sample arrays;
+// inputs and running sum in LDS) so that the carrier synth's walk (249 VGPRs) still finds room beside it.
 constexpr int SC = 16;              // samples per lane
 constexpr int STILE = 64 * SC;      // samples per tile
 constexpr int SROW = 65;            // LDS row stride in doubles: sample (lane, j) of a tile lives at j * SROW + lane
