@@ -178,7 +178,7 @@ inline bool config_error(const ra_voice_config &c, const char *&why) {
   why = nullptr;
   if (c.sample_rate < 1000) why = "sample_rate is too small";
   else if (c.n_channels < 1 || c.n_channels > 256) why = "n_channels must be in 1..256";
-  else if (c.mode == RA_VOICE_WIND) why = "WIND is not built: its voices read pink-noise buffers of cpp.algorithms, which is absent (DESIGN.md §8)";
+  else if (c.mode == RA_VOICE_WIND) why = "WIND is not built (DESIGN.md section 8 lists what it needs: its generators are in the reference, its order-N Filter and the default state of its unconfigured low-pass are not)";
   else if (c.mode < RA_VOICE_BIRDS || c.mode > RA_VOICE_SWEEP) why = "mode must be RA_VOICE_BIRDS, RA_VOICE_ROBOTS or RA_VOICE_SWEEP";
   else if (c.mode == RA_VOICE_SWEEP && (!(c.low_freq > 0.f) || !(c.high_freq > 0.f))) why = "the sweep's ends must be positive frequencies (LogRamp, audioelement.h:2566-2567)";
   else if (!(c.length_ms > 0.f) || !(c.length_exponent >= 0.f) || c.length_exponent > 7.f) why = "bad length / length exponent";

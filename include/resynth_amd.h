@@ -372,8 +372,9 @@ int ra_sqmag(const float *h_windows, int32_t n_windows, int32_t window_size, int
  * (ra_voice_expand_note shows the result), and every ramp becomes a job of the device kernels (csrc/ra_voice.hip).
  * What the path takes from the absent cpp.algorithms is decided in DESIGN.md §5 (PARITY UNPINNED): MarkovChain restated from its call
  * sites; mersenne<> draws = the declared counter hash (salt 5: the k-th draw after the per-note reseed; salt 3: SWEEP's random pan);
- * itp::interpolate = Penner's easing equations (enum ra_itp: this build's numbering).  WIND (soundengine.h:721-735) is not built: its
- * voices read pink-noise buffers of cpp.algorithms (RA_EINVAL at ra_voice_create).
+ * itp::interpolate = Penner's easing equations (enum ra_itp: this build's numbering).  WIND (soundengine.h:721-735) is not built
+ * (RA_EINVAL at ra_voice_create): its noise generators are in the reference (include/noise.h, source/sound.cpp), but its voices run
+ * cpp.algorithms' order-N Filter, and the first of them is never given a frequency (DESIGN.md section 8 has the list).
  */
 enum { RA_VOICE_BIRDS = 0, RA_VOICE_ROBOTS = 1, RA_VOICE_SWEEP = 2, RA_VOICE_WIND = 3 }; /* SoundEngineMode, soundengine.h:31-40 */
 enum { RA_XFADE_FREQ_NO = 0, RA_XFADE_FREQ_NONTRIVIAL = 1, RA_XFADE_FREQ_ALL = 2 };     /* FreqXfade, soundengine.h:3-11 */
