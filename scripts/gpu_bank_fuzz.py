@@ -69,7 +69,7 @@ def run(n_cfg, seed, verbose=True):
             dropped = 0
             for s in range(S):
                 ev = oracle.carrier_events([(r[0], r[2], r[3], r[4], r[5], r[6]) for r in rows if r[1] == s])
-                ref, car, _, dr = oracle.run_offline_ex(oracle.default_config(**dict(kw, seed=kw["seed"] + s)), x[s], None, ev, want_carrier=True)
+                ref, car, _, dr = oracle.run_offline_ex(oracle.default_config(**{k: v for k, v in dict(kw, seed=kw["seed"] + s).items() if k != "reference_order"}), x[s], None, ev, want_carrier=True)
                 dropped += dr[1]
                 dc = float(np.max(np.abs(cars[s] - car)))
                 if (vols[4] == 0.0 and dc != 0.0) or dc > 1e-11: msg.append(f"s{s}: carrier differs by {dc:.3g}")
