@@ -10,6 +10,7 @@
 // as an M = L/2 point complex FFT in LDS (fp64, like the reference), |X|^2 overwrites the same LDS slots,
 // peaks are compacted in bin order and only the short autotuned pitch list goes back to HBM.
 #include "ra_fft.cuh"
+#include <hip/hip_ext.h>
 #include "ra_math.cuh"
 #include "ra_lane.cuh"
 #include <algorithm>
@@ -727,11 +728,13 @@ void ra_launch_analysis(const RaParams &p, const RaBuffers &b, const float *d_vo
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_analysis_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ra_analysis_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
+  hipEvent_t ea = nullptr, eb = nullptr; // profiling: the launch stamps its own begin and end (RaExtTiming)
+  if (ra_ext_timing) { ea = ra_ext_timing->a; eb = ra_ext_timing->b; ra_ext_timing->used = true; }
   switch (ra_analysis_threads(p)) {
-  case 1024: hipLaunchKernelGGL(ra_analysis_kernel<1024>, grid, dim3(1024), lds, st, p, b, d_voice, t0, n, f_lo, (int)fb0, (int)nfb_total, (int)nfb_chunk); break;
-  case 128: hipLaunchKernelGGL(ra_analysis_kernel<128>, grid, dim3(128), lds, st, p, b, d_voice, t0, n, f_lo, (int)fb0, (int)nfb_total, (int)nfb_chunk); break;
-  case 512: hipLaunchKernelGGL(ra_analysis_kernel<512>, grid, dim3(512), lds, st, p, b, d_voice, t0, n, f_lo, (int)fb0, (int)nfb_total, (int)nfb_chunk); break;
-  default: hipLaunchKernelGGL(ra_analysis_kernel<256>, grid, dim3(256), lds, st, p, b, d_voice, t0, n, f_lo, (int)fb0, (int)nfb_total, (int)nfb_chunk); break;
+  case 1024: hipExtLaunchKernelGGL(ra_analysis_kernel<1024>, grid, dim3(1024), (uint32_t)lds, st, ea, eb, 0, p, b, d_voice, t0, n, f_lo, (int)fb0, (int)nfb_total, (int)nfb_chunk); break;
+  case 128: hipExtLaunchKernelGGL(ra_analysis_kernel<128>, grid, dim3(128), (uint32_t)lds, st, ea, eb, 0, p, b, d_voice, t0, n, f_lo, (int)fb0, (int)nfb_total, (int)nfb_chunk); break;
+  case 512: hipExtLaunchKernelGGL(ra_analysis_kernel<512>, grid, dim3(512), (uint32_t)lds, st, ea, eb, 0, p, b, d_voice, t0, n, f_lo, (int)fb0, (int)nfb_total, (int)nfb_chunk); break;
+  default: hipExtLaunchKernelGGL(ra_analysis_kernel<256>, grid, dim3(256), (uint32_t)lds, st, ea, eb, 0, p, b, d_voice, t0, n, f_lo, (int)fb0, (int)nfb_total, (int)nfb_chunk); break;
   }
 }
 

@@ -21,6 +21,7 @@
 #include <vector>
 
 static thread_local std::string g_last_error;
+thread_local RaExtTiming *ra_ext_timing = nullptr;
 #define RA_TRY(expr) do { if (int rc_ = (expr)) return rc_; } while (0)
 static int fail(int code, const std::string &msg) { g_last_error = msg; return code; }
 
@@ -70,6 +71,7 @@ struct ra_context {
   bool profiling = false;
   struct Timed { int stage; hipEvent_t a, b; };
   std::vector<Timed> timed;          // launches of the calls not yet resolved
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> spare; // recorded event pairs whose launch was timed by hipExtLaunchKernelGGL instead: back to the pool once resolved
   std::vector<hipEvent_t> ev_pool;   // recycled timing events
   double kernel_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // analysis, track, vocoder, propagate, render, history, tracking pre-pass (ST_*)
   int64_t kernel_calls = 0;
@@ -746,6 +748,8 @@ int resolve_timing(ra_context *c) {
     c->ev_pool.push_back(t.b);
   }
   c->timed.clear();
+  for (auto &sp : c->spare) { c->ev_pool.push_back(sp.first); c->ev_pool.push_back(sp.second); } // (recorded before / after launches that have completed by now)
+  c->spare.clear();
   return RA_OK;
 }
 
@@ -759,15 +763,25 @@ int timed_launch(ra_context *c, int stage, hipStream_t st, F &&launch) {
     return RA_OK;
   };
   if (!c->profiling) return checked();
-  hipEvent_t ev[2];
-  for (auto &e : ev) {
+  auto take = [&](hipEvent_t &e) -> int {
     if (c->ev_pool.empty()) { HIP_TRY(hipEventCreate(&e)); }
     else { e = c->ev_pool.back(); c->ev_pool.pop_back(); }
-  }
+    return RA_OK;
+  };
+  hipEvent_t ev[2] = {nullptr, nullptr}, xe[2] = {nullptr, nullptr};
+  for (auto &e : ev) RA_TRY(take(e));
+  // the throughput kernels are timed by the launch itself (RaExtTiming); the pair around the launch stays as the fallback for the launchers
+  // that do not take it (reference-order and diagnostic kernels)
+  const bool ext = stage == ST_ANALYSIS || stage == ST_RENDER;
+  RaExtTiming xt{nullptr, nullptr, false};
+  if (ext) { for (auto &e : xe) RA_TRY(take(e)); xt.a = xe[0]; xt.b = xe[1]; ra_ext_timing = &xt; }
   HIP_TRY(hipEventRecord(ev[0], st));
-  if (int lr = checked()) { c->ev_pool.push_back(ev[0]); c->ev_pool.push_back(ev[1]); return lr; }
+  const int lr = checked();
+  ra_ext_timing = nullptr;
+  if (lr) { for (auto e : ev) c->ev_pool.push_back(e); if (ext) for (auto e : xe) c->ev_pool.push_back(e); return lr; }
   HIP_TRY(hipEventRecord(ev[1], st));
-  c->timed.push_back({stage, ev[0], ev[1]});
+  if (xt.used) { c->timed.push_back({stage, xe[0], xe[1]}); c->spare.push_back({ev[0], ev[1]}); }
+  else { c->timed.push_back({stage, ev[0], ev[1]}); if (ext) for (auto e : xe) c->ev_pool.push_back(e); }
   if (c->timed.size() > 8192) return resolve_timing(c); // bounds the event pool when nobody reads the timers (waits for those launches)
   return RA_OK;
 }
@@ -1221,6 +1235,7 @@ void ra_destroy(ra_context *c) {
   if (c->shim.h_flags) (void)hipHostFree(c->shim.h_flags);
   for (auto &cs : c->car_stage) { if (cs.h) (void)hipHostFree(cs.h); if (cs.done) (void)hipEventDestroy(cs.done); }
   for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+  for (auto &sp : c->spare) { (void)hipEventDestroy(sp.first); (void)hipEventDestroy(sp.second); }
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->pipe_ready) {
     for (int i = 0; i < 6; ++i) { (void)hipStreamSynchronize(c->pipe_stream[i]); (void)hipStreamDestroy(c->pipe_stream[i]); }
@@ -2095,7 +2110,7 @@ struct ra_voice {
   // a channel is free iff no note is on and every ramp of its engine is finished; a note-off while a ramp is busy leaves that ramp
   // unfinished for good (nothing steps the element any more): the channel is lost (isEnvelopeFinished_internal, soundengine.h:470-480)
   struct Chan { bool odd = false, lost = false; int64_t noteid = -1, t_on = 0; int live = -1; std::vector<std::pair<int64_t, int64_t>> busy; /* element steps [k0, k1) */ };
-  struct LiveRamp { rav::Spec spec; int64_t k; int32_t T; int32_t carry; };
+  struct LiveRamp { rav::Spec spec; int64_t k; int32_t T; int32_t carry; int32_t ramp = 0, play = 0; /* which of the engine's three ramps; which spec */ };
   struct Live { int32_t chan; bool done; int64_t t_on, noteid, limit; double fL, fR; int32_t A, R; std::vector<LiveRamp> ramps; };
   struct JobRec { RaVoiceJob j; int32_t end, live, ramp; };
   struct Synth { // one stream: everything a block's host work touches for it (so that streams can be handed to different threads)
@@ -2146,6 +2161,14 @@ struct ra_voice {
   // a block failed after its events had been consumed and channel / live-note state changed (a size limit, a staging or device allocation, a
   // HIP call before the launches): the object is then neither at the block's start nor at its end; every later block returns RA_EINTERNAL
   bool poisoned = false;
+  // ---- WIND (ra_wind.cuh): the pink-noise buffer, the playing ramps' states (a slot per (stream, channel, ramp): a channel is taken again only
+  // when its ramps are finished), the block's jobs, the chunk's scratch ----
+  RaWindParams wp;
+  double *d_pink = nullptr, *d_wfstates = nullptr, *d_wscratch = nullptr;
+  RaWindState *d_wstates = nullptr;
+  RaWindJob *d_wjobs = nullptr;
+  int32_t *d_wstream_begin = nullptr;
+  int64_t wjobs_cap = 0, wsb_cap = 0, wscratch_cap = 0;
 };
 
 namespace {
@@ -2170,6 +2193,27 @@ const VoiceProgram kSweeps[] = {
     {"Sweep 1", 0, 0, 0, 0, RA_ITP_LINEAR, 0.f, 73.f, 5.f, 0.f, 0.f, 0.0109f, 0, 0.f, 0, 0, 0, 0.0009f, 20000.f},
     {"Fullrange", 0, 0, 0, 0, RA_ITP_LINEAR, 0.f, 500.f, 5.f, 0.f, 0.f, 0.0109f, 0, 0.f, 0, 0, 0, 0.000226f, 20000.f}};
 
+// ImplBase::getPrograms for WIND (gen.voice.h:762-806): make_noise_wind(order, width {min, max}, centre {min, max}, seconds per noise sample),
+// make_sine_wind(centre, short-term ratio, seconds long, seconds short), make_mixed_wind = make_noise_wind + the sine at 0.01 (:625-697)
+struct WindProgram { const char *name; int kind; int order; float w0, w1, c0, c1, sec_long, sec_short, short_ratio; }; // kind 0 noise, 1 sine, 2 mixed
+const WindProgram kWinds[] = {
+    {"Medium wind in trees", 0, 1, 0.f, 0.f, 1.f, 8.f, 2.268f, 0, 0},
+    {"Steady wind", 0, 4, 1.3f, 1.3f, 5.2f, 5.5f, 0.09f, 0, 0},
+    {"Strong wind", 0, 4, 3.8f, 3.8f, 1.f, 8.f, 2.268f, 0, 0},
+    {"Vinyl cracks", 0, 89, 3.45f, 5.f, 8.1f, 8.1f, 0.000748f, 0, 0},
+    {"Small animal eating", 0, 61, 0.f, 5.f, 8.1f, 8.1f, 0.000227f, 0, 0},
+    {"Heavy rain in a car", 0, 33, 3.45f, 5.f, 8.1f, 8.1f, 0.000227f, 0, 0},
+    {"Light rain in a car", 0, 89, 3.45f, 5.f, 8.1f, 8.1f, 0.000227f, 0, 0},
+    {"Heavy rain", 0, 13, 5.f, 5.f, 7.8f, 8.f, 0.000283f, 0, 0},
+    {"Light rain", 0, 13, 3.45f, 3.45f, 8.0f, 8.3f, 0.000227f, 0, 0},
+    {"Bubbles", 0, 129, 2.45f, 3.25f, 4.8f, 8.3f, 0.0229f, 0, 0},
+    {"Earth rumbling", 0, 30, 1.95f, 5.f, 2.5f, 3.2f, 0.1589f, 0, 0},
+    {"Sine wind", 1, 1, 0.f, 0.f, 4.6f, 6.8f, 2.268f, 0.0005f, 0.2f},
+    {"Kettle whistle pure", 1, 1, 0.f, 0.f, 7.5f, 7.7f, 0.0005f, 0.0005f, 0.f},
+    {"Kettle whistle mixed", 2, 7, .9f, .9f, 7.5f, 7.7f, 0.00716f, 0, 0}};
+// a parameter as the program array holds it and setupAudioElement reads it back: normalize<>() then denorm<>() (include/normalization.h:8-15)
+float through_params(float v, float m, float M) { const float x = (v - m) / (M - m); return m + x * (M - m); }
+
 void voice_common_defaults(ra_voice_config *c) { // make_common, gen.voice.h:474-531 + include/loudness_init_values.h
   std::memset(c, 0, sizeof(*c));
   c->sample_rate = 48000;
@@ -2179,6 +2223,7 @@ void voice_common_defaults(ra_voice_config *c) { // make_common, gen.voice.h:474
   c->pan = 0.f;
   c->low_freq = 100.f; c->high_freq = 20000.f;
   c->freq_interpolation = RA_ITP_EASE_IN_EXPO;
+  c->order_filters = 1; c->center_octave_min_long_term = 1.f; c->center_octave_max_long_term = 8.f; c->seconds_slow_iter_long_term = 1.f; // make_common :499-505
 }
 int pow2_ceil_log2(int v) { int k = 0; while ((1 << k) < v) ++k; return k; }
 } // namespace
@@ -2200,7 +2245,32 @@ int ra_voice_program(int32_t mode, int32_t index, ra_voice_config *c, const char
   if (mode == RA_VOICE_BIRDS) { tab = kBirds; count = 9; }
   else if (mode == RA_VOICE_ROBOTS) { tab = kRobots; count = 2; }
   else if (mode == RA_VOICE_SWEEP) { tab = kSweeps; count = 2; }
-  else return fail(RA_EINVAL, "ra_voice_program: mode must be RA_VOICE_BIRDS, RA_VOICE_ROBOTS or RA_VOICE_SWEEP (WIND is not built)");
+  else if (mode == RA_VOICE_WIND) {
+    const int n_wind = (int)(sizeof(kWinds) / sizeof(kWinds[0]));
+    if (index < 0 || index >= n_wind) return fail(RA_EINVAL, "ra_voice_program: no such program");
+    const WindProgram &g = kWinds[index];
+    voice_common_defaults(c);
+    c->mode = mode;
+    c->random_pan = 1; c->seed_param = 0;
+    // make_common(0, 0, 6, 0, 0, itp, 0.12f, 93.3f, 2.f, .5f, 0.0499f, ...), gen.voice.h:629,654,679
+    c->markov_start_node = 0; c->markov_pre_tries = 0; c->markov_min_path_length = 6; c->markov_additional_tries = 0;
+    c->interpolation = (g.kind == 1) ? RA_ITP_LINEAR : RA_ITP_PROPORTIONAL_VALUE_DERIVATIVE;
+    c->freq_scatter = 0.12f; c->length_ms = 93.3f; c->length_exponent = 2.f; c->length_exponent_scatter = .5f; c->xfade_length_seconds = 0.0499f;
+    c->order_filters = g.order;
+    c->pink_noise_lp_gain = 0.f; c->pink_noise_br_gain = 0.f;
+    c->pink_noise_bp_gain = (g.kind == 1) ? 0.f : 1.f;
+    c->sine_gain = (g.kind == 0) ? 0.f : (g.kind == 1 ? 0.1f : 0.01f);
+    c->loudness_compensation_amount = (g.kind == 2) ? 0.f : 1.f; // (:664, :690; make_noise_wind keeps make_common's 1)
+    c->bp_octave_width_min = through_params(g.w0, 0.f, 5.f); c->bp_octave_width_max = through_params(g.w1, 0.f, 5.f);
+    c->center_octave_min_long_term = through_params(g.c0, 0.f, 10.f); c->center_octave_max_long_term = through_params(g.c1, 0.f, 10.f);
+    constexpr float max_seconds_slow_iter = 2.268f;
+    c->seconds_slow_iter_long_term = std::log(g.sec_long) / std::log(max_seconds_slow_iter);
+    c->seconds_slow_iter_short_term = (g.kind == 1) ? std::log(g.sec_short) / std::log(max_seconds_slow_iter) : 0.f; // (make_common's 0.f otherwise)
+    c->center_short_term_ratio = g.short_ratio;
+    if (name) *name = g.name;
+    return RA_OK;
+  }
+  else return fail(RA_EINVAL, "ra_voice_program: mode must be a RA_VOICE_* value");
   if (index < 0 || index >= count) return fail(RA_EINVAL, "ra_voice_program: no such program");
   const VoiceProgram &g = tab[index];
   voice_common_defaults(c);
@@ -2248,6 +2318,50 @@ int ra_voice_expand_note(const ra_voice_config *cfg, float frequency, uint64_t s
   if (played && np > played_cap) return fail(RA_EOVERFLOW, "ra_voice_expand_note: play capacity too small");
   return RA_OK;
 }
+
+namespace {
+// setupAudioElement's WIND branches (gen.voice.h:936-978 over SetFilterWidths / ConfigureFilters / SetGains / SetSlowParams, :334-408): what is the same
+// for every ramp of the object; the pink-noise buffer goes to the device, the ramps' state slots are allocated once
+int voice_wind_setup(ra_voice *v) {
+  const ra_voice_config &c = v->cfg;
+  rav::PinkNoise pink;
+  rav::build_pink_noise(c.sample_rate, pink);
+  RaWindParams &w = v->wp;
+  std::memset(&w, 0, sizeof(w));
+  w.order = c.order_filters;
+  w.pink_len = (int)pink.values.size();
+  { // soundBufferWrapperAlgo::setStartAngle(0) (audioelement.h:1544-1557): the index before the first step
+    int index = static_cast<int>(((0. + 1.) * (double)pink.values.size() * 0.5) + 0.5);
+    w.pink_start = std::max(index, 0) - 1;
+  }
+  w.g_bp = c.pink_noise_bp_gain; w.g_br = c.pink_noise_br_gain; w.g_sine = c.sine_gain;
+  w.width_min = std::min(c.bp_octave_width_min, c.bp_octave_width_max); w.width_max = std::max(c.bp_octave_width_min, c.bp_octave_width_max);
+  { // octaveRangeToAngleIncrementsRange (:854-879) -> SoundEngineFreqCtrl::setAngleIncrementsRange (soundengine.h:56-63)
+    constexpr float lowest_f = 10.f;
+    float fm = lowest_f * std::pow(2.f, c.center_octave_min_long_term), fM = lowest_f * std::pow(2.f, c.center_octave_max_long_term);
+    if (fm > fM) std::swap(fm, fM);
+    const float ra_min = rav::inc_of(fm, c.sample_rate), ra_max = rav::inc_of(fM, c.sample_rate);
+    w.log_inc_min = static_cast<float>(std::log(static_cast<double>(ra_min)));
+    w.log_inc_max = static_cast<float>(std::log(static_cast<double>(ra_max)));
+    w.inv_approx_range = 1.f / (2.f * pink.abs_mean);
+  }
+  const float n_slow_steps = rav::wind_slow_steps(c.sample_rate, c.seconds_slow_iter_long_term);
+  const float n_slow_steps_short = rav::wind_slow_steps(c.sample_rate, c.seconds_slow_iter_short_term);
+  w.n_long = static_cast<int>(n_slow_steps);                                   // SetSlowParams::set(ctrl, int, int n_slow_steps_long, float)
+  w.n_band = static_cast<int32_t>(static_cast<unsigned int>(n_slow_steps));    // ConfigureFilters::configure(mix, unsigned int n_slow_steps, ra)
+  w.short_rate = static_cast<float>(static_cast<int>(n_slow_steps_short));     // set_short_term_noise_rate(float) fed the int
+  w.short_amplitude = c.center_short_term_ratio;
+  w.interp_long = c.interpolation;
+  const size_t slots = (size_t)v->n_streams * (size_t)c.n_channels * 3;
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&v->d_pink), sizeof(double) * pink.values.size()));
+  HIP_TRY(hipMemcpy(v->d_pink, pink.values.data(), sizeof(double) * pink.values.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&v->d_wstates), sizeof(RaWindState) * slots));
+  HIP_TRY(hipMemset(v->d_wstates, 0, sizeof(RaWindState) * slots));
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&v->d_wfstates), sizeof(double) * slots * 4 * (size_t)w.order));
+  HIP_TRY(hipMemset(v->d_wfstates, 0, sizeof(double) * slots * 4 * (size_t)w.order));
+  return RA_OK;
+}
+} // namespace
 
 int ra_voice_create(const ra_voice_config *cfg, int32_t n_streams, int32_t device, ra_voice **out) {
   if (!cfg || !out) return fail(RA_EINVAL, "null argument");
@@ -2299,6 +2413,9 @@ int ra_voice_create(const ra_voice_config *cfg, int32_t n_streams, int32_t devic
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&v->pre_stream, hipStreamNonBlocking, prio_greatest);
   }
   if (e != hipSuccess) { ra_voice_destroy(v); return fail(RA_EHIP, std::string("ra_voice_create: ") + hipGetErrorString(e)); }
+  if (c.mode == RA_VOICE_WIND) {
+    if (int r = voice_wind_setup(v)) { ra_voice_destroy(v); return r; }
+  }
   *out = v;
   return RA_OK;
 }
@@ -2319,6 +2436,7 @@ void ra_voice_destroy(ra_voice *v) {
   }
   for (int i = 0; i < 3; ++i) (void)hipFree(v->d_states[i]);
   (void)hipFree(v->d_seg);
+  (void)hipFree(v->d_pink); (void)hipFree(v->d_wfstates); (void)hipFree(v->d_wscratch); (void)hipFree(v->d_wstates); (void)hipFree(v->d_wjobs); (void)hipFree(v->d_wstream_begin);
   if (v->pre_stream) (void)hipStreamDestroy(v->pre_stream);
   for (auto &s : v->staging) { if (s.h) (void)hipHostFree(s.h); if (s.done) (void)hipEventDestroy(s.done); }
   for (auto &t : v->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); (void)hipEventDestroy(t.b2); (void)hipEventDestroy(t.c); }
@@ -2414,7 +2532,7 @@ void voice_stream_events(ra_voice *v, int s, int64_t t0, int64_t t1) {
       }
       for (const rav::Play &pl : note.plays) {
         c.busy.emplace_back(pl.k, pl.T > 0 ? pl.k + pl.T + note.R + 16 : pl.k + 16);
-        if (pl.T > 0 && pl.T + note.R - 1 > 0) l.ramps.push_back({note.specs[pl.spec], pl.k, pl.T, -1});
+        if (pl.T > 0 && pl.T + note.R - 1 > 0) l.ramps.push_back({note.specs[pl.spec], pl.k, pl.T, -1, pl.ramp, pl.spec});
       }
       if (!l.ramps.empty()) { c.live = (int)sy.live.size(); sy.live.push_back(std::move(l)); }
       else c.live = -1;
@@ -2482,6 +2600,19 @@ void voice_stream_jobs(ra_voice *v, int s, int64_t t0, int64_t t1) {
   sy.slots_used = (int32_t)sy.slot_end.size();
 }
 
+// retire the notes that have been rendered to their end (a channel stays taken until its note-off)
+void voice_retire(ra_voice::Synth &sy) {
+  size_t keep = 0;
+  for (size_t li = 0; li < sy.live.size(); ++li) {
+    ra_voice::Live &l = sy.live[li];
+    ra_voice::Chan &c = sy.chans[l.chan];
+    const bool mine = c.live == (int)li;
+    if (!l.done) { if (mine) c.live = (int)keep; if (keep != li) sy.live[keep] = std::move(l); ++keep; }
+    else if (mine) c.live = -1;
+  }
+  sy.live.resize(keep);
+}
+
 // second half, once the streams' offsets are known: the state slots become block-wide indices (and are remembered by the ramps that go
 // on), the jobs go to the staging image sorted by (slot, begin), finished notes are retired
 void voice_stream_emit(ra_voice *v, int s, int g, RaVoiceJob *hj, int32_t *hs, int32_t *ho) {
@@ -2502,16 +2633,31 @@ void voice_stream_emit(ra_voice *v, int s, int g, RaVoiceJob *hj, int32_t *hs, i
     hj[at] = j;
     if (j.state_out >= 0 || (j.begin + j.n - 1) / L > j.begin / L) ho[w++] = at;
   }
-  // retire the notes that have been rendered to their end (a channel stays taken until its note-off)
-  size_t keep = 0;
-  for (size_t li = 0; li < sy.live.size(); ++li) {
-    ra_voice::Live &l = sy.live[li];
-    ra_voice::Chan &c = sy.chans[l.chan];
-    const bool mine = c.live == (int)li;
-    if (!l.done) { if (mine) c.live = (int)keep; if (keep != li) sy.live[keep] = std::move(l); ++keep; }
-    else if (mine) c.live = -1;
+  voice_retire(sy);
+}
+
+// WIND: the stream's jobs as the wind kernels want them (ra_wind.cuh) — the ramp's state slot and the declared start positions of its six iterators
+void voice_wind_emit(ra_voice *v, int s, RaWindJob *hj, int32_t *hs) {
+  ra_voice::Synth &sy = v->synths[s];
+  const int P = v->cfg.n_channels;
+  const uint64_t key = v->cfg.seed + (uint64_t)s;
+  hs[s] = (int32_t)sy.job_base;
+  int64_t at = sy.job_base;
+  for (auto &jr : sy.jobs) {
+    const ra_voice::Live &l = sy.live[jr.live];
+    const ra_voice::LiveRamp &r = l.ramps[jr.ramp];
+    RaWindJob w;
+    std::memset(&w, 0, sizeof(w));
+    w.vol = jr.j.vol; w.fL = jr.j.fL; w.fR = jr.j.fR;
+    w.begin = jr.j.begin; w.n = jr.j.n; w.j0 = jr.j.j0; w.T = jr.j.T; w.A = jr.j.A; w.R = jr.j.R;
+    w.stream = s;
+    w.slot = (int32_t)((((int64_t)s * P + l.chan) * 3) + r.ramp);
+    if (w.j0 == 1)
+      for (int i = 0; i < 6; ++i)
+        for (int k = 0; k < 2; ++k) w.pos[i][k] = rav::wind_position(key, l.noteid, r.play, i, k, (size_t)v->wp.pink_len);
+    hj[at++] = w;
   }
-  sy.live.resize(keep);
+  voice_retire(sy);
 }
 
 void *voice_stage(ra_voice *v, size_t bytes, int &err) { // the pinned staging buffer of this block (waits for the block before last to have drained it)
@@ -2527,6 +2673,69 @@ void *voice_stage(ra_voice *v, size_t bytes, int &err) { // the pinned staging b
   return sg.h;
 }
 
+// A WIND block after the streams' events and jobs: the jobs go up through the staging buffer, then controls -> filter chains -> mix per chunk of
+// the block (ra_wind_launch), everything on the caller's stream.  The chunk length keeps the scratch (up to 8 doubles per job and frame) near 1 GiB.
+int voice_wind_block(ra_voice *v, int64_t n, float *d_out) {
+  const int S = v->n_streams;
+  int64_t n_jobs = 0;
+  for (auto &sy : v->synths) { sy.job_base = n_jobs; n_jobs += (int64_t)sy.jobs.size(); }
+  if (n_jobs > INT32_MAX - 2) return fail(RA_EINVAL, "the block has too many ramps: process it in shorter pieces");
+  const size_t bytes_jobs = sizeof(RaWindJob) * (size_t)n_jobs, bytes_sb = sizeof(int32_t) * (size_t)(S + 1);
+  static_assert(sizeof(RaWindJob) % 8 == 0, "the stream offsets follow the jobs in the staging image");
+  int err = RA_OK;
+  char *h = static_cast<char *>(voice_stage(v, bytes_jobs + bytes_sb + 64, err));
+  if (err) return err;
+  RaWindJob *hj = reinterpret_cast<RaWindJob *>(h);
+  int32_t *hs = reinterpret_cast<int32_t *>(h + bytes_jobs);
+  v->pool->run(S, [v, hj, hs](int s) { voice_wind_emit(v, s, hj, hs); });
+  hs[S] = (int32_t)n_jobs;
+  hipStream_t st = v->stream;
+  RA_TRY(voice_grow(&v->d_wjobs, v->wjobs_cap, n_jobs + 1, v));
+  RA_TRY(voice_grow(&v->d_wstream_begin, v->wsb_cap, (int64_t)S + 1, v));
+  if (n_jobs) HIP_TRY(hipMemcpyAsync(v->d_wjobs, hj, bytes_jobs, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(v->d_wstream_begin, hs, bytes_sb, hipMemcpyHostToDevice, st));
+  {
+    ra_voice::Staging &sg = v->staging[v->stage_parity];
+    HIP_TRY(hipEventRecord(sg.done, st));
+    sg.used = true;
+    v->stage_parity ^= 1;
+  }
+  const RaWindParams &w = v->wp;
+  const int arrays = (w.g_bp != 0.f ? 3 : 0) + (w.g_br != 0.f ? 4 : 0) + (w.g_sine != 0.f ? 1 : 0);
+  int64_t ch = (int64_t(1) << 30) / (std::max<int64_t>(1, n_jobs) * std::max(1, arrays) * 8);
+  ch = std::max<int64_t>(4096, ch);
+  if (const char *e = std::getenv("RA_WIND_CHUNK")) ch = std::max(64, std::atoi(e)); // (tests: a ramp's state across chunk boundaries)
+  ch = std::min<int64_t>(ch, n);
+  RA_TRY(voice_grow(&v->d_wscratch, v->wscratch_cap, std::max<int64_t>(1, n_jobs) * std::max(1, arrays) * ch, v));
+  RaWindScratch sc;
+  std::memset(&sc, 0, sizeof(sc));
+  sc.stride = ch;
+  {
+    double *q = v->d_wscratch;
+    const size_t each = (size_t)std::max<int64_t>(1, n_jobs) * (size_t)ch;
+    auto take = [&] { double *r = q; q += each; return r; };
+    if (w.g_bp != 0.f) { sc.k_bp_lp = take(); sc.k_bp_hp = take(); sc.p_bp = take(); }
+    if (w.g_br != 0.f) { sc.k_br_lp = take(); sc.k_br_hp = take(); sc.p_br_lp = take(); sc.p_br_hp = take(); }
+    if (w.g_sine != 0.f) sc.p_sine = take();
+  }
+  ra_voice::Timed tm{nullptr, nullptr, nullptr, nullptr};
+  if (v->profiling) {
+    hipEvent_t *evs[4] = {&tm.a, &tm.b, &tm.b2, &tm.c};
+    for (auto *pe : evs) {
+      if (!v->ev_pool.empty()) { *pe = v->ev_pool.back(); v->ev_pool.pop_back(); }
+      else HIP_TRY(hipEventCreate(pe));
+    }
+    HIP_TRY(hipEventRecord(tm.a, st)); HIP_TRY(hipEventRecord(tm.b, st)); HIP_TRY(hipEventRecord(tm.b2, st)); // (no pre-pass of its own: all of it counts as the render)
+  }
+  for (int64_t c0 = 0; c0 < n; c0 += ch)
+    ra_wind_launch(v->p, w, v->d_wjobs, (int)n_jobs, v->d_wstream_begin, S, v->d_pink, v->d_wstates, v->d_wfstates, sc, (int)c0, (int)std::min<int64_t>(ch, n - c0), n, d_out, st);
+  HIP_TRY(hipGetLastError());
+  if (v->profiling) { HIP_TRY(hipEventRecord(tm.c, st)); v->timed.push_back(tm); ++v->launches[0]; ++v->launches[1]; }
+  ++v->host_blocks;
+  v->t += n;
+  return RA_OK;
+}
+
 int voice_block_impl(ra_voice *v, int64_t n, float *d_out, bool &started) {
   HIP_TRY(hipSetDevice(v->device));
   if (n > INT32_MAX / 4) return fail(RA_EINVAL, "a block must have fewer than 2^29 frames");
@@ -2538,6 +2747,7 @@ int voice_block_impl(ra_voice *v, int64_t n, float *d_out, bool &started) {
   auto tp = clk();
   v->pool->run(S, [v, t0, t1](int s) { voice_stream_jobs(v, s, t0, t1); });
   lap(tp, 0);
+  if (v->cfg.mode == RA_VOICE_WIND) return voice_wind_block(v, n, d_out);
   int64_t n_jobs = 0, n_states = 0, n_work = 0;
   int g_needed = 1;
   for (auto &sy : v->synths) {

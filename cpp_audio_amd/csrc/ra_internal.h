@@ -347,6 +347,47 @@ void ra_voice_launch_pre(const RaVoiceParams &p, const RaVoiceJob *jobs, const i
 int ra_voice_launch_render(const RaVoiceParams &p, const RaVoiceJob *jobs, const int32_t *slot_begin, const RaVoiceState *st_prev, const RaVoiceState *st_cur, int n_streams,
                            int64_t n, int L, int g_log2, float *d_out, hipStream_t st);
 
+// ---- gen.voice WIND (K10, ra_wind.cuh inside ra_voice.hip) ----
+// A WIND ramp: FreqCtrl_<Mix<low-pass noise, band-pass noise, band-reject noise, sine>, ShortTermNoiseAdderCtrl> (soundengine.h:194-230).
+// Everything a kernel needs that is the same for every ramp of the voice object:
+struct RaWindParams {
+  int order;                     // ORDER_FILTERS: sections per filter (Filter<.., VariableOrder>::setOrder)
+  int pink_len, pink_start;      // the pink-noise buffer's length; the noise wrappers' index before the first step (setStartAngle(0): length / 2 - 1 after rounding)
+  float g_bp, g_br, g_sine;      // Mix gains (the low-pass voice's gain is 0: refused otherwise)
+  float width_min, width_max;    // BandAlgo_::width_range (octaves)
+  float log_inc_min, log_inc_max, inv_approx_range; // SoundEngineFreqCtrl: the same range and abs mean for the outer control and the two bands
+  int n_long, n_band;            // slow steps of the outer control's long-term iterator (int(n)) and of the bands' four iterators (int32(unsigned(n)))
+  float short_rate, short_amplitude; // ShortTermNoiseAdderCtrl::ratio (the short-term step count as a float) and noise_amplitude
+  int interp_long;               // the long-term iterator's interpolation (ra_itp): the engine's; every other iterator is linear
+};
+struct RaWindIter { int32_t pos, slow, n; float prev; }; // a SlowIter over the pink buffer: BufferIter position, slow_it, n_steps, prev
+struct RaWindState {             // what a playing ramp carries from chunk to chunk besides its filters
+  RaWindIter it[6];              // long-term, short-term, band-pass centre / width, band-reject centre / width
+  double theta, y;               // the sine's phase sum (units of pi) and its loudness volume
+  int32_t loud_k, pad;
+};
+struct RaWindJob {               // one playing ramp inside one block
+  double vol, fL, fR;            // the spec's volume; Element::baseVolume * velocity * the note's stereo gains
+  int32_t begin, n, j0;          // block-relative first frame, frames, 1-based index of that first step within the ramp
+  int32_t T, A, R;               // the envelope's three integers
+  int32_t stream, slot;          // slot: where the ramp's state lives ((stream * n_channels + channel) * 3 + ramp)
+  int32_t pos[6][2];             // the declared start positions of the six iterators: initializeForRun's, set_sample_rate's
+};
+struct RaWindScratch {           // per chunk: [job][chunk frames] each; what is not needed is not allocated (nullptr)
+  double *k_bp_lp, *k_bp_hp, *k_br_lp, *k_br_hp; // the one-pole coefficients per sample
+  double *p_bp, *p_br_lp, *p_br_hp, *p_sine;     // the voices' outputs per sample
+  int64_t stride;                // frames per job
+};
+void ra_wind_launch(const RaVoiceParams &vp, const RaWindParams &wp, const RaWindJob *jobs, int n_jobs, const int32_t *stream_begin, int n_streams, const double *pink,
+                    RaWindState *states, double *fstates, const RaWindScratch &sc, int c0, int clen, int64_t n, float *d_out, hipStream_t st);
+
+// Profiling (ra_set_profiling): the two throughput kernels are timed by the launch itself — hipExtLaunchKernelGGL stamps a start and a stop event with
+// the dispatch's own begin and end, the interval rocprofv3 reports — instead of by an event pair around the launch, which also spans the wait of
+// the launch's queue for its turn beside the other queues (measured: the renderer's 1.33 ms read as 1.42).  The host sets the pair before it calls
+// a launcher; a launcher that takes it says so.
+struct RaExtTiming { hipEvent_t a, b; bool used; };
+extern thread_local RaExtTiming *ra_ext_timing;
+
 // launchers (defined next to their kernels)
 void ra_launch_analysis(const RaParams &p, const RaBuffers &b, const float *d_voice, int64_t t0, int64_t n, int64_t f_lo, int64_t fb0, int64_t nfb_chunk,
                         int64_t nfb_total, hipStream_t st);

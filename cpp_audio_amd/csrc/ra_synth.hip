@@ -17,6 +17,7 @@
 // Outputs of a 16-frame tile are transposed through LDS and summed over channels by 32 lanes (one per frame x output),
 // so the cross-lane reduction costs ~2 LDS ops per channel-sample instead of a 64-lane butterfly per sample.
 #include "ra_chan.cuh"
+#include <hip/hip_ext.h>
 #include "ra_lane.cuh"
 #include <algorithm>
 #include <cstdlib>
@@ -824,6 +825,8 @@ void ra_launch_synth_render(const RaParams &p, const RaBuffers &b, const RaSpan 
   const unsigned group = (p.Ppad == 64) ? (unsigned)std::min(std::max(group_want, 1), RA_MAX_CHANNELS / 64) : 1u; // hops per workgroup
   const dim3 grid((unsigned)((sp.nfb + 1 + group - 1) / group), (unsigned)p.n_streams), block((unsigned)p.Ppad, group);
   const size_t lds = (size_t)group * ra_tile_bytes(p.Ppad, ra_hop_mono(p)); // the tiles (+ the gains)
-  if (ra_hop_mono(p)) hipLaunchKernelGGL(ra_synth_render_mono_kernel, grid, block, lds, st, p, b, sp, d_out, d_out_d);
-  else hipLaunchKernelGGL(ra_synth_render_kernel, grid, block, lds, st, p, b, sp, d_out, d_out_d);
+  hipEvent_t ea = nullptr, eb = nullptr; // profiling: the launch stamps its own begin and end (RaExtTiming)
+  if (ra_ext_timing) { ea = ra_ext_timing->a; eb = ra_ext_timing->b; ra_ext_timing->used = true; }
+  if (ra_hop_mono(p)) hipExtLaunchKernelGGL(ra_synth_render_mono_kernel, grid, block, (uint32_t)lds, st, ea, eb, 0, p, b, sp, d_out, d_out_d);
+  else hipExtLaunchKernelGGL(ra_synth_render_kernel, grid, block, (uint32_t)lds, st, ea, eb, 0, p, b, sp, d_out, d_out_d);
 }

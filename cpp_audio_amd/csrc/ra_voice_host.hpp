@@ -6,10 +6,14 @@
 // create_sweep / initialize_* / do_initialize (include/soundengine.h:497-562, 565-719, 883-1003); orchestrate_algos / playNextSpec
 // (:744-803) over the ramps' AHDSREnvelope (include/audioelement.h:702-781, 923-1084).
 // cpp.algorithms' MarkovChain, mersenne<> and itp:: are absent: the decisions of DESIGN.md §5 (declared, parity unpinned).
+// WIND adds the pink-noise sound buffer its voices and controls read (include/noise.h:82-165, source/sound.cpp:102-132,156-168) and the start
+// positions of a ramp's six iterators (include/sound.h:196-200), both over declared draws.
 #pragma once
 #include "../../include/resynth_amd.h"
 
 #include <algorithm>
+#include <cfloat>
+#include <climits>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -133,6 +137,9 @@ struct Builder {
         const float fr = drawn_frames(2.f * length);
         tone(inc_of(f2, sr), inc_of(f1, sr), fr, std::min(vol2, vol1), true);
       }
+    } else if (mode == RA_VOICE_WIND) { // create_wind :721-735: node 0's lambda takes a spec whichever way the chain moves; the spec's control plays for
+      // INT_MAX / 2 samples (ShortTermNoiseAdderCtrl::get_duration_in_samples, :151-154), its long-term iterator takes the engine's interpolation
+      if (node == 0) { if (Spec *s = next_spec()) { s->dur = double(INT_MAX / 2); s->interp = interp; } }
     } else { // create_sweep :697-719
       if (node == 0 && !enter) {
         const float fr = drawn_frames(length);
@@ -142,11 +149,16 @@ struct Builder {
   }
 };
 
+// float n_slow_steps = sample_rate * std::pow(max_seconds_slow_iter, denorm<SECONDS_SLOW_ITER_*>()), gen.voice.h:623,964-965
+inline float wind_slow_steps(int sr, float param) { constexpr float max_seconds_slow_iter = 2.268f; return sr * std::pow(max_seconds_slow_iter, param); }
+
 struct Edge { int from, to; float p; };
 inline const Edge *edges_of(int mode, int &n) {
   static const Edge birds[] = {{0, 1, 0.5f}, {1, 0, 0.015f}, {0, 2, 0.5f}, {2, 0, 0.015f}, {2, 1, 0.885f}};
   static const Edge robot[] = {{0, 1, 1.f}, {1, 2, 0.2f}, {2, 1, 0.1f}, {1, 3, 0.2f}, {3, 1, 1.f}};
   static const Edge sweep[] = {{0, 1, 1.f}};
+  static const Edge wind[] = {{0, 1, 1.f}, {1, 0, 1.f}};
+  if (mode == RA_VOICE_WIND) { n = 2; return wind; }
   if (mode == RA_VOICE_BIRDS) { n = 5; return birds; }
   if (mode == RA_VOICE_ROBOTS) { n = 5; return robot; }
   n = 1;
@@ -178,8 +190,7 @@ inline bool config_error(const ra_voice_config &c, const char *&why) {
   why = nullptr;
   if (c.sample_rate < 1000) why = "sample_rate is too small";
   else if (c.n_channels < 1 || c.n_channels > 256) why = "n_channels must be in 1..256";
-  else if (c.mode == RA_VOICE_WIND) why = "WIND is not built (DESIGN.md section 8 lists what it needs: its generators are in the reference, its order-N Filter and the default state of its unconfigured low-pass are not)";
-  else if (c.mode < RA_VOICE_BIRDS || c.mode > RA_VOICE_SWEEP) why = "mode must be RA_VOICE_BIRDS, RA_VOICE_ROBOTS or RA_VOICE_SWEEP";
+  else if (c.mode < RA_VOICE_BIRDS || c.mode > RA_VOICE_WIND) why = "mode must be a RA_VOICE_* value";
   else if (c.mode == RA_VOICE_SWEEP && (!(c.low_freq > 0.f) || !(c.high_freq > 0.f))) why = "the sweep's ends must be positive frequencies (LogRamp, audioelement.h:2566-2567)";
   else if (!(c.length_ms > 0.f) || !(c.length_exponent >= 0.f) || c.length_exponent > 7.f) why = "bad length / length exponent";
   else if (ms_to_frames(c.length_ms, c.sample_rate) <= 0) why = "length is too small (soundengine.h:966-970)";
@@ -203,6 +214,21 @@ inline bool config_error(const ra_voice_config &c, const char *&why) {
     else if (c.mode == RA_VOICE_BIRDS && (c.freq_interpolation < 0 || c.freq_interpolation >= RA_ITP_END)) why = "freq_interpolation must be a ra_itp value";
     else if (c.mode == RA_VOICE_BIRDS && c.xfade_freq != RA_XFADE_FREQ_NO && int(c.freq_transition_seconds * c.sample_rate) < 1)
       why = "a frequency transition needs a length of at least one frame (LogRamp::setup, audioelement.h:2518)";
+    else if (c.mode == RA_VOICE_WIND) {
+      if (c.pink_noise_lp_gain != 0.f)
+        why = "pink_noise_lp_gain must be 0: the reference never sets the frequency of that voice's filter (audioelement.h:2079-2086), its output is undefined";
+      else if (c.markov_start_node > 1) why = "WIND's chain has two nodes: markov_start_node must be 0 or 1";
+      else if (!(c.pink_noise_bp_gain >= 0.f && c.pink_noise_bp_gain <= 1.f) || !(c.pink_noise_br_gain >= 0.f && c.pink_noise_br_gain <= 1.f)) why = "the noise gains must be in 0..1";
+      else if (!(c.sine_gain >= 0.f && c.sine_gain <= 1.f)) why = "sine_gain must be in 0..1";
+      else if (c.order_filters < 1 || c.order_filters > 258) why = "order_filters must be in 1..258";
+      else if (!(c.bp_octave_width_min >= 0.f && c.bp_octave_width_min <= 5.f) || !(c.bp_octave_width_max >= 0.f && c.bp_octave_width_max <= 5.f)) why = "the band widths must be in 0..5 octaves";
+      else if (!(c.center_octave_min_long_term >= 0.f && c.center_octave_min_long_term <= 10.f) || !(c.center_octave_max_long_term >= 0.f && c.center_octave_max_long_term <= 10.f))
+        why = "the centre octaves must be in 0..10";
+      else if (!(c.center_short_term_ratio >= 0.f && c.center_short_term_ratio <= 1.f)) why = "center_short_term_ratio must be in 0..1";
+      else if (!(wind_slow_steps(c.sample_rate, c.seconds_slow_iter_long_term) >= 1.f) || !(wind_slow_steps(c.sample_rate, c.seconds_slow_iter_long_term) < 1e9f))
+        why = "seconds_slow_iter_long_term: a slow iterator needs at least one step per noise sample (SlowIter, audioelement.h:2862-2877)";
+      else if (!(wind_slow_steps(c.sample_rate, c.seconds_slow_iter_short_term) >= 0.f) || !(wind_slow_steps(c.sample_rate, c.seconds_slow_iter_short_term) < 1e9f)) why = "bad seconds_slow_iter_short_term";
+    }
   }
   return why != nullptr;
 }
@@ -277,13 +303,83 @@ inline void expand_note(const ra_voice_config &c, float frequency, uint64_t stre
     int ramp = 2;
     while (free_at[ramp] > k) --ramp; // get_ramps: the last finished ramp wins (:277-296)
     const Spec &s = out.specs[i];
-    const int T = std::max(int(.5f + s.dur) - xf, 0);
+    // (WIND: .5f + an int — a float sum, soundengine.h:797-798 over :151-154)
+    const int T = (c.mode == RA_VOICE_WIND) ? std::max(int(.5f + float(INT_MAX / 2)) - xf, 0) : std::max(int(.5f + s.dur) - xf, 0);
     out.plays.push_back(Play{k, ramp, i, T});
     free_at[ramp] = (T > 0) ? k + T + out.R + 17 : k + 17;
     // the release is seen T steps later (countStepsToRelease() == 0), then the pause if one follows; a skipped ramp is never seen pressed
     due = (T > 0) ? k + T + ((s.silence && pause > 0) ? pause : 0) : k + 1;
   }
   out.done_step = std::max(out.done_step, std::max(free_at[0], std::max(free_at[1], free_at[2])) - 1);
+}
+
+// ---- WIND: the pink-noise sound buffer (getPinkNoise, source/sound.cpp:7-10) --------------------------------------------------------------
+// soundBuffer<double>(soundId{sr, PINK_NOISE, .05f}): int(sr / .05f) frames (sound.functions.h:45-50) of the Voss-McCartney generator
+// (GaussianPinkNoiseAlgo, include/noise.h:82-165: relevantBits(sr / 20) rows of white noise, row i redrawn every 2^i samples and linearly
+// interpolated in between, the sample = their mean), the buffer's last tenth cross-faded (sin / cos gains) into samples the same generator
+// produced BEFORE the buffer's own (generate_with_smooth_transition, sound.cpp:102-132), then scaled to a peak just below 1
+// (normalize_audio, include/sound.h:96-118).  The generator's white draws: draw k = Box-Muller of the counter hash of ("pinknois", k), salt 9.
+struct PinkNoise {
+  std::vector<double> values;
+  float abs_mean = 0.f; // getPinkNoiseAbsMean (sound.cpp:22-43)
+};
+inline float pink_draw(uint64_t k) {
+  const uint64_t h = mix64(0x70696e6b6e6f6973ull ^ mix64(k * 2 + 9));
+  const double u1 = (double(h >> 40) + 1.0) * (1.0 / 16777216.0), u2 = double((h >> 16) & 0xffffffull) * (1.0 / 16777216.0);
+  return float(std::sqrt(-2.0 * std::log(u1)) * std::cos(2.0 * M_PI * u2));
+}
+inline void build_pink_noise(int sr, PinkNoise &out) {
+  int rows = 0;
+  for (unsigned v = unsigned(sr / (10.f * 2.f)); v; v >>= 1) ++rows; // relevantBits
+  struct Row { float value = 0.f, prev = 0.f; int at = 0; };
+  std::vector<Row> row((size_t)rows);
+  uint64_t draws = 0;
+  unsigned counter = 0;
+  auto redraw = [&](int i) { Row &r = row[(size_t)i]; r.at = int(counter); r.prev = r.value; r.value = pink_draw(draws++); };
+  auto redraw_by_counter = [&] { // the row whose period divides the counter: 1 + count_trailing_zeroes, the last row for 0 and beyond
+    unsigned i = counter ? 1u + unsigned(__builtin_ctz(counter)) : 33u;
+    redraw(int(std::min<unsigned>(i, unsigned(rows - 1))));
+  };
+  for (int i = rows - 1; i >= 1; --i) { counter = (1u << (rows - 2)) - (1u << (i - 1)); redraw_by_counter(); } // the constructor staggers the rows
+  auto next = [&] {
+    ++counter;
+    redraw(0);
+    redraw_by_counter();
+    float sum = 0.f;
+    for (int i = 0; i < rows; ++i) {
+      const Row &r = row[(size_t)i];
+      const float w = (1 + int(counter) - r.at) / float(1 << i);
+      sum += w * r.value + (1.f - w) * r.prev;
+    }
+    return sum / size_t(rows);
+  };
+  const int period = std::max(1, int(float(sr) / .05f));
+  const int fade = std::min(10 + period / 10, period);
+  std::vector<double> before((size_t)fade);
+  for (double &v : before) v = next();
+  out.values.resize((size_t)period);
+  for (double &v : out.values) v = next();
+  for (int i = 0; i < fade; ++i) {
+    const float part = (i + 1) / float(fade + 1);
+    const float angle = part * float(M_PI_2);
+    const float g_before = float(std::sin(double(angle))), g_own = float(std::cos(double(angle)));
+    double &v = out.values[out.values.size() - (size_t)fade + (size_t)i];
+    v = g_before * before[(size_t)i] + g_own * v;
+  }
+  float lo = float(out.values[0]), hi = lo;
+  for (double v : out.values) { lo = std::min(lo, float(v)); hi = std::max(hi, float(v)); }
+  const float scale = (1.f - FLT_EPSILON) / std::max(-lo, hi);
+  double sum = 0;
+  for (double &v : out.values) { v *= scale; sum += std::abs(v); }
+  out.abs_mean = float(sum / double(out.values.size()));
+}
+// BufferIter::initializeForRun's start position (include/sound.h:196-200) as declared: the counter hash of what the draw is for — the
+// stream's key, the note, which spec is being played, which of the ramp's six iterators, initializeForRun (0) or set_sample_rate (1); salt 11
+inline int32_t wind_position(uint64_t stream_seed, int64_t noteid, int play, int iter, int which, size_t size) {
+  const uint64_t id = ((uint64_t(noteid) * 64 + uint64_t(play)) * 8 + uint64_t(iter)) * 2 + uint64_t(which);
+  const uint64_t h = mix64(stream_seed ^ mix64(id * 2 + 11));
+  const double u = double(h >> 11) * (1.0 / 9007199254740992.0);
+  return int32_t(u * double(float(size - 1)));
 }
 
 } // namespace rav

@@ -362,19 +362,22 @@ int ra_sqmag(const float *h_windows, int32_t n_windows, int32_t window_size, int
              int32_t *fft_length);
 
 /*
- * ---- gen.voice: the SWEEP, BIRDS and ROBOTS voices ---------------------------------------------------------------
+ * ---- gen.voice: the SWEEP, BIRDS, ROBOTS and WIND voices ----------------------------------------------------------
  * voice::Impl_<..., MODE, ...> (include/gen.voice.h:1087-1190): the same ImplCRTP compute / onEvent boundary as the sine bank, the
  * element being VolumeAdjusted<SoundEngine<MODE, 2, ...>> (include/soundengine.h:240-1127).  A context of its own: the voice is driven
  * by note events, not by the analysis.  Parameters are the program's, de-normalised (gen.voice.h:55-208,474-529,533-621).
- * At a note-on the engine's Markov chain (create_birds :565-595, create_robot :597-695, create_sweep :697-719; do_initialize :963-1003)
- * writes up to 30 ramp specs; orchestrate_algos / playNextSpec (:744-803) then play them one after the other on the engine's three
- * cross-fading ramps.  Here the chain and the orchestration — integer and PRNG work — run on the host at the note-on
- * (ra_voice_expand_note shows the result), and every ramp becomes a job of the device kernels (csrc/ra_voice.hip).
+ * At a note-on the engine's Markov chain (create_birds :565-595, create_robot :597-695, create_sweep :697-719, create_wind :721-735;
+ * do_initialize :963-1003) writes up to 30 ramp specs; orchestrate_algos / playNextSpec (:744-803) then play them one after the other on
+ * the engine's three cross-fading ramps.  Here the chain and the orchestration — integer and PRNG work — run on the host at the note-on
+ * (ra_voice_expand_note shows the result), and every ramp becomes a job of the device kernels (csrc/ra_voice.hip, csrc/ra_wind.cuh).
  * What the path takes from the absent cpp.algorithms is decided in DESIGN.md §5 (PARITY UNPINNED): MarkovChain restated from its call
- * sites; mersenne<> draws = the declared counter hash (salt 5: the k-th draw after the per-note reseed; salt 3: SWEEP's random pan);
- * itp::interpolate = Penner's easing equations (enum ra_itp: this build's numbering).  WIND (soundengine.h:721-735) is not built
- * (RA_EINVAL at ra_voice_create): its noise generators are in the reference (include/noise.h, source/sound.cpp), but its voices run
- * cpp.algorithms' order-N Filter, and the first of them is never given a frequency (DESIGN.md section 8 has the list).
+ * sites; mersenne<> draws = the declared counter hash (salt 5: the k-th draw after the per-note reseed; salt 3: SWEEP's random pan;
+ * salt 9: the pink-noise generator's white draws; salt 11: the start positions of a WIND ramp's iterators);
+ * itp::interpolate = Penner's easing equations (enum ra_itp: this build's numbering).
+ * WIND (soundengine.h:194-230,721-735): a ramp mixes three filtered pink-noise voices and the sine; its generators (include/noise.h,
+ * source/sound.cpp) and controls are the reference's, its order-n Filter is n one-poles in series and its band-pass' compensation is
+ * expt<VariableOrder>(.) = 1 (decided).  The Mix's first voice — a low-pass whose frequency nothing ever sets — is
+ * undefined in the reference: pink_noise_lp_gain must be 0 (as in every program of the reference), else RA_EINVAL.
  */
 enum { RA_VOICE_BIRDS = 0, RA_VOICE_ROBOTS = 1, RA_VOICE_SWEEP = 2, RA_VOICE_WIND = 3 }; /* SoundEngineMode, soundengine.h:31-40 */
 enum { RA_XFADE_FREQ_NO = 0, RA_XFADE_FREQ_NONTRIVIAL = 1, RA_XFADE_FREQ_ALL = 2 };     /* FreqXfade, soundengine.h:3-11 */
@@ -416,6 +419,15 @@ typedef struct ra_voice_config {
   float freq_transition_seconds; /* FREQ_TRANSITION_LENGTH (BIRDS; 0 .. 0.5) */
   int32_t freq_interpolation;    /* FREQ_TRANSITION_INTERPOLATION (BIRDS; ra_itp) */
   int32_t seed_param;            /* SEED (0 .. 257): 0 = the next of 1 .. 257 per note-on of a stream, else this seed for every note */
+  /* ---- WIND (gen.voice.h:142-175) ---- */
+  float pink_noise_lp_gain;      /* PINK_NOISE_LP_GAIN: must be 0 (the voice is undefined in the reference, see above) */
+  float pink_noise_bp_gain;      /* PINK_NOISE_BP_GAIN (0 .. 1): Mix gain of the band-passed pink noise */
+  float pink_noise_br_gain;      /* PINK_NOISE_BR_GAIN (0 .. 1): of the band-rejected pink noise */
+  float bp_octave_width_min, bp_octave_width_max;                 /* PINK_NOISE_BP_OCTAVE_WIDTH_MIN / MAX (0 .. 5): the bands' half width, octaves */
+  float center_octave_min_long_term, center_octave_max_long_term; /* CENTER_OCTAVE_MIN / MAX_LONG_TERM (0 .. 10): centres range over 10 Hz * 2^value */
+  float center_short_term_ratio; /* CENTER_SHORT_TERM_RATIO (0 .. 1): octaves the short-term noise moves the sine by */
+  float seconds_slow_iter_short_term, seconds_slow_iter_long_term; /* SECONDS_SLOW_ITER_*: the parameter x — a slow iterator takes sample_rate * 2.268^x steps per noise sample */
+  int32_t order_filters;         /* ORDER_FILTERS (1 .. 258) */
 } ra_voice_config;
 typedef struct ra_voice_event {
   int64_t sample;    /* frame of Impl_::doProcessing at which the event reaches onEvent (gen.voice.h:1159-1165) */
@@ -427,8 +439,8 @@ typedef struct ra_voice_event {
 } ra_voice_event;
 typedef struct ra_voice ra_voice;
 int ra_voice_default_config(ra_voice_config *cfg); /* the "Sweep 1" program (gen.voice.h:752-754) with its sweep ends at 100 Hz / 20 kHz */
-/* the reference's own programs (ImplBase::getPrograms, gen.voice.h:700-761) with make_common's defaults (:474-531): mode RA_VOICE_BIRDS
- * index 0 .. 8, RA_VOICE_ROBOTS 0 .. 1, RA_VOICE_SWEEP 0 .. 1; returns RA_EINVAL beyond.  `name` (may be NULL) receives the program's name. */
+/* the reference's own programs (ImplBase::getPrograms, gen.voice.h:700-810) with make_common's defaults (:474-531): mode RA_VOICE_BIRDS
+ * index 0 .. 8, RA_VOICE_ROBOTS 0 .. 1, RA_VOICE_SWEEP 0 .. 1, RA_VOICE_WIND 0 .. 14; returns RA_EINVAL beyond.  `name` (may be NULL) receives the program's name. */
 int ra_voice_program(int32_t mode, int32_t index, ra_voice_config *cfg, const char **name);
 int ra_voice_create(const ra_voice_config *cfg, int32_t n_streams, int32_t device, ra_voice **out);
 void ra_voice_destroy(ra_voice *v);

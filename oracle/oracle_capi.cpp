@@ -44,6 +44,18 @@ int64_t ora_white_noise(int32_t sample_rate, double *out, int64_t cap) {
   for (int64_t i = 0; i < cap && i < static_cast<int64_t>(b.size()); ++i) out[i] = b[i];
   return static_cast<int64_t>(b.size());
 }
+// the pink-noise sound buffer of gen.voice's WIND (oracle_wind.hpp): the same, and its abs mean
+int64_t ora_pink_noise(int32_t sample_rate, double *out, int64_t cap, float *abs_mean) {
+  auto const &b = getPinkNoise(sample_rate);
+  for (int64_t i = 0; i < cap && i < static_cast<int64_t>(b.values.size()); ++i) out[i] = b.values[static_cast<size_t>(i)];
+  if (abs_mean) *abs_mean = b.abs_mean;
+  return static_cast<int64_t>(b.values.size());
+}
+// one playNextSpec's start position of one of a WIND ramp's six iterators (oracle_wind.hpp: the declared draws)
+int32_t ora_wind_start_position(uint64_t key, int64_t noteid, int32_t play, int32_t iter, int32_t which, int64_t size) {
+  WindDrawCtx c; c.key = key; c.noteid = noteid; c.play = play;
+  return wind_start_position(c, iter, which, static_cast<size_t>(size));
+}
 void ora_stereo(double pan, double *l, double *r) { auto g = stereo(pan); *l = g.gains[0]; *r = g.gains[1]; }
 float ora_hash_uniform_pm1(uint64_t seed, uint64_t noteid, uint64_t salt) { return hash_uniform_pm1(seed, noteid, salt); }
 
@@ -226,6 +238,7 @@ int64_t ora_resynth_notes(const int32_t *start, const int32_t *end, const double
 // out [n_frames][2] float.  Returns the number of note-ons dropped.
 int32_t ora_voice_run(const ora_voice_params *p, const int64_t *ev_sample, const int32_t *ev_type, const int64_t *ev_noteid, const float *ev_freq,
                       const float *ev_vel, int64_t n_ev, int64_t n_frames, float *out) {
+  if (p->mode == VOICE_WIND && (p->pink_noise_lp_gain != 0.f || p->order_filters < 1)) return -1; // the low-pass voice's output is undefined in the reference (oracle_wind.hpp)
   Stepper stepper;
   VoiceSynth synth(p->n_channels);
   synth.phase_policy = 1; // DefaultStartPhase::Zero

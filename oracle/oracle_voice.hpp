@@ -1,5 +1,5 @@
 /*
- * TEST INFRASTRUCTURE — CPU oracle, part 6: gen.voice — the SWEEP, BIRDS and ROBOTS sound engines.
+ * TEST INFRASTRUCTURE — CPU oracle, part 6: gen.voice — the SWEEP, BIRDS, ROBOTS and WIND sound engines (WIND's own parts: oracle_wind.hpp).
  *
  * voice::Impl_<..., MODE, ...> (include/gen.voice.h:1087-1190) = ImplCRTP (include/gen.crtp.h, SynchronizePhase::No,
  * DefaultStartPhase::Zero) over VolumeAdjusted<SoundEngine<MODE, 2, ...>> (include/soundengine.h:240-1127), whose three "ramps" are
@@ -7,7 +7,7 @@
  * (soundengine.h:175-180,205-211,246-258; audioelement.h:1784-1880 Mix, :1275-1317 LoudnessVolumeAdjusted, :2464-2572 LogRamp).
  * The engine is restated as it is written: per sample, three ramp objects, a list of up to 30 ramp specs filled by a Markov chain at
  * note-on (create_birds :565-595, create_robot :597-695, create_sweep :697-719, do_initialize :963-1003) and played one after the other
- * by orchestrate_algos / playNextSpec (:744-803).  WIND (:721-735) is not restated: its voices read pink-noise buffers of cpp.algorithms.
+ * by orchestrate_algos / playNextSpec (:744-803).  WIND (:721-735): the same engine over another Mix and another control, oracle_wind.hpp.
  *
  * What this path takes from the absent cpp.algorithms — PARITY UNPINNED, decided here and in DESIGN.md §5:
  *   - MarkovChain: its contract is visible at the call sites — `emplace(lambda)` makes a node, the lambda is called with
@@ -34,10 +34,11 @@
  */
 #pragma once
 #include "oracle_synth.hpp"
+#include "oracle_wind.hpp"
 
 namespace ora {
 
-enum VoiceMode : int32_t { VOICE_BIRDS = 0, VOICE_ROBOTS = 1, VOICE_SWEEP = 2 }; // SoundEngineMode, soundengine.h:31-40
+enum VoiceMode : int32_t { VOICE_BIRDS = 0, VOICE_ROBOTS = 1, VOICE_SWEEP = 2, VOICE_WIND = 3 }; // SoundEngineMode, soundengine.h:31-40
 enum VoiceXfade : int32_t { XFADE_NO = 0, XFADE_NONTRIVIAL = 1, XFADE_ALL = 2 }; // FreqXfade, soundengine.h:3-11
 enum VoiceItp : int32_t {
   ITP_LINEAR = 0, ITP_PROPORTIONAL_VALUE_DERIVATIVE = 1,
@@ -75,6 +76,13 @@ struct ora_voice_params { // a program's parameters, de-normalised (gen.voice.h:
   float freq_transition_seconds;// FREQ_TRANSITION_LENGTH (BIRDS)
   int32_t freq_interpolation;   // FREQ_TRANSITION_INTERPOLATION (BIRDS)
   int32_t seed_param;           // SEED: 0 = another seed per note (1 .. 257, cycling), else fixed
+  // ---- WIND (gen.voice.h:142-175) ----
+  float pink_noise_lp_gain, pink_noise_bp_gain, pink_noise_br_gain; // PINK_NOISE_LP / BP / BR_GAIN
+  float bp_octave_width_min, bp_octave_width_max;                   // PINK_NOISE_BP_OCTAVE_WIDTH_MIN / MAX
+  float center_octave_min_long_term, center_octave_max_long_term;   // CENTER_OCTAVE_MIN / MAX_LONG_TERM: 10 Hz * 2^value
+  float center_short_term_ratio;                                    // CENTER_SHORT_TERM_RATIO
+  float seconds_slow_iter_short_term, seconds_slow_iter_long_term;  // SECONDS_SLOW_ITER_*: the parameter x of sample_rate * 2.268^x steps
+  int32_t order_filters;                                            // ORDER_FILTERS (1 .. 258)
 };
 
 namespace loudness {
@@ -219,6 +227,11 @@ struct VoiceRamp {
   double finit = 0;
   OnePoleLowPass filter;
   StereoGain gain_{{0, 0}};
+  // WIND: the control is a ShortTermNoiseAdderCtrl, the Mix has three noise voices before the sine (gains: lp, bp, br; gain0 stays the sine's)
+  bool wind = false;
+  WindMainCtrl wctrl;
+  WindVoices wv;
+  float gain_lp = 0.f, gain_bp = 0.f, gain_br = 0.f;
 
   double mixAngleIncrements() const { // Mix::angleIncrements :1856-1865
     double minAngle = 0;
@@ -228,19 +241,21 @@ struct VoiceRamp {
   double angleIncrements() const { // FreqCtrl_::angleIncrements :3117-3124
     double const ai = mixAngleIncrements();
     if (ai) return ai;
-    return ctrl.getAngleIncrementFrom();
+    return wind ? static_cast<double>(wctrl.getAngleIncrementFrom()) : ctrl.getAngleIncrementFrom();
   }
   void forgetPastSignals() { // StereoPanned -> BaseVolumeAdjusted -> Enveloped -> FreqCtrl_ (LogRamp: nothing) -> Mix -> LoudnessVolumeAdjusted
     env.forgetPastSignals();
+    if (wind) { wctrl.forgetPastSignals(); wv.forgetPastSignals(); }
     l_volume.reset(); l_target.reset();
     volume.reset(); volume_target.reset();
   }
   void step() {
     env.step();
-    double const inc = ctrl.step();
+    double const inc = wind ? static_cast<double>(wctrl.step()) : ctrl.step();
     // LoudnessVolumeAdjusted::setAngleIncrements :1291-1298 (angle_increment_to_freq, sound.functions.h:64-68, narrowed to the float parameter)
     l_target = loudness::equal_loudness_volume_from_freq(static_cast<float>(inc * 0.5 * sample_rate), low_index, log_ratio, loudness_level);
     sine.setAngleIncrements(inc);
+    if (wind) wv.step(); // Mix::step: the voices in order (the noise wrappers ignore setAngleIncrements, the bands hand it to their own, empty, control)
     { // BaseVolumeAdjusted::step of the loudness adjustment :1195-1216
       sine.step();
       if (!l_volume) {
@@ -269,6 +284,11 @@ struct VoiceRamp {
   }
   double mixImag() const { // Mix::imag :1867-1873
     double sum = 0.f;
+    if (wind) {
+      // gain_lp * LowPassAlgo<PinkNoiseAlgo>::imag(): 0 * (the output of a filter nobody configured, taken as finite) — a non-zero gain is refused at setup
+      sum += gain_bp * wv.bp.imag();
+      sum += gain_br * wv.br.imag();
+    }
     sum += gain0 * (*l_volume * sine.imag());
     return sum;
   }
@@ -293,13 +313,14 @@ struct VoiceElement {
   float state_freq = 0, state_factor = 0;
   float freq1_robot = 0, freq2_robot = 0, vol1 = 1.f, vol2 = 1.f;
   VoiceRng *rng = nullptr;          // mersenne<SEEDED::Yes>(): one engine per synth here
+  WindDrawCtx wind_ctx;             // WIND: what BufferIter's start positions are drawn for (oracle_wind.hpp)
   std::unique_ptr<MarkovChain> markov;
   // setupAudioElement's arguments to initialize_*, handed over by the initializer (the reference passes them in one call)
   float low_freq = 0, high_freq = 0;
   int start_node = 0, pre_tries = 0, min_path_length = 0, additional_tries = 0, pause_param = 0;
   bool setup_ok = true;
   // RampSpecs :1035-1120
-  struct Spec { LogRamp ctrl; float vol = 1.f; bool silenceAfter = true; };
+  struct Spec { LogRamp ctrl; WindMainCtrl wctrl; float vol = 1.f; bool silenceAfter = true; };
   struct RampSpecs {
     static constexpr int n_specs = 30;
     int it = -1, end = 0; // (`it` is a 5-bit unsigned in the reference: its -1 is 31 >= end)
@@ -365,6 +386,7 @@ struct VoiceElement {
     switch (mode) {
       case VOICE_SWEEP: setup_ok = initialize_sweep(low_freq, high_freq); break;
       case VOICE_BIRDS: setup_ok = initialize_birds(); break;
+      case VOICE_WIND: setup_ok = initialize_wind(); break;
       default: setup_ok = initialize_robot(); break;
     }
   }
@@ -487,6 +509,20 @@ struct VoiceElement {
     mc->def_transition(node0, node1, 1.f);
     return mc;
   }
+  std::unique_ptr<MarkovChain> create_wind() { // :721-735: the lambda runs on ENTER and on LEAVE alike
+    auto mc = std::make_unique<MarkovChain>();
+    int node0 = mc->emplace([this](MarkovChain::Move) {
+      if (Spec *s = ramp_specs.get_next_ramp_for_build()) s->wctrl.ctrl.ctrl.it.set_interpolation(interpolation); // getUnderlyingIter(): the long-term SlowIter
+    });
+    int node1 = mc->emplace([](MarkovChain::Move) {});
+    mc->def_transition(node0, node1, 1.f);
+    mc->def_transition(node1, node0, 1.f);
+    return mc;
+  }
+  bool initialize_wind() { // :913-924 with SoundEngineInitPolicy::StartAfresh (gen.voice.h:1017-1022); the pause keeps the member's value (0)
+    if (!markov) markov = create_wind();
+    return do_initialize(true, start_node, pre_tries, min_path_length, additional_tries, articulative_pause_length);
+  }
   bool initialize_sweep(float low, float high) { // :883-896
     if (!markov) markov = create_sweep();
     freq1_robot = low;
@@ -540,13 +576,16 @@ struct VoiceElement {
     if (!new_spec) return;
     if (trace) trace->push_back({steps_taken, static_cast<int32_t>(new_ramp - ramps.data()), static_cast<int32_t>(ramp_specs.it)});
     new_ramp->ctrl = new_spec->ctrl;
+    if (mode == VOICE_WIND) { new_ramp->wctrl = new_spec->wctrl; wind_ctx.play = ramp_specs.it; } // (the draws of this play: oracle_wind.hpp)
     new_ramp->forgetPastSignals();
     new_ramp->sample_rate = sample_rate;
+    if (mode == VOICE_WIND) { new_ramp->wctrl.set_sample_rate(sample_rate); new_ramp->wv.set_sample_rate(sample_rate); new_ramp->wv.setStartAngle(start_angle); wind_ctx.play = -1; }
     new_ramp->sine.setStartAngle(start_angle);
     new_ramp->volume_target = new_spec->vol;
     new_ramp->env.setAHDSR(AHDSR{xfade_len, 0, 0, xfade_len, 1.f}, sample_rate);
     new_ramp->env.tryAcquire();
-    int const time_to_release = static_cast<int>(.5f + new_ramp->ctrl.get_duration_in_samples()) - xfade_len;
+    int const time_to_release = (mode == VOICE_WIND ? static_cast<int>(.5f + new_ramp->wctrl.get_duration_in_samples()) // (.5f + an int: a float sum)
+                                                    : static_cast<int>(.5f + new_ramp->ctrl.get_duration_in_samples())) - xfade_len;
     new_ramp->env.onKeyPressed(0);
     new_ramp->env.onKeyReleased(std::max(time_to_release, 0));
   }
@@ -648,6 +687,48 @@ struct VoiceInitializer {
       e.xfade_freq = XFADE_NO;                                                          // the constructor's value :271
     }
     if (p.mode == VOICE_ROBOTS) { e.d1 = p.d1; e.d2 = p.d2; e.har_att = clamp_har_att(p.harmonic_attenuation); }
+    if (p.mode == VOICE_WIND) setup_wind(e, noteid);
+  }
+  // setupAudioElement's WIND branches (gen.voice.h:936-978) over SetFilterWidths / ConfigureFilters / SetGains / SetSlowParams (:334-408)
+  void setup_wind(VoiceElement &e, int64_t noteid) const {
+    int const sr = p.sample_rate;
+    e.wind_ctx.key = p.seed; e.wind_ctx.noteid = noteid; e.wind_ctx.play = -1;
+    auto bind = [&e](PinkIter &it, int id) { it.ctx = &e.wind_ctx; it.id = id; };
+    for (auto &r : e.ramps) {
+      r.wind = true;
+      bind(r.wctrl.ctrl.ctrl.it.it, WI_LONG); bind(r.wctrl.noise.it, WI_SHORT);
+      bind(r.wv.bp.center.ctrl.it.it, WI_BP_CENTER); bind(r.wv.bp.width.it.it, WI_BP_WIDTH);
+      bind(r.wv.br.center.ctrl.it.it, WI_BR_CENTER); bind(r.wv.br.width.it.it, WI_BR_WIDTH);
+      r.wctrl.set_sample_rate(sr); r.wv.set_sample_rate(sr);       // SoundEngine::set_sample_rate :484-492 (gen.crtp.h:424)
+      r.wv.setFiltersOrder(p.order_filters);                       // engine.setFiltersOrder(value<ORDER_FILTERS>()) :939
+      float const m = p.bp_octave_width_min, M = p.bp_octave_width_max; // :941-950
+      r.wv.bp.width_min = r.wv.br.width_min = std::min(m, M);
+      r.wv.bp.width_max = r.wv.br.width_max = std::max(m, M);
+      r.gain_lp = p.pink_noise_lp_gain; r.gain_bp = p.pink_noise_bp_gain; r.gain_br = p.pink_noise_br_gain; // SetGains<WIND> :399-406 (gain0 = SINE_GAIN)
+    }
+    for (auto &s : e.ramp_specs.a) { bind(s.wctrl.ctrl.ctrl.it.it, WI_LONG); bind(s.wctrl.noise.it, WI_SHORT); s.wctrl.set_sample_rate(sr); }
+    // octaveRangeToAngleIncrementsRange<CENTER_OCTAVE_MIN_LONG_TERM, CENTER_OCTAVE_MAX_LONG_TERM> :854-879
+    constexpr float lowest_f = 10.f;
+    float fm = lowest_f * std::pow(2.f, p.center_octave_min_long_term), fM = lowest_f * std::pow(2.f, p.center_octave_max_long_term);
+    if (fm > fM) std::swap(fm, fM);
+    float const ra_min = freq_to_angle_increment(fm, sr), ra_max = freq_to_angle_increment(fM, sr);
+    constexpr float max_seconds_slow_iter = 2.268f; // :623
+    float const n_slow_steps = sr * std::pow(max_seconds_slow_iter, p.seconds_slow_iter_long_term);
+    float const n_slow_steps_short = sr * std::pow(max_seconds_slow_iter, p.seconds_slow_iter_short_term);
+    for (auto &r : e.ramps) { // ConfigureFilters<WIND>::configure(mix, unsigned int n_slow_steps, ra) :367-388
+      unsigned int const n = static_cast<unsigned int>(n_slow_steps);
+      for (WindBand *b : {&r.wv.bp, &r.wv.br}) {
+        b->center.ctrl.it.set_n_slow_steps(static_cast<int32_t>(n));
+        b->center.setAngleIncrementsRange(ra_min, ra_max);
+        b->width.it.set_n_slow_steps(static_cast<int32_t>(n));
+      }
+    }
+    for (auto &s : e.ramp_specs.a) { // SetSlowParams<WIND>::set(ctrl, int n_slow_steps_short, int n_slow_steps_long, float ratio) :332-341, then the range :976
+      s.wctrl.ctrl.ctrl.it.set_n_slow_steps(static_cast<int>(n_slow_steps));
+      s.wctrl.ratio = static_cast<float>(static_cast<int>(n_slow_steps_short)); // set_short_term_noise_rate(float) fed the int
+      s.wctrl.noise_amplitude = p.center_short_term_ratio;                      // set_short_term_noise_amplitude
+      s.wctrl.ctrl.setAngleIncrementsRange(ra_min, ra_max);
+    }
   }
 };
 

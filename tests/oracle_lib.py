@@ -290,7 +290,11 @@ class OraVoiceParams(C.Structure):
                 ("markov_min_path_length", C.c_int32), ("markov_additional_tries", C.c_int32), ("articulative_pause_seconds", C.c_float),
                 ("freq_scatter", C.c_float), ("length_exponent_scatter", C.c_float), ("phase_ratio1", C.c_float), ("phase_ratio2", C.c_float),
                 ("d1", C.c_float), ("d2", C.c_float), ("harmonic_attenuation", C.c_float), ("xfade_freq", C.c_int32),
-                ("freq_transition_seconds", C.c_float), ("freq_interpolation", C.c_int32), ("seed_param", C.c_int32)]
+                ("freq_transition_seconds", C.c_float), ("freq_interpolation", C.c_int32), ("seed_param", C.c_int32),
+                ("pink_noise_lp_gain", C.c_float), ("pink_noise_bp_gain", C.c_float), ("pink_noise_br_gain", C.c_float),
+                ("bp_octave_width_min", C.c_float), ("bp_octave_width_max", C.c_float), ("center_octave_min_long_term", C.c_float),
+                ("center_octave_max_long_term", C.c_float), ("center_short_term_ratio", C.c_float), ("seconds_slow_iter_short_term", C.c_float),
+                ("seconds_slow_iter_long_term", C.c_float), ("order_filters", C.c_int32)]
 
 
 def voice_params_from(cfg, seed):

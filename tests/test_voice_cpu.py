@@ -123,10 +123,14 @@ def test_expand_note_argument_errors(api):
     cfg, _ = api.voice_program(0, 0)
     with pytest.raises(api.RaError):
         api.voice_expand_note(cfg, 0.0, 1, 1)
-    cfg.mode = 3
+    cfg.mode = 4
     with pytest.raises(api.RaError) as e:
         api.voice_expand_note(cfg, 440.0, 1, 1)
-    assert "WIND" in str(e.value)
+    assert "mode" in str(e.value)
+    cfg, _ = api.voice_program(3, 0, pink_noise_lp_gain=0.25)
+    with pytest.raises(api.RaError) as e:
+        api.voice_expand_note(cfg, 440.0, 1, 1)
+    assert "pink_noise_lp_gain" in str(e.value)
     cfg, _ = api.voice_program(1, 1)
     with pytest.raises(api.RaError) as e:
         api.voice_expand_note(cfg, 440.0, 1, 1, spec_cap=2)
