@@ -292,6 +292,14 @@ def voice_workload(api, which, S, seconds, blocks):
     elif which == "birds":
         cfg, name = api.voice_program(api.VOICE_BIRDS, 8, seed=99)       # "Talkative bird": six Markov steps, frequency transitions, pauses: ~4 s of ~10 ramps
         desc, every, hold = f"BIRDS program '{name}': a note-on every 350 ms, released after 5 s", (SR * 35) // 100, 5 * SR
+    elif which == "wind":
+        # "Light rain in a car": pink noise through a band-pass of 89 + 89 one-pole sections whose centre and width move every ~11 samples.
+        # A WIND note is one ramp that sounds until its note-off (which loses the channel for good): four notes per synth, held
+        cfg, name = api.voice_program(api.VOICE_WIND, 6, seed=99)
+        rows = []
+        for s in range(S):
+            rows += [(k * (SR // 2) + 7 * (s % 64), s, 0, k, 220.0 + 20.0 * k, 0.5) for k in range(4)]
+        return cfg, rows, f"WIND program '{name}' (filters of order 89): four notes per synth, held"
     else:
         cfg, name = api.voice_program(api.VOICE_ROBOTS, 1, seed=99)      # "Communication": 16 + 14 Markov steps: ~2 s of ~20 tones
         desc, every, hold = f"ROBOTS program '{name}': a note-on every 250 ms, released after 3.5 s", SR // 4, (7 * SR) // 2
@@ -357,7 +365,7 @@ def workloads(N=4096, H=1024, P=64):
                      256, "synth"),
         "configs3": ("configs[3]: 1000 stereo = 2000 mono streams, N = 8192, H = 2048, P = 128, autotune major / C",
                      dict(parity, window_size=8192, stride=2048, n_channels=128, use_autotune=1, autotune_type=0, autotune_scale_mode=0, autotune_root_note=0), 2000, None),
-        "voice_sweep": ("sweep", 256), "voice_birds": ("birds", 256), "voice_robots": ("robots", 256),
+        "voice_sweep": ("sweep", 256), "voice_birds": ("birds", 256), "voice_robots": ("robots", 256), "voice_wind": ("wind", 256),
     }
 
 
@@ -809,7 +817,7 @@ def main():
                     o["target"] = ">= 10 x real time for each of the 1000 streams (BASELINE.json north_star)"
                     o["pcie_inclusive"] = pcie_inclusive(api, torch, api.default_config(sample_rate=SR, **kw), S2, 10 * SR, local_rank)
                 others.append(o)
-            for name in ("voice_sweep", "voice_birds", "voice_robots"):
+            for name in ("voice_sweep", "voice_birds", "voice_robots", "voice_wind"):
                 o = time_voice(api, torch, dev, wl[name][0], wl[name][1], 10.0, 6)
                 o["workload"] = name
                 others.append(o)

@@ -81,7 +81,7 @@ EXPORTED_SYMBOLS = [
     "ra_feed", "ra_compute", "ra_get_stats", "ra_get_events", "ra_get_frame_pitches", "ra_resynth_notes", "ra_sqmag",
     "ra_host_alloc", "ra_host_free", "ra_process_host_pipelined", "ra_set_profiling", "ra_get_kernel_ms", "ra_get_kernel_launches", "ra_get_stage_timing", "ra_set_clock_stamps", "ra_get_clock_stamps", "ra_render_note",
     "ra_carrier_events", "ra_get_carrier", "ra_set_pipeline_serial", "ra_deduce_notes", "ra_deduce_notes_batch",
-    "ra_voice_default_config", "ra_voice_program", "ra_voice_expand_note", "ra_voice_create", "ra_voice_destroy", "ra_voice_events", "ra_voice_process_host", "ra_voice_process_device",
+    "ra_voice_default_config", "ra_voice_program", "ra_voice_expand_note", "ra_voice_pink_noise", "ra_voice_wind_start_position", "ra_voice_create", "ra_voice_destroy", "ra_voice_events", "ra_voice_process_host", "ra_voice_process_device",
     "ra_voice_process_device_async", "ra_voice_set_hip_stream", "ra_voice_synchronize", "ra_voice_get_kernel_ms", "ra_voice_dropped_note_ons",
 ]
 
@@ -445,6 +445,24 @@ def voice_expand_note(cfg, frequency, stream_seed, seed_value, noteid=1, spec_ca
     ns, npl = int(info[0]), int(info[1])
     gain = np.array([info[3]], np.int64).astype(np.int32).view(np.float32)[0]
     return dict(specs_d=sd[:ns], specs_i=si[:ns], vol=sv[:ns], played=pl[:npl], done_step=int(info[2]), gain_left=float(gain))
+
+
+def voice_pink_noise(sample_rate):
+    """Host-only: the pink-noise sound buffer of WIND and its abs mean (ra_voice_pink_noise)."""
+    L = lib()
+    L.ra_voice_pink_noise.restype = C.c_int64
+    L.ra_voice_pink_noise.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
+    am = C.c_float()
+    n = _check(L.ra_voice_pink_noise(int(sample_rate), None, 0, C.byref(am)))
+    out = np.zeros(n, np.float64)
+    _check(L.ra_voice_pink_noise(int(sample_rate), _p(out), n, C.byref(am)))
+    return out, am.value
+
+
+def voice_wind_start_position(stream_seed, noteid, play, iterator, which, buffer_length):
+    L = lib()
+    L.ra_voice_wind_start_position.argtypes = [C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64]
+    return _check(L.ra_voice_wind_start_position(int(stream_seed), int(noteid), int(play), int(iterator), int(which), int(buffer_length)))
 
 
 class Voice:

@@ -2290,6 +2290,20 @@ int ra_voice_program(int32_t mode, int32_t index, ra_voice_config *c, const char
   return RA_OK;
 }
 
+// host-only: the pink-noise sound buffer WIND reads and a ramp's declared start positions (ra_voice_host.hpp), for CPU tests
+int64_t ra_voice_pink_noise(int32_t sample_rate, double *h_out, int64_t cap, float *abs_mean) {
+  if (sample_rate < 1000) return fail(RA_EINVAL, "sample_rate is too small");
+  rav::PinkNoise pn;
+  rav::build_pink_noise(sample_rate, pn);
+  for (int64_t i = 0; h_out && i < cap && i < (int64_t)pn.values.size(); ++i) h_out[i] = pn.values[(size_t)i];
+  if (abs_mean) *abs_mean = pn.abs_mean;
+  return (int64_t)pn.values.size();
+}
+int32_t ra_voice_wind_start_position(uint64_t stream_seed, int64_t noteid, int32_t play, int32_t iterator, int32_t which, int64_t buffer_length) {
+  if (noteid < 0 || play < 0 || play >= 30 || iterator < 0 || iterator >= 6 || which < 0 || which > 1 || buffer_length < 2) return fail(RA_EINVAL, "bad argument");
+  return rav::wind_position(stream_seed, noteid, play, iterator, which, (size_t)buffer_length);
+}
+
 int ra_voice_expand_note(const ra_voice_config *cfg, float frequency, uint64_t stream_seed, int32_t seed_value, int64_t noteid, double *spec_d, int32_t *spec_i, float *spec_vol,
                          int64_t spec_cap, int64_t *played, int64_t played_cap, int64_t *info) {
   if (!cfg) return fail(RA_EINVAL, "null config");

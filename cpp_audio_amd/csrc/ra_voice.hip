@@ -426,20 +426,16 @@ __global__ void __launch_bounds__(MAXT) ra_voice_render_kernel(RaVoiceParams p, 
 
 } // namespace
 
-// One chunk [c0, c0 + clen) of a WIND block: controls (+ sine), the filter chains, the mix (ra_wind.cuh).  A chain's M = sections per lane.
+// One chunk [c0, c0 + clen) of a WIND block: controls (+ sine), the filter chains, the mix (ra_wind.cuh).
 void ra_wind_launch(const RaVoiceParams &vp, const RaWindParams &wp, const RaWindJob *jobs, int n_jobs, const int32_t *stream_begin, int n_streams, const double *pink,
                     RaWindState *states, double *fstates, const RaWindScratch &sc, int c0, int clen, int64_t n, float *d_out, hipStream_t st) {
   if (clen <= 0) return;
   if (n_jobs > 0) {
     hipLaunchKernelGGL(ra_wind_ctl_kernel, dim3((unsigned)n_jobs, 3), dim3(64), 0, st, vp, wp, jobs, pink, states, sc, c0, clen);
-    auto chains = [&](int first, int count, int sections) {
-      const dim3 grid((unsigned)n_jobs, (unsigned)count), block(64);
-      const int m = (sections + 63) / 64;
-      if (m <= 1) hipLaunchKernelGGL(ra_wind_chain_kernel<1>, grid, block, 0, st, wp, jobs, pink, fstates, sc, c0, clen, first);
-      else if (m <= 2) hipLaunchKernelGGL(ra_wind_chain_kernel<2>, grid, block, 0, st, wp, jobs, pink, fstates, sc, c0, clen, first);
-      else if (m <= 3) hipLaunchKernelGGL(ra_wind_chain_kernel<3>, grid, block, 0, st, wp, jobs, pink, fstates, sc, c0, clen, first);
-      else if (m <= 5) hipLaunchKernelGGL(ra_wind_chain_kernel<5>, grid, block, 0, st, wp, jobs, pink, fstates, sc, c0, clen, first);
-      else hipLaunchKernelGGL(ra_wind_chain_kernel<9>, grid, block, 0, st, wp, jobs, pink, fstates, sc, c0, clen, first);
+    auto chains = [&](int first, int count, int sections) { // a wave per 64 sections (<= 516 sections: nine waves)
+      const int waves = (sections + 63) / 64;
+      hipLaunchKernelGGL(ra_wind_chain_kernel, dim3((unsigned)n_jobs, (unsigned)count), dim3((unsigned)(64 * waves)), (size_t)waves * kWindWaveLds * sizeof(double), st, wp, jobs, pink,
+                         fstates, sc, c0, clen, first);
     };
     if (wp.g_bp != 0.f) chains(0, 1, 2 * wp.order);
     if (wp.g_br != 0.f) chains(1, 2, wp.order);

@@ -35,31 +35,56 @@ __device__ inline float wind_interp(int kind, int slow, int n, float prev, float
   return (float)v;
 }
 
-// WindFreqIter<SlowIter<AbsIter<PinkNoiseIter>>, 3> (audioelement.h:2932-2966 over :2846-2927): `cnt` steps of the iterator; lane i < cnt returns
+// WindFreqIter<SlowIter<AbsIter<PinkNoiseIter>>, 3> (audioelement.h:2932-2966 over :2846-2927): `cnt` <= 64 steps of the iterator; lane i < cnt returns
 // the value read after step i + 1.  A step advances slow_it by 1 when the piece descends (prev > next) and by up to 3 when it ascends, and
 // stops at the major step (slow_it reaches n_steps: prev <- next, the buffer moves on, slow_it <- 0).  `s` is the same in every lane.
-__device__ inline float wind_iter_batch(RaWindIter &s, int kind, const double *__restrict__ pink, int len, int cnt, int lane) {
-  float my_prev = 0.f, my_next = 0.f;
-  int my_slow = 0;
-  float next = wind_abs(pink[s.pos]);
-  int done = 0;
-  while (done < cnt) {
-    const int rate = (s.prev > next) ? 1 : 3;
-    const int to_major = max(1, (s.n - s.slow + rate - 1) / rate); // steps up to and including the major one
-    const int take = min(to_major, cnt - done);
-    const bool major = take == to_major;
-    const int pos2 = wind_wrap(s.pos + 1, len);
-    const float next2 = major ? wind_abs(pink[pos2]) : next;
-    const int i = lane - done + 1;
-    if (i >= 1 && i <= take) {
-      if (i == to_major) { my_slow = 0; my_prev = next; my_next = next2; }
-      else { my_slow = s.slow + rate * i; my_prev = s.prev; my_next = next; }
-    }
-    if (major) { s.prev = next; s.pos = pos2; next = next2; s.slow = 0; }
-    else s.slow += rate * take;
-    done += take;
+// No walk: a piece that starts at a major step lasts ceil(n / rate) steps, and its rate depends on the two buffer samples it runs between — so
+// lane q holds the piece between window samples q - 1 and q (lane 0: the piece under way), an inclusive scan of the lengths says in which step each
+// piece ends, the steps with a major become a 64-bit mask, and a sample's piece is the number of majors before it (one mbcnt).
+// (A piece-by-piece walk cost ~25 dependent instructions per piece — with pieces of four samples most of the controls' time.)
+__device__ inline float wind_iter_batch(RaWindIter &s, int kind, const double *__restrict__ pink, int len, int cnt, int lane, int *lds64) {
+  float w0, w1; // the window: sample lane and sample 64 + lane after the iterator's position
+  {
+    int p0 = s.pos + lane;
+    p0 = p0 >= len ? p0 - len : p0;
+    int p1 = p0 + 64;
+    p1 = p1 >= len ? p1 - len : p1;
+    w0 = wind_abs(pink[p0]); w1 = wind_abs(pink[p1]);
   }
-  return wind_interp(kind, my_slow, s.n, my_prev, my_next);
+  const float w64 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w1), 0));
+  // piece q = lane: from prev_q to next_q
+  const float below = __shfl_up(w0, 1);
+  const float prev_q = lane == 0 ? s.prev : below, next_q = w0;
+  const int rate_q = (prev_q > next_q) ? 1 : 3;
+  const int len_q = max(1, ((lane == 0 ? s.n - s.slow : s.n) + rate_q - 1) / rate_q);
+  int end_q = len_q; // the step (1-based) of the piece's major
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { const int t = __shfl_up(end_q, 1 << k); if (lane >= (1 << k)) end_q += t; }
+  __syncthreads();
+  lds64[lane] = 0;
+  __syncthreads();
+  if (end_q <= 64) lds64[end_q - 1] = 1;
+  __syncthreads();
+  const unsigned long long majors = __ballot(lds64[lane] != 0); // bit j - 1: step j ends a piece
+  const int q = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(majors >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)majors, 0u)); // the piece of step lane + 1
+  const bool major = (majors >> lane) & 1ull;
+  // (every shuffle with all lanes in: a lane that sits out a branch reads as 0 to the others)
+  const int end_sh = __shfl(end_q, max(q - 1, 0));
+  const int end_before = q > 0 ? end_sh : 0;
+  const float pq = __shfl(prev_q, q), nq = __shfl(next_q, q);
+  const float after_sh = __shfl(w0, (q + 1) & 63);
+  const float after = (q + 1 < 64) ? after_sh : w64; // window sample q + 1: the piece after q runs to it
+  const int rq = (pq > nq) ? 1 : 3;
+  const int slow = major ? 0 : (q == 0 ? s.slow : 0) + rq * (lane + 1 - end_before);
+  const float my_prev = major ? nq : pq, my_next = major ? after : nq;
+  // the state after step cnt: what lane cnt - 1 found
+  const int lc = cnt - 1;
+  const int q_c = __builtin_amdgcn_readlane(q, lc), major_c = __builtin_amdgcn_readlane((int)major, lc), slow_c = __builtin_amdgcn_readlane(slow, lc);
+  const float prev_c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_prev), lc));
+  s.prev = prev_c; s.slow = slow_c;
+  s.pos += q_c + (major_c ? 1 : 0);
+  s.pos = s.pos >= len ? s.pos - len : s.pos;
+  return wind_interp(kind, slow, s.n, my_prev, my_next);
 }
 // a ramp's iterator as playNextSpec leaves it (soundengine.h:776-803): forgetPastSignals -> initializeForRun (position p0, prev taken there, the
 // buffer moves on), then set_sample_rate draws the position again (p1); ABS: over AbsIter
@@ -82,6 +107,7 @@ __device__ inline double wind_k(double w) { const double a = M_PI * w; return a 
 __global__ void __launch_bounds__(64) ra_wind_ctl_kernel(RaVoiceParams vp, RaWindParams wp, const RaWindJob *__restrict__ jobs, const double *__restrict__ pink,
                                                           RaWindState *__restrict__ states, RaWindScratch sc, int c0, int clen) {
   __shared__ float lf[29], le[29];
+  __shared__ int flags[64];
   load_tables(vp, lf, le);
   const int ji = blockIdx.x, role = blockIdx.y, lane = threadIdx.x;
   if ((role == 0 && wp.g_sine == 0.f) || (role == 1 && wp.g_bp == 0.f) || (role == 2 && wp.g_br == 0.f)) return; // Mix::imag: 0 * (a finite voice)
@@ -101,8 +127,8 @@ __global__ void __launch_bounds__(64) ra_wind_ctl_kernel(RaVoiceParams vp, RaWin
     double *k_lp = (role == 1 ? sc.k_bp_lp : sc.k_br_lp) + base, *k_hp = (role == 1 ? sc.k_bp_hp : sc.k_br_hp) + base;
     for (int b0 = 0; b0 < cnt; b0 += 64) {
       const int c64 = min(64, cnt - b0);
-      const float vc = wind_iter_batch(c, RA_ITP_LINEAR, pink, len, c64, lane);
-      const float vw = wind_iter_batch(w, RA_ITP_LINEAR, pink, len, c64, lane);
+      const float vc = wind_iter_batch(c, RA_ITP_LINEAR, pink, len, c64, lane, flags);
+      const float vw = wind_iter_batch(w, RA_ITP_LINEAR, pink, len, c64, lane, flags);
       if (lane < c64) {
         const double increment = (double)wind_center_inc(wp, vc);
         const float at = wp.width_min + fabsf(vw) * (wp.width_max - wp.width_min); // range<float>::getAt
@@ -129,7 +155,7 @@ __global__ void __launch_bounds__(64) ra_wind_ctl_kernel(RaVoiceParams vp, RaWin
   const bool short_term = wp.short_amplitude != 0.f; // 2^(0 x) = 1: the short-term iterator's walk decides nothing
   for (int b0 = 0; b0 < cnt; b0 += 64) {
     const int c64 = min(64, cnt - b0);
-    const float vl = wind_iter_batch(lg, wp.interp_long, pink, len, c64, lane);
+    const float vl = wind_iter_batch(lg, wp.interp_long, pink, len, c64, lane, flags);
     const float long_inc = wind_center_inc(wp, vl);
     float inc_f = long_inc;
     if (short_term) {
@@ -175,15 +201,30 @@ __global__ void __launch_bounds__(64) ra_wind_ctl_kernel(RaVoiceParams vp, RaWin
   if (lane == min(63, (cnt - 1) & 63)) S->loud_k = r.loud_k; // (the table interval the last sample was in: a hint, any lane's would do)
 }
 
-// ---- filter chains: one wave per (job, chain); chain 0 = band-pass (n low-pass sections, then n high-pass), 1 = band-reject's low-pass, 2 = its high-pass
-template <int M>
-__global__ void __launch_bounds__(64) ra_wind_chain_kernel(RaWindParams wp, const RaWindJob *__restrict__ jobs, const double *__restrict__ pink, double *__restrict__ fstates,
-                                                            RaWindScratch sc, int c0, int clen, int chain0) {
-  __shared__ double ring_x[128], ring_a[128], ring_b[128];
-  const int ji = blockIdx.x, chain = chain0 + blockIdx.y, l = threadIdx.x;
+// ---- filter chains: one workgroup per (job, chain); chain 0 = band-pass (n low-pass sections, then n high-pass), 1 = band-reject's low-pass, 2 = its high-pass.
+// A lane holds ONE section; a chain of more than 64 sections takes several waves, wave w the sections 64 w .. 64 w + 63: its lane 63 writes what
+// lane 0 of wave w + 1 reads into a ring in LDS, and wave w + 1 runs two batches of 64 steps behind wave w (lane 63 of a wave finishes a sample 63
+// steps after lane 0 started it), one workgroup barrier per batch.  (r04's first version kept several sections per lane in one wave: a step's
+// instructions then form one dependent chain on a SIMD with nothing else to issue — 460 cycles per step at three sections per lane.)
+// A step of the steady state: two DPP moves, subtract / multiply / add, sign flip + multiply-add for the output, two LDS reads at immediate
+// offsets, and four lane moves that collect the tap lane's output into lane tt of a register the wave stores once per batch.
+// LDS per wave, in doubles: two coefficient rings and the input ring (wave 0: the noise) of 128 samples, the output ring of 256 (a wave reads its input
+// two batches after the wave before wrote it); every ring is followed by a copy of its first 64 entries, so that the 65 entries a lane reads during
+// a batch are contiguous wherever they start: one address per batch and immediate offsets, instead of three address instructions per read.
+constexpr int kWindRing = 128 + 64, kWindLink = 256 + 64, kWindWaveLds = 3 * kWindRing + kWindLink;
+__device__ inline void wind_ring_put(double *ring, int size, int i, double v) { ring[i] = v; if (i < 64) ring[i + size] = v; }
+__device__ inline double wind_fma3(double a, double b, double c) { // a b + c as the three-address instruction
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__global__ void __launch_bounds__(576) ra_wind_chain_kernel(RaWindParams wp, const RaWindJob *__restrict__ jobs, const double *__restrict__ pink, double *__restrict__ fstates,
+                                                             RaWindScratch sc, int c0, int clen, int chain0) {
+  double *wsm = reinterpret_cast<double *>(ra_smem_voice);
+  const int ji = blockIdx.x, chain = chain0 + blockIdx.y, w = threadIdx.x >> 6, l = threadIdx.x & 63, W = blockDim.x >> 6;
   const RaWindJob J = jobs[ji];
   const int lo = max(J.begin, c0), hi = min(J.begin + J.n, c0 + clen);
-  if (hi <= lo) return;
+  if (hi <= lo) return; // (the whole workgroup)
   const int cnt = hi - lo, N = wp.order, len = wp.pink_len;
   const int L = chain == 0 ? 2 * N : N;            // sections of this chain
   const int ns = chain == 2 ? 0 : N;               // sections below ns are low-pass (coefficient a), the others high-pass (coefficient b)
@@ -193,46 +234,73 @@ __global__ void __launch_bounds__(64) ra_wind_chain_kernel(RaWindParams wp, cons
   double *fs = fstates + (size_t)J.slot * (size_t)(4 * N) + (chain == 0 ? 0 : (chain == 1 ? 2 * N : 3 * N));
   const int j_lo = J.j0 + (lo - J.begin);
   const bool fresh = j_lo == 1; // Filter::forgetPastSignals: the sections start at 0
-  double y[M];
-#pragma unroll
-  for (int j = 0; j < M; ++j) { const int s = l * M + j; y[j] = (s < L && !fresh) ? fs[s] : 0.0; }
-  const int out_lane = (L - 1) / M;
-  const int total = cnt + out_lane;
-  // the noise wrapper's index at step j: pink_start + j (soundBufferWrapperAlgo::step, audioelement.h:1568-1574)
-  int px = (int)(((long long)wp.pink_start + j_lo + l) % len); // lane l stages sample tau0 + l
+  double *ring_a = wsm + (size_t)w * kWindWaveLds, *ring_b = ring_a + kWindRing, *ring_x = ring_b + kWindRing, *link_out = ring_x + kWindRing;
+  const double *xin = w == 0 ? ring_x : link_out - kWindWaveLds; // lane 0's input: the noise, or what the wave before hands on
+  const int xmask = w == 0 ? 127 : 255;
+  const int sidx = 64 * w + l;
+  const bool on = sidx < L, hp = sidx >= ns, last = w == W - 1;
+  double y = (on && !fresh) ? fs[sidx] : 0.0;
+  const double *rk = hp ? ring_b : ring_a;
+  const double hm = hp ? 1.0 : 0.0;                 // the section's output: y (low-pass) or x - y (high-pass) = fma(hm, x, -+y): exact either way
+  const int sgn = hp ? (int)0x80000000 : 0;
+  const int tap = last ? (L - 1 - 64 * w) : 63;     // the lane whose output leaves the wave (lanes beyond the chain's end work on what nobody reads)
+  const int total = cnt + 63, nb = (total + 63) / 64;
+  // the noise wrapper's index at step j: pink_start + j (soundBufferWrapperAlgo::step, audioelement.h:1568-1574); lane l of wave 0 stages sample tau0 + l
+  int px = (int)(((long long)wp.pink_start + j_lo + l) % len);
   double xout = 0.0; // what this lane handed on in the previous step
-  for (int tau0 = 0; tau0 < total; tau0 += 64) {
-    __syncthreads();
-    {
+  for (int b = 0; b < nb + 2 * (W - 1); ++b) {
+    const int bl = b - 2 * w;
+    const bool mine = bl >= 0 && bl < nb;
+    const int tau0 = 64 * bl;
+    if (mine) {
       const int t = tau0 + l;
-      if (t < cnt) { ring_x[t & 127] = pink[px]; ring_a[t & 127] = ka[t]; ring_b[t & 127] = kb[t]; }
+      if (t < cnt) {
+        wind_ring_put(ring_a, 128, t & 127, ka[t]);
+        wind_ring_put(ring_b, 128, t & 127, kb[t]);
+        if (w == 0) wind_ring_put(ring_x, 128, t & 127, pink[px]);
+      }
       px = (int)(((long long)px + 64) % len);
     }
-    __syncthreads();
-    const int steps = min(64, total - tau0);
-    for (int tt = 0; tt < steps; ++tt) {
-      const int tau = tau0 + tt, t = tau - l;
-      const bool act = t >= 0 && t < cnt;
-      double x = wave_shr1_f64(0.0, xout);
-      if (l == 0) x = ring_x[tau & 127];
-      const double ca = ring_a[t & 127], cb = ring_b[t & 127];
+    __syncthreads(); // this batch's rings are filled; what the wave before wrote in the last batch is visible
+    if (!mine) continue;
+    const double *pc = rk + ((tau0 - l) & 127);   // the lane's coefficient of step tau0 + tt: pc[tt]
+    const double *px0 = xin + (tau0 & xmask);     // lane 0's input of step tau0 + tt: px0[tt]
+    if (tau0 >= 63 && tau0 + 64 <= cnt) { // every lane has a sample in every step of this batch
+      double collected = 0.0; // lane tt: what the tap lane put out in step tt
+      double c = pc[0], x0 = px0[0];
 #pragma unroll
-      for (int j = 0; j < M; ++j) {
-        const int s = l * M + j;
-        if (s < L) {
-          const bool hp = s >= ns;
-          const double k = hp ? cb : ca;
-          const double yn = y[j] + k * (x - y[j]); // s = s + k (x - s), the operations of the restatement
-          y[j] = act ? yn : y[j];
-          x = hp ? x - yn : yn;
+      for (int tt = 0; tt < 64; ++tt) {
+        const double c_n = pc[tt + 1], x0_n = px0[tt + 1]; // (one step ahead: an LDS round trip is as long as a step's arithmetic; entry 64 of the last step is never used)
+        const double x = wave_shr1_f64(x0, xout);
+        y = y + c * (x - y); // s = s + k (x - s), the operations of the restatement
+        xout = wind_fma3(hm, x, __hiloint2double(__double2hiint(y) ^ sgn, __double2loint(y)));
+        {
+          const int lo32 = __builtin_amdgcn_readlane(__double2loint(xout), tap), hi32 = __builtin_amdgcn_readlane(__double2hiint(xout), tap);
+          int clo = __double2loint(collected), chi = __double2hiint(collected);
+          asm("v_writelane_b32 %0, %1, %2" : "+v"(clo) : "s"(lo32), "i"(tt));
+          asm("v_writelane_b32 %0, %1, %2" : "+v"(chi) : "s"(hi32), "i"(tt));
+          collected = __hiloint2double(chi, clo);
         }
+        c = c_n; x0 = x0_n;
       }
-      xout = x;
-      if (act && l == out_lane) out[t] = x;
+      const int t = tau0 + l - tap; // the sample lane l's collected value belongs to
+      if (last) out[t] = collected;
+      else wind_ring_put(link_out, 256, t & 255, collected);
+    } else {
+      const int steps = min(64, total - tau0);
+      for (int tt = 0; tt < steps; ++tt) {
+        const int t = tau0 + tt - l;
+        const bool act = t >= 0 && t < cnt;
+        const double c = pc[tt], x0 = px0[tt];
+        const double x = wave_shr1_f64(x0, xout);
+        const double yn = y + c * (x - y);
+        y = act ? yn : y;
+        xout = fma(hm, x, __hiloint2double(__double2hiint(yn) ^ sgn, __double2loint(yn)));
+        if (act && l == tap) { if (last) out[t] = xout; else wind_ring_put(link_out, 256, t & 255, xout); }
+      }
     }
   }
-#pragma unroll
-  for (int j = 0; j < M; ++j) { const int s = l * M + j; if (s < L) fs[s] = y[j]; }
+  if (on) fs[sidx] = y;
 }
 
 // ---- mix: one lane per (stream, frame) of the chunk

@@ -442,6 +442,12 @@ int ra_voice_default_config(ra_voice_config *cfg); /* the "Sweep 1" program (gen
 /* the reference's own programs (ImplBase::getPrograms, gen.voice.h:700-810) with make_common's defaults (:474-531): mode RA_VOICE_BIRDS
  * index 0 .. 8, RA_VOICE_ROBOTS 0 .. 1, RA_VOICE_SWEEP 0 .. 1, RA_VOICE_WIND 0 .. 14; returns RA_EINVAL beyond.  `name` (may be NULL) receives the program's name. */
 int ra_voice_program(int32_t mode, int32_t index, ra_voice_config *cfg, const char **name);
+/* host-only (no GPU): the pink-noise sound buffer WIND's voices and controls read (getPinkNoise, source/sound.cpp:7-10; include/noise.h:82-165)
+ * over the declared draws — returns its length, copies min(cap, length) samples to h_out (may be NULL), its abs mean to *abs_mean (may be
+ * NULL) — and the declared start position of one of a ramp's six iterators (0 long-term, 1 short-term, 2 / 3 band-pass centre / width,
+ * 4 / 5 band-reject centre / width; which: 0 initializeForRun, 1 set_sample_rate; include/sound.h:196-200) */
+int64_t ra_voice_pink_noise(int32_t sample_rate, double *h_out, int64_t cap, float *abs_mean);
+int32_t ra_voice_wind_start_position(uint64_t stream_seed, int64_t noteid, int32_t play, int32_t iterator, int32_t which, int64_t buffer_length);
 int ra_voice_create(const ra_voice_config *cfg, int32_t n_streams, int32_t device, ra_voice **out);
 void ra_voice_destroy(ra_voice *v);
 /* queue events (HOST pointer; per stream in non-decreasing sample order, not before the frames already processed) */

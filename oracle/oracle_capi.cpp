@@ -265,8 +265,12 @@ int32_t ora_voice_run(const ora_voice_params *p, const int64_t *ev_sample, const
 // ramp EnvelopeDone2 and no spec left), pan as float bits}.  Returns 0, or -1 when a capacity is too small / a note does not end in max_steps.
 int32_t ora_voice_trace(const ora_voice_params *p, const float *freqs, int32_t n_notes, int64_t max_steps, double *spec_d, int32_t *spec_i, float *spec_vol,
                         int64_t spec_cap, int64_t *played, int64_t played_cap, int64_t *note_info) {
+  // WIND: a spec plays for 2^30 steps and a note-off leaves the channel's ramp unfinished for good (the channel is lost): one channel per note,
+  // each note stepped for 2000 samples only; its "steps until finished" is reported as -1, its specs as {0, 0, INT_MAX / 2, 0} + the long-term
+  // iterator's interpolation
+  bool const wind = p->mode == VOICE_WIND;
   Stepper stepper;
-  VoiceSynth synth(1);
+  VoiceSynth synth(wind ? std::max(1, n_notes) : 1);
   synth.phase_policy = 1;
   VoiceInitializer init;
   init.p = *p;
@@ -280,7 +284,7 @@ int32_t ora_voice_trace(const ora_voice_params *p, const float *freqs, int32_t n
     trace.clear();
     Event on{EventType::NoteOn, i + 1, freqs[i], 1.f, 0};
     if (synth.onEvent(p->sample_rate, on, stepper) != onEventResult::OK) return -1;
-    VoiceElement &e = synth.channels[0].elem;
+    VoiceElement &e = synth.channels[wind ? static_cast<size_t>(i) : 0].elem;
     if (!e.setup_ok) return -1;
     int32_t const n_specs = e.ramp_specs.end;
     if (ns + n_specs > spec_cap) return -1;
@@ -288,6 +292,10 @@ int32_t ora_voice_trace(const ora_voice_params *p, const float *freqs, int32_t n
       auto const &sp = e.ramp_specs.a[s];
       spec_d[4 * ns + 0] = sp.ctrl.from; spec_d[4 * ns + 1] = sp.ctrl.to; spec_d[4 * ns + 2] = sp.ctrl.duration_in_samples; spec_d[4 * ns + 3] = sp.ctrl.cur_sample;
       spec_i[3 * ns + 0] = sp.ctrl.interp; spec_i[3 * ns + 1] = sp.silenceAfter ? 1 : 0; spec_i[3 * ns + 2] = 0;
+      if (wind) {
+        spec_d[4 * ns + 0] = spec_d[4 * ns + 1] = spec_d[4 * ns + 3] = 0; spec_d[4 * ns + 2] = sp.wctrl.get_duration_in_samples();
+        spec_i[3 * ns + 0] = sp.wctrl.ctrl.ctrl.it.interp;
+      }
       spec_vol[ns] = sp.vol;
     }
     int64_t k = 0;
@@ -297,6 +305,7 @@ int32_t ora_voice_trace(const ora_voice_params *p, const float *freqs, int32_t n
       bool busy = !e.ramp_specs.done();
       for (auto const &r : e.ramps) if (r.env.state != EnvelopeState::EnvelopeDone2) busy = true;
       if (!busy) break;
+      if (wind && k >= 2000) { k = -1; break; }
       if (k >= max_steps) return -1;
     }
     if (np + static_cast<int64_t>(trace.size()) > played_cap) return -1;

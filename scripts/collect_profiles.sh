@@ -42,7 +42,7 @@ if [ "$PART" = headline ]; then
     wc -c $OUT/bench.json
   fi
 else
-  NAMES=${@:-configs1 north_star stereo voc_fft voc_bank configs3 voice_sweep voice_birds voice_robots}
+  NAMES=${@:-configs1 north_star stereo voc_fft voc_bank configs3 voice_sweep voice_birds voice_robots voice_wind}
   cd /tmp && export TMPDIR=/tmp
   for w in $NAMES; do
     W=$OUT/workloads/$w

@@ -280,6 +280,23 @@ def deduce_notes(x, sr, half_window_size, stride, window_kind=0, cap=1 << 20):
     return st[:n], en[:n], fr[:n], am[:n]
 
 
+def pink_noise(sample_rate):
+    """The pink-noise sound buffer of gen.voice's WIND (getPinkNoise, source/sound.cpp:7-10; draws: the declared policy) and its abs mean."""
+    L = lib()
+    L.ora_pink_noise.restype = C.c_int64
+    am = C.c_float()
+    n = L.ora_pink_noise(C.c_int32(sample_rate), None, C.c_int64(0), C.byref(am))
+    out = np.zeros(n, np.float64)
+    L.ora_pink_noise(C.c_int32(sample_rate), _p(out), C.c_int64(n), C.byref(am))
+    return out, am.value
+
+
+def wind_start_position(key, noteid, play, it, which, size):
+    L = lib()
+    L.ora_wind_start_position.restype = C.c_int32
+    return L.ora_wind_start_position(C.c_uint64(key), C.c_int64(noteid), C.c_int32(play), C.c_int32(it), C.c_int32(which), C.c_int64(size))
+
+
 class OraVoiceParams(C.Structure):
     """Mirror of oracle/oracle_voice.hpp: ora_voice_params."""
     _fields_ = [("sample_rate", C.c_int32), ("n_channels", C.c_int32), ("length_ms", C.c_float), ("length_exponent", C.c_float),

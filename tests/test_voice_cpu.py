@@ -44,6 +44,37 @@ def test_note_expansion_equals_the_oracles_engine_for_the_reference_programs(api
         assert any(np.any(t["specs_i"][:, 0] != cfg.interpolation) or len(t["specs_d"]) > 2 for t in trace)
 
 
+@pytest.mark.parametrize("index", [0, 3, 11, 13])
+def test_wind_note_expansion(api, oracle, index):
+    # WIND (create_wind, soundengine.h:721-735): node 0's lambda takes a spec on ENTER and on LEAVE — one per step of the path — and sets the long-term
+    # iterator's interpolation; playNextSpec plays spec 0 in the first element step, for 2^30 - xfade steps (the oracle's engine is stepped for
+    # 2000 samples per note: the later plays, 2^30 steps apart, are the product's arithmetic alone)
+    cfg, name = api.voice_program(3, index, seed=5)
+    freqs = [220.0, 330.0, 1000.0]
+    trace = oracle.voice_trace(oracle.voice_params_from(cfg, 5), freqs)
+    xf = int(0.5 + cfg.xfade_length_seconds * cfg.sample_rate)
+    for i, (f, sv, t) in enumerate(zip(freqs, seeds_of(cfg, len(freqs)), trace)):
+        e = api.voice_expand_note(cfg, f, 5, sv, noteid=i + 1)
+        assert len(t["specs_d"]) == 6 and np.array_equal(e["specs_d"], t["specs_d"]) and np.all(e["specs_d"][:, 2] == 2 ** 30 - 1)
+        assert np.array_equal(e["specs_i"], t["specs_i"]) and np.all(e["specs_i"][:, 0] == cfg.interpolation)
+        assert len(t["played"]) == 1 and np.array_equal(e["played"][0, :3], t["played"][0]) and tuple(t["played"][0]) == (1, 2, 0)
+        assert e["played"][0, 3] == 2 ** 30 - xf and len(e["played"]) == 6 and np.all(np.diff(e["played"][:, 0]) == 2 ** 30 - xf)
+        assert e["gain_left"] == t["gain_left"]
+
+
+def test_wind_pink_noise_and_start_positions_equal_the_oracles(api, oracle):
+    # the product's own restatement of the pink-noise sound buffer (ra_voice_host.hpp) against the oracle's (oracle_wind.hpp): every sample, the abs mean;
+    # the declared start positions of a ramp's iterators
+    for sr in (48000, 44100):
+        a, am = api.voice_pink_noise(sr)
+        b, bm = oracle.pink_noise(sr)
+        assert len(a) == int(np.float32(sr) / np.float32(0.05)) and np.array_equal(a, b) and am == bm
+    rng = np.random.default_rng(4)
+    for _ in range(200):
+        key, noteid, play, it, which = int(rng.integers(1, 1 << 62)), int(rng.integers(1, 1 << 40)), int(rng.integers(0, 30)), int(rng.integers(0, 6)), int(rng.integers(0, 2))
+        assert api.voice_wind_start_position(key, noteid, play, it, which, 960000) == oracle.wind_start_position(key, noteid, play, it, which, 960000)
+
+
 def test_note_expansion_over_random_programs(api, oracle):
     rng = np.random.default_rng(2024)
     long_lists = skipped = waits = 0
