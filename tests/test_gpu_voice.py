@@ -130,6 +130,26 @@ def test_wind_variants(api, oracle, kw, monkeypatch):
     check_against_oracle(api, oracle, cfg, rows, S, n, (n // 2 + 1, n - n // 2 - 1), 77, min_rms=1e-9, rel_bar=1e-5)
 
 
+def test_wind_block_and_chunk_cuts_do_not_show(api, monkeypatch):
+    # 64 synths x 3 held notes of "Bubbles" (order 129: five waves per band-pass chain) over one second: one block = ragged blocks = chunks of 4160 frames,
+    # bit for bit (a noise voice's arithmetic does not depend on where a batch of 64 steps starts); synth s is not synth 0 (its own draws)
+    cfg, _ = api.voice_program(api.VOICE_WIND, 9, seed=5, n_channels=4)
+    S, n = 64, 48000
+    rows = [(100 * k + 3 * s, s, 0, 3 * s + k + 1, 300.0 + 50 * k, 0.7) for s in range(S) for k in range(3)]
+    rows.sort(key=lambda r: (r[1], r[0]))
+
+    def run(cuts):
+        with api.Voice(cfg, S, 0) as v:
+            v.events(rows)
+            return np.concatenate([v.process(m) for m in cuts], axis=1)
+    whole = run((n,))
+    assert np.sqrt(np.mean(whole.astype(np.float64) ** 2)) > 1e-5
+    assert np.array_equal(whole, run((1, 777, 64, 20000, n - 20842)))
+    monkeypatch.setenv("RA_WIND_CHUNK", "4160")
+    assert np.array_equal(whole, run((n,)))
+    assert not np.array_equal(whole[0], whole[1])
+
+
 def test_wind_is_band_limited_noise(api):
     # "Steady wind": pink noise through an order-4 band-pass whose centre stays within 10 Hz * 2^5.2 .. 2^5.5 (368 .. 453 Hz), 1.3 octaves either side:
     # the spectrum peaks there and falls off on both sides; the level follows the attack of the cross-fade envelope
