@@ -2367,6 +2367,7 @@ int voice_wind_setup(ra_voice *v) {
   w.short_amplitude = c.center_short_term_ratio;
   w.interp_long = c.interpolation;
   const size_t slots = (size_t)v->n_streams * (size_t)c.n_channels * 3;
+  if (v->n_streams > 65535 || slots > (size_t)INT32_MAX) return fail(RA_EINVAL, "WIND: at most 65535 streams per object (the mix kernel's grid)");
   HIP_TRY(hipMalloc(reinterpret_cast<void **>(&v->d_pink), sizeof(double) * pink.values.size()));
   HIP_TRY(hipMemcpy(v->d_pink, pink.values.data(), sizeof(double) * pink.values.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc(reinterpret_cast<void **>(&v->d_wstates), sizeof(RaWindState) * slots));

@@ -13,6 +13,11 @@ __device__ inline double wave_shr1_f64(double own, double v) { // lane l takes l
   const int hi = __builtin_amdgcn_update_dpp(__double2hiint(own), __double2hiint(v), 0x138, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
+__device__ inline double wave_shl1_f64(double own, double v) { // lane l takes lane l + 1's v (DPP wave_shl:1), lane 63 keeps `own`
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(own), __double2loint(v), 0x130, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(own), __double2hiint(v), 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
 __device__ inline double lane_xor32_low(double x) { // value of lane ^ 32, valid in lanes 0..31
   const unsigned lo = __double2loint(x), hi = __double2hiint(x);
   const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);

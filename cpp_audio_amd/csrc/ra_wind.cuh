@@ -206,18 +206,42 @@ __global__ void __launch_bounds__(64) ra_wind_ctl_kernel(RaVoiceParams vp, RaWin
 // lane 0 of wave w + 1 reads into a ring in LDS, and wave w + 1 runs two batches of 64 steps behind wave w (lane 63 of a wave finishes a sample 63
 // steps after lane 0 started it), one workgroup barrier per batch.  (r04's first version kept several sections per lane in one wave: a step's
 // instructions then form one dependent chain on a SIMD with nothing else to issue — 460 cycles per step at three sections per lane.)
-// A step of the steady state: two DPP moves, subtract / multiply / add, sign flip + multiply-add for the output, two LDS reads at immediate
-// offsets, and four lane moves that collect the tap lane's output into lane tt of a register the wave stores once per batch.
+// A step of the steady state: two DPP moves for the input, subtract / multiply / add, the output (nothing for a wave of low-pass sections, a subtraction
+// for a wave of high-pass sections), two LDS reads at immediate offsets, and two DPP moves of a second shift register that collects lane 63's outputs
+// for one store per batch (a readlane / writelane pair per word cost twice that and SGPR hazards).
 // LDS per wave, in doubles: two coefficient rings and the input ring (wave 0: the noise) of 128 samples, the output ring of 256 (a wave reads its input
 // two batches after the wave before wrote it); every ring is followed by a copy of its first 64 entries, so that the 65 entries a lane reads during
 // a batch are contiguous wherever they start: one address per batch and immediate offsets, instead of three address instructions per read.
 constexpr int kWindRing = 128 + 64, kWindLink = 256 + 64, kWindWaveLds = 3 * kWindRing + kWindLink;
+static_assert(kWindLink >= kWindRing && 9 * kWindWaveLds * 8 <= 65536, "nine waves (order 258) within the default 64 KB of dynamic LDS");
 __device__ inline void wind_ring_put(double *ring, int size, int i, double v) { ring[i] = v; if (i < 64) ring[i + size] = v; }
 __device__ inline double wind_fma3(double a, double b, double c) { // a b + c as the three-address instruction
   double d;
   asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
+// 64 steps of a wave in the steady state (every lane has a sample in every step).  KIND: 0 = every lane a low-pass section (output y), 1 = every lane a
+// high-pass section or one of the last wave's leading pass-through lanes (output x - y), 2 = both kinds in the wave (output fma(hm, x, -+y): exact either way).
+// The tap is lane 63: its outputs are collected by a second shift register running the other way (wave_shl: lane l takes lane l + 1's, lane 63 its own
+// new output), so that after the 64 steps lane tt holds step tt's.
+template <int KIND>
+__device__ inline double wind_chain_batch(const double *__restrict__ pc, const double *__restrict__ px0, double &y, double &xout, double hm, int sgn) {
+  double collected = 0.0;
+  double c = pc[0], x0 = px0[0];
+#pragma unroll
+  for (int tt = 0; tt < 64; ++tt) {
+    const double c_n = pc[tt + 1], x0_n = px0[tt + 1]; // (one step ahead; entry 64 is read and never used)
+    const double x = wave_shr1_f64(x0, xout);
+    y = y + c * (x - y); // s = s + k (x - s), the operations of the restatement
+    if (KIND == 0) xout = y;
+    else if (KIND == 1) xout = x - y;
+    else xout = wind_fma3(hm, x, __hiloint2double(__double2hiint(y) ^ sgn, __double2loint(y)));
+    collected = wave_shl1_f64(xout, collected);
+    c = c_n; x0 = x0_n;
+  }
+  return collected;
+}
+
 __global__ void __launch_bounds__(576) ra_wind_chain_kernel(RaWindParams wp, const RaWindJob *__restrict__ jobs, const double *__restrict__ pink, double *__restrict__ fstates,
                                                              RaWindScratch sc, int c0, int clen, int chain0) {
   double *wsm = reinterpret_cast<double *>(ra_smem_voice);
@@ -235,19 +259,25 @@ __global__ void __launch_bounds__(576) ra_wind_chain_kernel(RaWindParams wp, con
   const int j_lo = J.j0 + (lo - J.begin);
   const bool fresh = j_lo == 1; // Filter::forgetPastSignals: the sections start at 0
   double *ring_a = wsm + (size_t)w * kWindWaveLds, *ring_b = ring_a + kWindRing, *ring_x = ring_b + kWindRing, *link_out = ring_x + kWindRing;
+  double *zeros = wsm + (size_t)(W - 1) * kWindWaveLds + 3 * kWindRing; // kWindRing zeros, the "coefficients" of the pass-through lanes: in the last wave's output ring, which it does not use
   const double *xin = w == 0 ? ring_x : link_out - kWindWaveLds; // lane 0's input: the noise, or what the wave before hands on
   const int xmask = w == 0 ? 127 : 255;
-  const int sidx = 64 * w + l;
-  const bool on = sidx < L, hp = sidx >= ns, last = w == W - 1;
+  // The last wave holds its sections in its LAST lanes, so that every wave's output leaves at lane 63; the lanes before them pass their input on unchanged:
+  // a high-pass section whose coefficient and state are 0 does exactly that (y = 0 + 0 (x - 0) = 0, output x - 0).
+  const bool last = w == W - 1;
+  const int lead = last ? 64 * W - L : 0;
+  const int sidx = 64 * w + l - lead;
+  const bool on = l >= lead, hp = !on || sidx >= ns;
   double y = (on && !fresh) ? fs[sidx] : 0.0;
-  const double *rk = hp ? ring_b : ring_a;
-  const double hm = hp ? 1.0 : 0.0;                 // the section's output: y (low-pass) or x - y (high-pass) = fma(hm, x, -+y): exact either way
+  const double *rk = !on ? zeros : (hp ? ring_b : ring_a);
+  const double hm = hp ? 1.0 : 0.0;
   const int sgn = hp ? (int)0x80000000 : 0;
-  const int tap = last ? (L - 1 - 64 * w) : 63;     // the lane whose output leaves the wave (lanes beyond the chain's end work on what nobody reads)
+  const int kind = __ballot(hp) == 0ull ? 0 : (__ballot(!hp) == 0ull ? 1 : 2);
   const int total = cnt + 63, nb = (total + 63) / 64;
   // the noise wrapper's index at step j: pink_start + j (soundBufferWrapperAlgo::step, audioelement.h:1568-1574); lane l of wave 0 stages sample tau0 + l
   int px = (int)(((long long)wp.pink_start + j_lo + l) % len);
   double xout = 0.0; // what this lane handed on in the previous step
+  if (last) for (int i = l; i < kWindRing; i += 64) zeros[i] = 0.0;
   for (int b = 0; b < nb + 2 * (W - 1); ++b) {
     const int bl = b - 2 * w;
     const bool mine = bl >= 0 && bl < nb;
@@ -266,24 +296,11 @@ __global__ void __launch_bounds__(576) ra_wind_chain_kernel(RaWindParams wp, con
     const double *pc = rk + ((tau0 - l) & 127);   // the lane's coefficient of step tau0 + tt: pc[tt]
     const double *px0 = xin + (tau0 & xmask);     // lane 0's input of step tau0 + tt: px0[tt]
     if (tau0 >= 63 && tau0 + 64 <= cnt) { // every lane has a sample in every step of this batch
-      double collected = 0.0; // lane tt: what the tap lane put out in step tt
-      double c = pc[0], x0 = px0[0];
-#pragma unroll
-      for (int tt = 0; tt < 64; ++tt) {
-        const double c_n = pc[tt + 1], x0_n = px0[tt + 1]; // (one step ahead: an LDS round trip is as long as a step's arithmetic; entry 64 of the last step is never used)
-        const double x = wave_shr1_f64(x0, xout);
-        y = y + c * (x - y); // s = s + k (x - s), the operations of the restatement
-        xout = wind_fma3(hm, x, __hiloint2double(__double2hiint(y) ^ sgn, __double2loint(y)));
-        {
-          const int lo32 = __builtin_amdgcn_readlane(__double2loint(xout), tap), hi32 = __builtin_amdgcn_readlane(__double2hiint(xout), tap);
-          int clo = __double2loint(collected), chi = __double2hiint(collected);
-          asm("v_writelane_b32 %0, %1, %2" : "+v"(clo) : "s"(lo32), "i"(tt));
-          asm("v_writelane_b32 %0, %1, %2" : "+v"(chi) : "s"(hi32), "i"(tt));
-          collected = __hiloint2double(chi, clo);
-        }
-        c = c_n; x0 = x0_n;
-      }
-      const int t = tau0 + l - tap; // the sample lane l's collected value belongs to
+      double collected;
+      if (kind == 0) collected = wind_chain_batch<0>(pc, px0, y, xout, hm, sgn);
+      else if (kind == 1) collected = wind_chain_batch<1>(pc, px0, y, xout, hm, sgn);
+      else collected = wind_chain_batch<2>(pc, px0, y, xout, hm, sgn);
+      const int t = tau0 + l - 63; // the sample lane l's collected value belongs to
       if (last) out[t] = collected;
       else wind_ring_put(link_out, 256, t & 255, collected);
     } else {
@@ -296,7 +313,7 @@ __global__ void __launch_bounds__(576) ra_wind_chain_kernel(RaWindParams wp, con
         const double yn = y + c * (x - y);
         y = act ? yn : y;
         xout = fma(hm, x, __hiloint2double(__double2hiint(yn) ^ sgn, __double2loint(yn)));
-        if (act && l == tap) { if (last) out[t] = xout; else wind_ring_put(link_out, 256, t & 255, xout); }
+        if (act && l == 63) { if (last) out[t] = xout; else wind_ring_put(link_out, 256, t & 255, xout); }
       }
     }
   }
