@@ -2169,6 +2169,8 @@ struct ra_voice {
   RaWindJob *d_wjobs = nullptr;
   int32_t *d_wstream_begin = nullptr;
   int64_t wjobs_cap = 0, wsb_cap = 0, wscratch_cap = 0;
+  hipStream_t wind_stream = nullptr;                 // the controls' queue
+  hipEvent_t ev_wctl[2] = {nullptr, nullptr}, ev_wchain[2] = {nullptr, nullptr}, ev_wblock = nullptr;
 };
 
 namespace {
@@ -2366,6 +2368,8 @@ int voice_wind_setup(ra_voice *v) {
   w.short_rate = static_cast<float>(static_cast<int>(n_slow_steps_short));     // set_short_term_noise_rate(float) fed the int
   w.short_amplitude = c.center_short_term_ratio;
   w.interp_long = c.interpolation;
+  HIP_TRY(hipStreamCreateWithFlags(&v->wind_stream, hipStreamNonBlocking));
+  for (auto *e : {&v->ev_wctl[0], &v->ev_wctl[1], &v->ev_wchain[0], &v->ev_wchain[1], &v->ev_wblock}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
   const size_t slots = (size_t)v->n_streams * (size_t)c.n_channels * 3;
   if (v->n_streams > 65535 || slots > (size_t)INT32_MAX) return fail(RA_EINVAL, "WIND: at most 65535 streams per object (the mix kernel's grid)");
   HIP_TRY(hipMalloc(reinterpret_cast<void **>(&v->d_pink), sizeof(double) * pink.values.size()));
@@ -2451,6 +2455,8 @@ void ra_voice_destroy(ra_voice *v) {
   }
   for (int i = 0; i < 3; ++i) (void)hipFree(v->d_states[i]);
   (void)hipFree(v->d_seg);
+  if (v->wind_stream) (void)hipStreamDestroy(v->wind_stream);
+  for (auto e : {v->ev_wctl[0], v->ev_wctl[1], v->ev_wchain[0], v->ev_wchain[1], v->ev_wblock}) if (e) (void)hipEventDestroy(e);
   (void)hipFree(v->d_pink); (void)hipFree(v->d_wfstates); (void)hipFree(v->d_wscratch); (void)hipFree(v->d_wstates); (void)hipFree(v->d_wjobs); (void)hipFree(v->d_wstream_begin);
   if (v->pre_stream) (void)hipStreamDestroy(v->pre_stream);
   for (auto &s : v->staging) { if (s.h) (void)hipHostFree(s.h); if (s.done) (void)hipEventDestroy(s.done); }
@@ -2472,6 +2478,7 @@ int ra_voice_synchronize(ra_voice *v) {
   if (!v) return fail(RA_EINVAL, "null context");
   HIP_TRY(hipSetDevice(v->device));
   HIP_TRY(hipStreamSynchronize(v->pre_stream));
+  if (v->wind_stream) HIP_TRY(hipStreamSynchronize(v->wind_stream));
   HIP_TRY(hipStreamSynchronize(v->stream));
   return RA_OK;
 }
@@ -2689,7 +2696,8 @@ void *voice_stage(ra_voice *v, size_t bytes, int &err) { // the pinned staging b
 }
 
 // A WIND block after the streams' events and jobs: the jobs go up through the staging buffer, then controls -> filter chains -> mix per chunk of
-// the block (ra_wind_launch), everything on the caller's stream.  The chunk length keeps the scratch (up to 8 doubles per job and frame) near 1 GiB.
+// the block; the controls on a queue of the object's own, one chunk ahead of the chains and the mix on the caller's stream.  The chunk length keeps the scratch
+// (up to 13 doubles per job and frame) near 1.5 GiB.
 int voice_wind_block(ra_voice *v, int64_t n, float *d_out) {
   const int S = v->n_streams;
   int64_t n_jobs = 0;
@@ -2716,22 +2724,32 @@ int voice_wind_block(ra_voice *v, int64_t n, float *d_out) {
     v->stage_parity ^= 1;
   }
   const RaWindParams &w = v->wp;
-  const int arrays = (w.g_bp != 0.f ? 3 : 0) + (w.g_br != 0.f ? 4 : 0) + (w.g_sine != 0.f ? 1 : 0);
-  int64_t ch = (int64_t(1) << 30) / (std::max<int64_t>(1, n_jobs) * std::max(1, arrays) * 8);
+  // scratch per job and frame: what the controls write (two coefficients per band, the sine's output) exists twice — the controls of chunk k + 1 run on their
+  // own queue beside the chains of chunk k, a latency-bound kernel of one wave per job beside an issue-bound one —, the chains' outputs once
+  const int n_ctl = (w.g_bp != 0.f ? 2 : 0) + (w.g_br != 0.f ? 2 : 0) + (w.g_sine != 0.f ? 1 : 0), n_out = (w.g_bp != 0.f ? 1 : 0) + (w.g_br != 0.f ? 2 : 0);
+  const int arrays = std::max(1, 2 * n_ctl + n_out);
+  const int64_t jobs1 = std::max<int64_t>(1, n_jobs);
+  int64_t ch = (int64_t(3) << 29) / (jobs1 * arrays * 8); // ~1.5 GiB
   ch = std::max<int64_t>(4096, ch);
   if (const char *e = std::getenv("RA_WIND_CHUNK")) ch = std::max(64, std::atoi(e)); // (tests: a ramp's state across chunk boundaries)
   ch = std::min<int64_t>(ch, n);
-  RA_TRY(voice_grow(&v->d_wscratch, v->wscratch_cap, std::max<int64_t>(1, n_jobs) * std::max(1, arrays) * ch, v));
-  RaWindScratch sc;
-  std::memset(&sc, 0, sizeof(sc));
-  sc.stride = ch;
+  RA_TRY(voice_grow(&v->d_wscratch, v->wscratch_cap, jobs1 * arrays * ch, v));
+  RaWindScratch sc2[2];
   {
     double *q = v->d_wscratch;
-    const size_t each = (size_t)std::max<int64_t>(1, n_jobs) * (size_t)ch;
+    const size_t each = (size_t)jobs1 * (size_t)ch;
     auto take = [&] { double *r = q; q += each; return r; };
-    if (w.g_bp != 0.f) { sc.k_bp_lp = take(); sc.k_bp_hp = take(); sc.p_bp = take(); }
-    if (w.g_br != 0.f) { sc.k_br_lp = take(); sc.k_br_hp = take(); sc.p_br_lp = take(); sc.p_br_hp = take(); }
-    if (w.g_sine != 0.f) sc.p_sine = take();
+    double *p_bp = nullptr, *p_lp = nullptr, *p_hp = nullptr;
+    if (w.g_bp != 0.f) p_bp = take();
+    if (w.g_br != 0.f) { p_lp = take(); p_hp = take(); }
+    for (auto &sc : sc2) {
+      std::memset(&sc, 0, sizeof(sc));
+      sc.stride = ch;
+      sc.p_bp = p_bp; sc.p_br_lp = p_lp; sc.p_br_hp = p_hp;
+      if (w.g_bp != 0.f) { sc.k_bp_lp = take(); sc.k_bp_hp = take(); }
+      if (w.g_br != 0.f) { sc.k_br_lp = take(); sc.k_br_hp = take(); }
+      if (w.g_sine != 0.f) sc.p_sine = take();
+    }
   }
   ra_voice::Timed tm{nullptr, nullptr, nullptr, nullptr};
   if (v->profiling) {
@@ -2740,10 +2758,26 @@ int voice_wind_block(ra_voice *v, int64_t n, float *d_out) {
       if (!v->ev_pool.empty()) { *pe = v->ev_pool.back(); v->ev_pool.pop_back(); }
       else HIP_TRY(hipEventCreate(pe));
     }
-    HIP_TRY(hipEventRecord(tm.a, st)); HIP_TRY(hipEventRecord(tm.b, st)); HIP_TRY(hipEventRecord(tm.b2, st)); // (no pre-pass of its own: all of it counts as the render)
+    HIP_TRY(hipEventRecord(tm.a, st)); HIP_TRY(hipEventRecord(tm.b, st)); HIP_TRY(hipEventRecord(tm.b2, st)); // (reported as the render: the controls' queue runs inside this interval)
   }
-  for (int64_t c0 = 0; c0 < n; c0 += ch)
-    ra_wind_launch(v->p, w, v->d_wjobs, (int)n_jobs, v->d_wstream_begin, S, v->d_pink, v->d_wstates, v->d_wfstates, sc, (int)c0, (int)std::min<int64_t>(ch, n - c0), n, d_out, st);
+  // the controls' queue starts behind the job table's upload and behind whatever the caller's stream still does with the scratch (the last block's chains)
+  // ... when the chains run as scans (every chain within one wave): beside the wave pipelines of longer chains — issue-bound at 0.69 of the nominal rate —
+  // the controls only compete for the same issue slots (measured, order 129: 71 -> 80 ms per step with the second queue): one queue then
+  const bool scans = (w.g_bp == 0.f || 2 * w.order <= 64) && (w.g_br == 0.f || w.order <= 64);
+  static const bool one_queue = std::getenv("RA_WIND_ONE_QUEUE") != nullptr; // tuning aid
+  hipStream_t sc_q = (scans && !one_queue) ? v->wind_stream : st;
+  HIP_TRY(hipEventRecord(v->ev_wblock, st));
+  HIP_TRY(hipStreamWaitEvent(sc_q, v->ev_wblock, 0));
+  int k = 0;
+  for (int64_t c0 = 0; c0 < n; c0 += ch, ++k) {
+    const int clen = (int)std::min<int64_t>(ch, n - c0), q = k & 1;
+    if (k >= 2) HIP_TRY(hipStreamWaitEvent(sc_q, v->ev_wchain[q], 0)); // chunk k - 2's chains have read this half
+    ra_wind_launch_controls(v->p, w, v->d_wjobs, (int)n_jobs, v->d_pink, v->d_wstates, sc2[q], (int)c0, clen, sc_q);
+    HIP_TRY(hipEventRecord(v->ev_wctl[q], sc_q));
+    HIP_TRY(hipStreamWaitEvent(st, v->ev_wctl[q], 0));
+    ra_wind_launch_chains(w, v->d_wjobs, (int)n_jobs, v->d_wstream_begin, S, v->d_pink, v->d_wfstates, sc2[q], (int)c0, clen, n, d_out, st);
+    HIP_TRY(hipEventRecord(v->ev_wchain[q], st));
+  }
   HIP_TRY(hipGetLastError());
   if (v->profiling) { HIP_TRY(hipEventRecord(tm.c, st)); v->timed.push_back(tm); ++v->launches[0]; ++v->launches[1]; }
   ++v->host_blocks;

@@ -373,13 +373,15 @@ struct RaWindJob {               // one playing ramp inside one block
   int32_t stream, slot;          // slot: where the ramp's state lives ((stream * n_channels + channel) * 3 + ramp)
   int32_t pos[6][2];             // the declared start positions of the six iterators: initializeForRun's, set_sample_rate's
 };
-struct RaWindScratch {           // per chunk: [job][chunk frames] each; what is not needed is not allocated (nullptr)
+struct RaWindScratch {           // per chunk: [job][chunk frames] each; what is not needed is not allocated (nullptr); what the controls write exists twice (chunk k + 1 beside chunk k)
   double *k_bp_lp, *k_bp_hp, *k_br_lp, *k_br_hp; // the one-pole coefficients per sample
   double *p_bp, *p_br_lp, *p_br_hp, *p_sine;     // the voices' outputs per sample
   int64_t stride;                // frames per job
 };
-void ra_wind_launch(const RaVoiceParams &vp, const RaWindParams &wp, const RaWindJob *jobs, int n_jobs, const int32_t *stream_begin, int n_streams, const double *pink,
-                    RaWindState *states, double *fstates, const RaWindScratch &sc, int c0, int clen, int64_t n, float *d_out, hipStream_t st);
+void ra_wind_launch_controls(const RaVoiceParams &vp, const RaWindParams &wp, const RaWindJob *jobs, int n_jobs, const double *pink, RaWindState *states, const RaWindScratch &sc, int c0,
+                             int clen, hipStream_t st);
+void ra_wind_launch_chains(const RaWindParams &wp, const RaWindJob *jobs, int n_jobs, const int32_t *stream_begin, int n_streams, const double *pink, double *fstates,
+                           const RaWindScratch &sc, int c0, int clen, int64_t n, float *d_out, hipStream_t st);
 
 // Profiling (ra_set_profiling): the two throughput kernels are timed by the launch itself — hipExtLaunchKernelGGL stamps a start and a stop event with
 // the dispatch's own begin and end, the interval rocprofv3 reports — instead of by an event pair around the launch, which also spans the wait of

@@ -426,16 +426,30 @@ __global__ void __launch_bounds__(MAXT) ra_voice_render_kernel(RaVoiceParams p, 
 
 } // namespace
 
-// One chunk [c0, c0 + clen) of a WIND block: controls (+ sine), the filter chains, the mix (ra_wind.cuh).
-void ra_wind_launch(const RaVoiceParams &vp, const RaWindParams &wp, const RaWindJob *jobs, int n_jobs, const int32_t *stream_begin, int n_streams, const double *pink,
-                    RaWindState *states, double *fstates, const RaWindScratch &sc, int c0, int clen, int64_t n, float *d_out, hipStream_t st) {
+// One chunk [c0, c0 + clen) of a WIND block in two halves, so that the host can run the controls of chunk k + 1 on a queue of their own beside the filter
+// chains of chunk k (ra_wind.cuh): the controls (+ the sine voice) write the coefficients and the sine's output; the chains and the mix read them.
+void ra_wind_launch_controls(const RaVoiceParams &vp, const RaWindParams &wp, const RaWindJob *jobs, int n_jobs, const double *pink, RaWindState *states, const RaWindScratch &sc, int c0,
+                             int clen, hipStream_t st) {
+  if (clen <= 0 || n_jobs <= 0) return;
+  hipLaunchKernelGGL(ra_wind_ctl_kernel, dim3((unsigned)n_jobs, 3), dim3(64), 0, st, vp, wp, jobs, pink, states, sc, c0, clen);
+}
+void ra_wind_launch_chains(const RaWindParams &wp, const RaWindJob *jobs, int n_jobs, const int32_t *stream_begin, int n_streams, const double *pink, double *fstates,
+                           const RaWindScratch &sc, int c0, int clen, int64_t n, float *d_out, hipStream_t st) {
   if (clen <= 0) return;
   if (n_jobs > 0) {
-    hipLaunchKernelGGL(ra_wind_ctl_kernel, dim3((unsigned)n_jobs, 3), dim3(64), 0, st, vp, wp, jobs, pink, states, sc, c0, clen);
-    auto chains = [&](int first, int count, int sections) { // a wave per 64 sections (<= 516 sections: nine waves)
-      const int waves = (sections + 63) / 64;
-      hipLaunchKernelGGL(ra_wind_chain_kernel, dim3((unsigned)n_jobs, (unsigned)count), dim3((unsigned)(64 * waves)), (size_t)waves * kWindWaveLds * sizeof(double), st, wp, jobs, pink,
-                         fstates, sc, c0, clen, first);
+    static const int forced_m = std::getenv("RA_WIND_SECTIONS_PER_LANE") ? std::atoi(std::getenv("RA_WIND_SECTIONS_PER_LANE")) : 0; // tuning aid
+    static const bool no_scan = std::getenv("RA_WIND_NO_SCAN") != nullptr; // tuning aid: the wave pipeline for short chains too
+    auto chains = [&](int first, int count, int sections) {
+      const dim3 grid((unsigned)n_jobs, (unsigned)count);
+      // A chain that fits one wave runs as scans over time (ra_wind_scan_kernel).  Longer ones as a pipeline of waves, one section per lane while that keeps a
+      // SIMD's few waves busy: a step's instructions are one dependent chain, and with two sections per lane the chain is twice as long (measured at 1024 ramps
+      // of 178 sections: 3.6 ms per chunk against 4.7; at 4096 ramps two per lane win by 5 %).  Orders above 160 need two per lane (five waves of LDS rings).
+      const int w1 = (sections + 63) / 64, w2 = (sections + 127) / 128;
+      const bool two = forced_m ? forced_m == 2 : (sections > 320 || (long long)n_jobs * count * w2 >= 8192);
+      if (sections <= 64 && !no_scan) hipLaunchKernelGGL(ra_wind_scan_kernel, grid, dim3(64), 0, st, wp, jobs, pink, fstates, sc, c0, clen, first);
+      else if ((!two || sections <= 64) && sections <= 320)
+        hipLaunchKernelGGL(ra_wind_chain_kernel<1>, grid, dim3((unsigned)(64 * w1)), (size_t)w1 * kWindWaveLds * sizeof(double), st, wp, jobs, pink, fstates, sc, c0, clen, first);
+      else hipLaunchKernelGGL(ra_wind_chain_kernel<2>, grid, dim3((unsigned)(64 * w2)), (size_t)w2 * kWindWaveLds * sizeof(double), st, wp, jobs, pink, fstates, sc, c0, clen, first);
     };
     if (wp.g_bp != 0.f) chains(0, 1, 2 * wp.order);
     if (wp.g_br != 0.f) chains(1, 2, wp.order);

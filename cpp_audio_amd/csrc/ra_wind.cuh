@@ -42,24 +42,45 @@ __device__ inline float wind_interp(int kind, int slow, int n, float prev, float
 // lane q holds the piece between window samples q - 1 and q (lane 0: the piece under way), an inclusive scan of the lengths says in which step each
 // piece ends, the steps with a major become a 64-bit mask, and a sample's piece is the number of majors before it (one mbcnt).
 // (A piece-by-piece walk cost ~25 dependent instructions per piece — with pieces of four samples most of the controls' time.)
-__device__ inline float wind_iter_batch(RaWindIter &s, int kind, const double *__restrict__ pink, int len, int cnt, int lane, int *lds64) {
+// The window comes out of a stretch of |pink| the wave keeps in LDS (kWindWin samples from position `wbase` on) and refills when the iterator has moved past
+// it: the iterator's next position depends on this batch, so a fetch from memory per batch would be a serial round trip (it was: ~1 of 1.6 us per batch).
+constexpr int kWindWin = 512;
+struct WindWin { float *v; int base; }; // base < 0: nothing loaded yet
+__device__ inline float wind_iter_batch(RaWindIter &s, int kind, const double *__restrict__ pink, int len, int cnt, int lane, int *lds64, WindWin &win) {
   float w0, w1; // the window: sample lane and sample 64 + lane after the iterator's position
   {
-    int p0 = s.pos + lane;
-    p0 = p0 >= len ? p0 - len : p0;
-    int p1 = p0 + 64;
-    p1 = p1 >= len ? p1 - len : p1;
-    w0 = wind_abs(pink[p0]); w1 = wind_abs(pink[p1]);
+    int rel = s.pos - win.base;
+    rel = rel < 0 ? rel + len : rel;
+    if (win.base < 0 || rel + 128 > kWindWin) { // (uniform) refill from the iterator's position on
+      __syncthreads();
+      for (int i = lane; i < kWindWin; i += 64) {
+        int p = s.pos + i;
+        p = p >= len ? p - len : p;
+        win.v[i] = wind_abs(pink[p]);
+      }
+      win.base = s.pos;
+      rel = 0;
+      __syncthreads();
+    }
+    w0 = win.v[rel + lane]; w1 = win.v[rel + 64 + lane];
   }
   const float w64 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w1), 0));
   // piece q = lane: from prev_q to next_q
-  const float below = __shfl_up(w0, 1);
+  const float below = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(w0), 0x138, 0xf, 0xf, false)); // lane l - 1's (wave_shr:1)
   const float prev_q = lane == 0 ? s.prev : below, next_q = w0;
   const int rate_q = (prev_q > next_q) ? 1 : 3;
   const int len_q = max(1, ((lane == 0 ? s.n - s.slow : s.n) + rate_q - 1) / rate_q);
-  int end_q = len_q; // the step (1-based) of the piece's major
-#pragma unroll
-  for (int k = 0; k < 6; ++k) { const int t = __shfl_up(end_q, 1 << k); if (lane >= (1 << k)) end_q += t; }
+  // the step (1-based) of the piece's major: an inclusive scan of the lengths — rows of 16 lanes by DPP row shifts (lanes short of a source add 0), the rows'
+  // totals through scalar registers (six rounds of ds_bpermute were ~700 cycles of dependent LDS round trips per batch on a lone wave)
+  int end_q = len_q;
+  end_q += __builtin_amdgcn_update_dpp(0, end_q, 0x111, 0xf, 0xf, true);
+  end_q += __builtin_amdgcn_update_dpp(0, end_q, 0x112, 0xf, 0xf, true);
+  end_q += __builtin_amdgcn_update_dpp(0, end_q, 0x114, 0xf, 0xf, true);
+  end_q += __builtin_amdgcn_update_dpp(0, end_q, 0x118, 0xf, 0xf, true);
+  {
+    const int r0 = __builtin_amdgcn_readlane(end_q, 15), r1 = __builtin_amdgcn_readlane(end_q, 31), r2 = __builtin_amdgcn_readlane(end_q, 47);
+    end_q += lane >= 48 ? r0 + r1 + r2 : (lane >= 32 ? r0 + r1 : (lane >= 16 ? r0 : 0));
+  }
   __syncthreads();
   lds64[lane] = 0;
   __syncthreads();
@@ -108,6 +129,8 @@ __global__ void __launch_bounds__(64) ra_wind_ctl_kernel(RaVoiceParams vp, RaWin
                                                           RaWindState *__restrict__ states, RaWindScratch sc, int c0, int clen) {
   __shared__ float lf[29], le[29];
   __shared__ int flags[64];
+  __shared__ float windows[2][kWindWin];
+  WindWin win0{windows[0], -1}, win1{windows[1], -1};
   load_tables(vp, lf, le);
   const int ji = blockIdx.x, role = blockIdx.y, lane = threadIdx.x;
   if ((role == 0 && wp.g_sine == 0.f) || (role == 1 && wp.g_bp == 0.f) || (role == 2 && wp.g_br == 0.f)) return; // Mix::imag: 0 * (a finite voice)
@@ -122,13 +145,13 @@ __global__ void __launch_bounds__(64) ra_wind_ctl_kernel(RaVoiceParams vp, RaWin
   if (role != 0) {
     // BandAlgo_::step (audioelement.h:2283-2300) under FreqCtrl_::step: the centre from the band's SoundEngineFreqCtrl, the width from its Ctrl
     const int ic = 2 * role, iw = 2 * role + 1;
-    RaWindIter c = fresh ? wind_iter_fresh(J.pos[ic], wp.n_band, pink, true) : S->it[ic];
-    RaWindIter w = fresh ? wind_iter_fresh(J.pos[iw], wp.n_band, pink, true) : S->it[iw];
+    RaWindIter c = fresh ? wind_iter_fresh(jobs[ji].pos[ic], wp.n_band, pink, true) : S->it[ic];
+    RaWindIter w = fresh ? wind_iter_fresh(jobs[ji].pos[iw], wp.n_band, pink, true) : S->it[iw];
     double *k_lp = (role == 1 ? sc.k_bp_lp : sc.k_br_lp) + base, *k_hp = (role == 1 ? sc.k_bp_hp : sc.k_br_hp) + base;
     for (int b0 = 0; b0 < cnt; b0 += 64) {
       const int c64 = min(64, cnt - b0);
-      const float vc = wind_iter_batch(c, RA_ITP_LINEAR, pink, len, c64, lane, flags);
-      const float vw = wind_iter_batch(w, RA_ITP_LINEAR, pink, len, c64, lane, flags);
+      const float vc = wind_iter_batch(c, RA_ITP_LINEAR, pink, len, c64, lane, flags, win0);
+      const float vw = wind_iter_batch(w, RA_ITP_LINEAR, pink, len, c64, lane, flags, win1);
       if (lane < c64) {
         const double increment = (double)wind_center_inc(wp, vc);
         const float at = wp.width_min + fabsf(vw) * (wp.width_max - wp.width_min); // range<float>::getAt
@@ -144,8 +167,8 @@ __global__ void __launch_bounds__(64) ra_wind_ctl_kernel(RaVoiceParams vp, RaWin
     return;
   }
   // ShortTermNoiseAdderCtrl::step (soundengine.h:139-149), then LoudnessVolumeAdjusted<SineOscillatorAlgo> as the other modes run it
-  RaWindIter lg = fresh ? wind_iter_fresh(J.pos[0], wp.n_long, pink, true) : S->it[0];
-  RaWindIter sh = fresh ? wind_iter_fresh(J.pos[1], -1, pink, false) : S->it[1];
+  RaWindIter lg = fresh ? wind_iter_fresh(jobs[ji].pos[0], wp.n_long, pink, true) : S->it[0];
+  RaWindIter sh = fresh ? wind_iter_fresh(jobs[ji].pos[1], -1, pink, false) : S->it[1];
   double theta = fresh ? 0.0 : S->theta, y = fresh ? 0.0 : S->y;
   Ramp r;
   r.loud_k = fresh ? 14 : S->loud_k;
@@ -155,27 +178,49 @@ __global__ void __launch_bounds__(64) ra_wind_ctl_kernel(RaVoiceParams vp, RaWin
   const bool short_term = wp.short_amplitude != 0.f; // 2^(0 x) = 1: the short-term iterator's walk decides nothing
   for (int b0 = 0; b0 < cnt; b0 += 64) {
     const int c64 = min(64, cnt - b0);
-    const float vl = wind_iter_batch(lg, wp.interp_long, pink, len, c64, lane, flags);
+    const float vl = wind_iter_batch(lg, wp.interp_long, pink, len, c64, lane, flags, win0);
     const float long_inc = wind_center_inc(wp, vl);
     float inc_f = long_inc;
     if (short_term) {
-      float mine = 0.f;
-      for (int i = 0; i < c64; ++i) { // SlowIter<PinkNoiseIter>: set_n_slow_steps (:2862-2877), ++, * — the same in every lane
-        const float li = __shfl(long_inc, i);
+      // SlowIter<PinkNoiseIter>: set_n_slow_steps (:2862-2877), ++, * — a serial walk, the same in every lane, over samples the lanes fetched beforehand (the
+      // buffer moves on by at most two samples per step); lane i keeps step i's (slow_it, n_steps, prev, next) and the interpolations follow in parallel
+      float b0v, b1v, b2v;
+      {
+        int p = sh.pos + lane;
+        p = p >= len ? p - len : p;
+        b0v = (float)pink[p];
+        p += 64; p = p >= len ? p - len : p;
+        b1v = (float)pink[p];
+        p += 64; p = p >= len ? p - len : p;
+        b2v = (float)pink[p];
+      }
+      auto at = [&](int rel) { // sample `rel` (uniform) after the batch's first position
+        const int u = __builtin_amdgcn_readfirstlane(rel);
+        const int a0 = __builtin_amdgcn_readlane(__float_as_int(b0v), u & 63), a1 = __builtin_amdgcn_readlane(__float_as_int(b1v), u & 63),
+                  a2 = __builtin_amdgcn_readlane(__float_as_int(b2v), u & 63);
+        return __int_as_float(u < 64 ? a0 : (u < 128 ? a1 : a2));
+      };
+      int rel = 0, m_slow = 0, m_n = 1;
+      float m_prev = 0.f, m_next = 0.f;
+      for (int i = 0; i < c64; ++i) {
+        const float li = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(long_inc), i));
         const int n = (int)(1 + wp.short_rate / li);
         if (n != sh.n) {
           if (sh.slow) {
             const float ratio = (sh.slow + .5f) / (float)sh.n;
             sh.slow = (int)(ratio * (float)n);
-            if (sh.slow == n) { sh.slow = 0; sh.prev = (float)pink[sh.pos]; sh.pos = wind_wrap(sh.pos + 1, len); }
+            if (sh.slow == n) { sh.slow = 0; sh.prev = at(rel); ++rel; }
           }
           sh.n = n;
         }
         ++sh.slow;
-        if (sh.slow >= sh.n) { sh.slow = 0; sh.prev = (float)pink[sh.pos]; sh.pos = wind_wrap(sh.pos + 1, len); }
-        const float nv = wind_interp(RA_ITP_LINEAR, sh.slow, sh.n, sh.prev, (float)pink[sh.pos]);
-        if (i == lane) mine = nv;
+        if (sh.slow >= sh.n) { sh.slow = 0; sh.prev = at(rel); ++rel; }
+        const float cur = at(rel);
+        if (i == lane) { m_slow = sh.slow; m_n = sh.n; m_prev = sh.prev; m_next = cur; }
       }
+      sh.pos += rel;
+      sh.pos = sh.pos >= len ? sh.pos - len : sh.pos;
+      const float mine = wind_interp(RA_ITP_LINEAR, m_slow, m_n, m_prev, m_next);
       inc_f = long_inc * (float)exp2((double)(mine * wp.short_amplitude));
     }
     const bool on = lane < c64;
@@ -213,36 +258,50 @@ __global__ void __launch_bounds__(64) ra_wind_ctl_kernel(RaVoiceParams vp, RaWin
 // two batches after the wave before wrote it); every ring is followed by a copy of its first 64 entries, so that the 65 entries a lane reads during
 // a batch are contiguous wherever they start: one address per batch and immediate offsets, instead of three address instructions per read.
 constexpr int kWindRing = 128 + 64, kWindLink = 256 + 64, kWindWaveLds = 3 * kWindRing + kWindLink;
-static_assert(kWindLink >= kWindRing && 9 * kWindWaveLds * 8 <= 65536, "nine waves (order 258) within the default 64 KB of dynamic LDS");
+static_assert(kWindLink >= kWindRing && 5 * kWindWaveLds * 8 <= 65536, "five waves (order 258: 516 sections, two per lane) within the default 64 KB of dynamic LDS");
 __device__ inline void wind_ring_put(double *ring, int size, int i, double v) { ring[i] = v; if (i < 64) ring[i + size] = v; }
 __device__ inline double wind_fma3(double a, double b, double c) { // a b + c as the three-address instruction
   double d;
   asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
-// 64 steps of a wave in the steady state (every lane has a sample in every step).  KIND: 0 = every lane a low-pass section (output y), 1 = every lane a
-// high-pass section or one of the last wave's leading pass-through lanes (output x - y), 2 = both kinds in the wave (output fma(hm, x, -+y): exact either way).
-// The tap is lane 63: its outputs are collected by a second shift register running the other way (wave_shl: lane l takes lane l + 1's, lane 63 its own
-// new output), so that after the 64 steps lane tt holds step tt's.
-template <int KIND>
-__device__ inline double wind_chain_batch(const double *__restrict__ pc, const double *__restrict__ px0, double &y, double &xout, double hm, int sgn) {
+// 64 steps of a wave in the steady state (every lane has a sample in every step); a lane holds M consecutive sections.  KIND: 0 = every section of the wave
+// a low-pass (output y), 1 = every one a high-pass or a pass-through of the last wave (output x - y), 2 = both kinds in the wave (output fma(hm, x, -+y):
+// exact either way).  The tap is lane 63: its outputs are collected by a second shift register running the other way (wave_shl: lane l takes lane l + 1's,
+// lane 63 its own new output), so that after the 64 steps lane tt holds step tt's.
+template <int M, int KIND>
+__device__ inline double wind_chain_batch(const double *const (&pc)[M], const double *__restrict__ px0, double (&y)[M], double &xout, const double (&hm)[M], const int (&sgn)[M]) {
   double collected = 0.0;
-  double c = pc[0], x0 = px0[0];
+  double c[M], x0 = px0[0];
+#pragma unroll
+  for (int j = 0; j < M; ++j) c[j] = pc[j][0];
 #pragma unroll
   for (int tt = 0; tt < 64; ++tt) {
-    const double c_n = pc[tt + 1], x0_n = px0[tt + 1]; // (one step ahead; entry 64 is read and never used)
-    const double x = wave_shr1_f64(x0, xout);
-    y = y + c * (x - y); // s = s + k (x - s), the operations of the restatement
-    if (KIND == 0) xout = y;
-    else if (KIND == 1) xout = x - y;
-    else xout = wind_fma3(hm, x, __hiloint2double(__double2hiint(y) ^ sgn, __double2loint(y)));
+    double c_n[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) c_n[j] = pc[j][tt + 1]; // (one step ahead; entry 64 is read and never used)
+    const double x0_n = px0[tt + 1];
+    double x = wave_shr1_f64(x0, xout);
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      y[j] = y[j] + c[j] * (x - y[j]); // s = s + k (x - s), the operations of the restatement
+      if (KIND == 0) x = y[j];
+      else if (KIND == 1) x = x - y[j];
+      else x = wind_fma3(hm[j], x, __hiloint2double(__double2hiint(y[j]) ^ sgn[j], __double2loint(y[j])));
+    }
+    xout = x;
     collected = wave_shl1_f64(xout, collected);
-    c = c_n; x0 = x0_n;
+#pragma unroll
+    for (int j = 0; j < M; ++j) c[j] = c_n[j];
+    x0 = x0_n;
   }
   return collected;
 }
 
-__global__ void __launch_bounds__(576) ra_wind_chain_kernel(RaWindParams wp, const RaWindJob *__restrict__ jobs, const double *__restrict__ pink, double *__restrict__ fstates,
+// M sections per lane: 1 for a chain that fits one wave (the shortest dependent chain per step), 2 beyond (the two DPP moves in, the two out and the input
+// read are shared by two sections: 11 -> 6.5 instructions per section and step)
+template <int M>
+__global__ void __launch_bounds__(320) ra_wind_chain_kernel(RaWindParams wp, const RaWindJob *__restrict__ jobs, const double *__restrict__ pink, double *__restrict__ fstates,
                                                              RaWindScratch sc, int c0, int clen, int chain0) {
   double *wsm = reinterpret_cast<double *>(ra_smem_voice);
   const int ji = blockIdx.x, chain = chain0 + blockIdx.y, w = threadIdx.x >> 6, l = threadIdx.x & 63, W = blockDim.x >> 6;
@@ -259,20 +318,30 @@ __global__ void __launch_bounds__(576) ra_wind_chain_kernel(RaWindParams wp, con
   const int j_lo = J.j0 + (lo - J.begin);
   const bool fresh = j_lo == 1; // Filter::forgetPastSignals: the sections start at 0
   double *ring_a = wsm + (size_t)w * kWindWaveLds, *ring_b = ring_a + kWindRing, *ring_x = ring_b + kWindRing, *link_out = ring_x + kWindRing;
-  double *zeros = wsm + (size_t)(W - 1) * kWindWaveLds + 3 * kWindRing; // kWindRing zeros, the "coefficients" of the pass-through lanes: in the last wave's output ring, which it does not use
+  double *zeros = wsm + (size_t)(W - 1) * kWindWaveLds + 3 * kWindRing; // kWindRing zeros, the "coefficients" of the pass-through sections: in the last wave's output ring, which it does not use
   const double *xin = w == 0 ? ring_x : link_out - kWindWaveLds; // lane 0's input: the noise, or what the wave before hands on
   const int xmask = w == 0 ? 127 : 255;
-  // The last wave holds its sections in its LAST lanes, so that every wave's output leaves at lane 63; the lanes before them pass their input on unchanged:
-  // a high-pass section whose coefficient and state are 0 does exactly that (y = 0 + 0 (x - 0) = 0, output x - 0).
+  // The chain ends at the last lane of the last wave, so that every wave's output leaves at lane 63; the places before its first section pass their input on
+  // unchanged: a high-pass section whose coefficient and state are 0 does exactly that (y = 0 + 0 (x - 0) = 0, output x - 0).
   const bool last = w == W - 1;
-  const int lead = last ? 64 * W - L : 0;
-  const int sidx = 64 * w + l - lead;
-  const bool on = l >= lead, hp = !on || sidx >= ns;
-  double y = (on && !fresh) ? fs[sidx] : 0.0;
-  const double *rk = !on ? zeros : (hp ? ring_b : ring_a);
-  const double hm = hp ? 1.0 : 0.0;
-  const int sgn = hp ? (int)0x80000000 : 0;
-  const int kind = __ballot(hp) == 0ull ? 0 : (__ballot(!hp) == 0ull ? 1 : 2);
+  const int lead = 64 * M * W - L;
+  int sidx[M], sgn[M];
+  bool on[M];
+  double y[M], hm[M];
+  const double *rk[M];
+  bool any_lp = false, any_hp = false;
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    sidx[j] = (64 * w + l) * M + j - lead;
+    on[j] = sidx[j] >= 0;
+    const bool hp = !on[j] || sidx[j] >= ns;
+    y[j] = (on[j] && !fresh) ? fs[sidx[j]] : 0.0;
+    rk[j] = !on[j] ? zeros : (hp ? ring_b : ring_a);
+    hm[j] = hp ? 1.0 : 0.0;
+    sgn[j] = hp ? (int)0x80000000 : 0;
+    any_lp |= !hp; any_hp |= hp;
+  }
+  const int kind = __ballot(any_hp) == 0ull ? 0 : (__ballot(any_lp) == 0ull ? 1 : 2);
   const int total = cnt + 63, nb = (total + 63) / 64;
   // the noise wrapper's index at step j: pink_start + j (soundBufferWrapperAlgo::step, audioelement.h:1568-1574); lane l of wave 0 stages sample tau0 + l
   int px = (int)(((long long)wp.pink_start + j_lo + l) % len);
@@ -293,13 +362,15 @@ __global__ void __launch_bounds__(576) ra_wind_chain_kernel(RaWindParams wp, con
     }
     __syncthreads(); // this batch's rings are filled; what the wave before wrote in the last batch is visible
     if (!mine) continue;
-    const double *pc = rk + ((tau0 - l) & 127);   // the lane's coefficient of step tau0 + tt: pc[tt]
+    const double *pc[M]; // the lane's coefficients of step tau0 + tt: pc[j][tt]
+#pragma unroll
+    for (int j = 0; j < M; ++j) pc[j] = rk[j] + ((tau0 - l) & 127);
     const double *px0 = xin + (tau0 & xmask);     // lane 0's input of step tau0 + tt: px0[tt]
     if (tau0 >= 63 && tau0 + 64 <= cnt) { // every lane has a sample in every step of this batch
       double collected;
-      if (kind == 0) collected = wind_chain_batch<0>(pc, px0, y, xout, hm, sgn);
-      else if (kind == 1) collected = wind_chain_batch<1>(pc, px0, y, xout, hm, sgn);
-      else collected = wind_chain_batch<2>(pc, px0, y, xout, hm, sgn);
+      if (kind == 0) collected = wind_chain_batch<M, 0>(pc, px0, y, xout, hm, sgn);
+      else if (kind == 1) collected = wind_chain_batch<M, 1>(pc, px0, y, xout, hm, sgn);
+      else collected = wind_chain_batch<M, 2>(pc, px0, y, xout, hm, sgn);
       const int t = tau0 + l - 63; // the sample lane l's collected value belongs to
       if (last) out[t] = collected;
       else wind_ring_put(link_out, 256, t & 255, collected);
@@ -308,16 +379,85 @@ __global__ void __launch_bounds__(576) ra_wind_chain_kernel(RaWindParams wp, con
       for (int tt = 0; tt < steps; ++tt) {
         const int t = tau0 + tt - l;
         const bool act = t >= 0 && t < cnt;
-        const double c = pc[tt], x0 = px0[tt];
-        const double x = wave_shr1_f64(x0, xout);
-        const double yn = y + c * (x - y);
-        y = act ? yn : y;
-        xout = fma(hm, x, __hiloint2double(__double2hiint(yn) ^ sgn, __double2loint(yn)));
+        double x = wave_shr1_f64(px0[tt], xout);
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+          const double yn = y[j] + pc[j][tt] * (x - y[j]);
+          y[j] = act ? yn : y[j];
+          x = fma(hm[j], x, __hiloint2double(__double2hiint(yn) ^ sgn[j], __double2loint(yn)));
+        }
+        xout = x;
         if (act && l == 63) { if (last) out[t] = xout; else wind_ring_put(link_out, 256, t & 255, xout); }
       }
     }
   }
-  if (on) fs[sidx] = y;
+#pragma unroll
+  for (int j = 0; j < M; ++j) if (on[j]) fs[sidx[j]] = y[j];
+}
+
+// ---- filter chains that fit one wave (<= 64 sections: band-pass orders <= 32, band-reject orders <= 64) — as scans over time instead.
+// One section per lane would leave most of a lone wave's lanes idle (order 4: 8 of 64) and every step a dependent chain (measured: 200 cycles per sample).
+// A one-pole with a coefficient per sample is still an affine map of its state per sample, y -> (1 - k) y + k x: a lane takes 16 consecutive samples,
+// composes their maps (pass 1), an inclusive scan over the 64 lanes composes the lanes' (six rounds), and each lane replays its samples from the state it
+// is handed (pass 2, the restatement's own y + k (x - y)) — section after section over a tile of 1024 samples held in registers.  The state a lane is
+// handed went through another association than the sample-serial order: 1e-16 relative, where the wave pipeline above is bit-identical.
+constexpr int kWindScanSamples = 16;
+template <bool HP>
+__device__ inline void wind_scan_section(double (&x)[kWindScanSamples], const double (&k)[kWindScanSamples], double *__restrict__ state, int lane) {
+  double A = 1.0, B = 0.0;
+#pragma unroll
+  for (int j = 0; j < kWindScanSamples; ++j) { B = B + k[j] * (x[j] - B); A = fma(-k[j], A, A); }
+#pragma unroll
+  for (int r = 0; r < 6; ++r) { // (A, B) <- (A, B) o (A, B) of the lane 2^r below
+    const double At = __shfl_up(A, 1 << r), Bt = __shfl_up(B, 1 << r);
+    if (lane >= (1 << r)) { B = fma(A, Bt, B); A *= At; }
+  }
+  const double carry = *state; // the section's state before the tile
+  double y = fma(wave_shr1_f64(1.0, A), carry, wave_shr1_f64(0.0, B)); // the state this lane's first sample sees
+#pragma unroll
+  for (int j = 0; j < kWindScanSamples; ++j) {
+    y = y + k[j] * (x[j] - y);
+    x[j] = HP ? x[j] - y : y;
+  }
+  __syncthreads();
+  if (lane == 63) *state = y; // (lanes past the chunk's end hold identity maps: lane 63 ends at the state after the last sample)
+  __syncthreads();
+}
+__global__ void __launch_bounds__(64) ra_wind_scan_kernel(RaWindParams wp, const RaWindJob *__restrict__ jobs, const double *__restrict__ pink, double *__restrict__ fstates,
+                                                           RaWindScratch sc, int c0, int clen, int chain0) {
+  __shared__ double st[64];
+  constexpr int SC = kWindScanSamples;
+  const int ji = blockIdx.x, chain = chain0 + blockIdx.y, l = threadIdx.x;
+  const RaWindJob J = jobs[ji];
+  const int lo = max(J.begin, c0), hi = min(J.begin + J.n, c0 + clen);
+  if (hi <= lo) return;
+  const int cnt = hi - lo, N = wp.order, len = wp.pink_len;
+  const int L = chain == 0 ? 2 * N : N, ns = chain == 2 ? 0 : N;
+  const size_t base = (size_t)ji * (size_t)sc.stride + (size_t)(lo - c0);
+  const double *ka = (chain == 0 ? sc.k_bp_lp : sc.k_br_lp) + base, *kb = (chain == 0 ? sc.k_bp_hp : sc.k_br_hp) + base;
+  double *out = (chain == 0 ? sc.p_bp : (chain == 1 ? sc.p_br_lp : sc.p_br_hp)) + base;
+  double *fs = fstates + (size_t)J.slot * (size_t)(4 * N) + (chain == 0 ? 0 : (chain == 1 ? 2 * N : 3 * N));
+  const int j_lo = J.j0 + (lo - J.begin);
+  st[l] = (l < L && j_lo != 1) ? fs[l] : 0.0;
+  __syncthreads();
+  for (int tile0 = 0; tile0 < cnt; tile0 += 64 * SC) {
+    const int t0 = tile0 + l * SC;
+    double x[SC], a[SC], b[SC];
+    int px = (int)(((long long)wp.pink_start + j_lo + t0) % len);
+#pragma unroll
+    for (int j = 0; j < SC; ++j) { // past the chunk's end: coefficient 0 (the identity map), input 0
+      const bool in = t0 + j < cnt;
+      x[j] = in ? pink[px] : 0.0;
+      a[j] = (in && ns > 0) ? ka[t0 + j] : 0.0;
+      b[j] = (in && ns < L) ? kb[t0 + j] : 0.0;
+      px = px + 1 == len ? 0 : px + 1;
+    }
+    for (int s = 0; s < ns; ++s) wind_scan_section<false>(x, a, st + s, l);
+    for (int s = ns; s < L; ++s) wind_scan_section<true>(x, b, st + s, l);
+#pragma unroll
+    for (int j = 0; j < SC; ++j) if (t0 + j < cnt) out[t0 + j] = x[j];
+  }
+  if (l < L) fs[l] = st[l];
 }
 
 // ---- mix: one lane per (stream, frame) of the chunk
