@@ -1664,12 +1664,14 @@ int ra_compute(ra_context *c, int32_t stream, double *h_buffer, int32_t n) {
   if (c->p.post_limit && c->p.fb_gain != 0.f)
     return fail(RA_EINVAL, "ra_compute with post = limit and an output feedback: the loop feeds back what was PLAYED, i.e. the limited signal, which only the caller of the "
                            "computes has (SimpleAudioOutContext::step runs the post-processors after them, lib.cpp:1245-1275) — use ra_process_*");
-  HIP_TRY(hipSetDevice(c->device));
   shim_init(c);
   ra_context::Shim &sh = c->shim;
   const int64_t t = sh.served[stream];
   if (sh.in_base + (int64_t)sh.in_voice[stream].size() < t + n) return fail(RA_EINVAL, "ra_compute: fewer frames fed than requested");
-  while (sh.rendered < t + n) RA_TRY(shim_render(c, t + n));
+  if (sh.rendered < t + n) { // (only a compute that has to render touches the device: the others — all but one per hop and context — are served from the host ring)
+    HIP_TRY(hipSetDevice(c->device));
+    while (sh.rendered < t + n) RA_TRY(shim_render(c, t + n));
+  }
   const double *ring = sh.ring[stream].data() + sh.ring_head[stream];
   for (int i = 0; i < 2 * n; ++i) h_buffer[i] += ring[i]; // the reference computes accumulate (gen.crtp.h:364-369)
   sh.ring_head[stream] += 2 * (size_t)n;
