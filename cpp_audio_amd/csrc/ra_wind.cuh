@@ -148,10 +148,12 @@ __global__ void __launch_bounds__(64) ra_wind_ctl_kernel(RaVoiceParams vp, RaWin
     RaWindIter c = fresh ? wind_iter_fresh(jobs[ji].pos[ic], wp.n_band, pink, true) : S->it[ic];
     RaWindIter w = fresh ? wind_iter_fresh(jobs[ji].pos[iw], wp.n_band, pink, true) : S->it[iw];
     double *k_lp = (role == 1 ? sc.k_bp_lp : sc.k_br_lp) + base, *k_hp = (role == 1 ? sc.k_bp_hp : sc.k_br_hp) + base;
+    const bool fixed_width = wp.width_max == wp.width_min;
     for (int b0 = 0; b0 < cnt; b0 += 64) {
       const int c64 = min(64, cnt - b0);
       const float vc = wind_iter_batch(c, RA_ITP_LINEAR, pink, len, c64, lane, flags, win0);
-      const float vw = wind_iter_batch(w, RA_ITP_LINEAR, pink, len, c64, lane, flags, win1);
+      // (a width range of one value — five of the reference's programs —: min + |v| * 0 is the minimum whatever the width's iterator reads; it is not walked)
+      const float vw = fixed_width ? 0.f : wind_iter_batch(w, RA_ITP_LINEAR, pink, len, c64, lane, flags, win1);
       if (lane < c64) {
         const double increment = (double)wind_center_inc(wp, vc);
         const float at = wp.width_min + fabsf(vw) * (wp.width_max - wp.width_min); // range<float>::getAt
@@ -200,11 +202,11 @@ __global__ void __launch_bounds__(64) ra_wind_ctl_kernel(RaVoiceParams vp, RaWin
                   a2 = __builtin_amdgcn_readlane(__float_as_int(b2v), u & 63);
         return __int_as_float(u < 64 ? a0 : (u < 128 ? a1 : a2));
       };
-      int rel = 0, m_slow = 0, m_n = 1;
-      float m_prev = 0.f, m_next = 0.f;
+      const int n_mine = (int)(1 + wp.short_rate / long_inc); // every sample's step count at once: the division is off the serial chain
+      int rel = 0, m_slow = 0, m_n = 1, m_rel = 0;
+      float m_prev = 0.f;
       for (int i = 0; i < c64; ++i) {
-        const float li = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(long_inc), i));
-        const int n = (int)(1 + wp.short_rate / li);
+        const int n = __builtin_amdgcn_readlane(n_mine, i);
         if (n != sh.n) {
           if (sh.slow) {
             const float ratio = (sh.slow + .5f) / (float)sh.n;
@@ -215,11 +217,13 @@ __global__ void __launch_bounds__(64) ra_wind_ctl_kernel(RaVoiceParams vp, RaWin
         }
         ++sh.slow;
         if (sh.slow >= sh.n) { sh.slow = 0; sh.prev = at(rel); ++rel; }
-        const float cur = at(rel);
-        if (i == lane) { m_slow = sh.slow; m_n = sh.n; m_prev = sh.prev; m_next = cur; }
+        if (i == lane) { m_slow = sh.slow; m_n = sh.n; m_prev = sh.prev; m_rel = rel; }
       }
       sh.pos += rel;
       sh.pos = sh.pos >= len ? sh.pos - len : sh.pos;
+      // the sample each step's iterator points at, gathered in one go (all lanes in every shuffle)
+      const float g0 = __shfl(b0v, m_rel & 63), g1 = __shfl(b1v, m_rel & 63), g2 = __shfl(b2v, m_rel & 63);
+      const float m_next = m_rel < 64 ? g0 : (m_rel < 128 ? g1 : g2);
       const float mine = wind_interp(RA_ITP_LINEAR, m_slow, m_n, m_prev, m_next);
       inc_f = long_inc * (float)exp2((double)(mine * wp.short_amplitude));
     }
