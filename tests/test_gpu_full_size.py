@@ -66,10 +66,10 @@ def test_configs1_full_size_block_cuts_and_stream_independence(env, oracle):
         assert np.sqrt(np.mean((got.astype(np.float64) - ref) ** 2)) <= 1e-7, s
 
 
-@pytest.mark.parametrize("which", ["sweep", "birds"])
+@pytest.mark.parametrize("which", ["sweep", "birds", "wind"])
 def test_voice_full_size_block_cuts(env, oracle, which):
-    # the bench's gen.voice workloads (256 synths x 16 channels x 10 s): one block against three ragged ones (another cut packs the ramps into other
-    # slots: the sums associate differently), no dropped note, and two synths against the oracle
+    # the bench's gen.voice workloads (256 synths x 16 channels x 10 s; WIND: four held notes per synth through band-passes of order 89): one block against
+    # three ragged ones (another cut packs the ramps into other slots: the sums associate differently), no dropped note, and two synths against the oracle
     torch, bench, api = env
     S, n = 256, 10 * SR
     dev = torch.device("cuda", 0)
@@ -86,7 +86,7 @@ def test_voice_full_size_block_cuts(env, oracle, which):
             assert v.dropped_note_ons() == 0
         outs.append(torch.cat(parts, dim=1))
     d = outs[0].double() - outs[1].double()
-    assert float(outs[0].double().pow(2).mean().sqrt()) > 1e-3
+    assert float(outs[0].double().pow(2).mean().sqrt()) > (1e-4 if which == "wind" else 1e-3)
     assert float(d.abs().max()) < 1e-6
     for s in (0, 131):
         ref, dropped = oracle.voice_run(oracle.voice_params_from(cfg, cfg.seed + s), [(r[0], r[2], r[3], r[4], r[5]) for r in rows if r[1] == s], n)
