@@ -130,6 +130,18 @@ def test_wind_variants(api, oracle, kw, monkeypatch):
     check_against_oracle(api, oracle, cfg, rows, S, n, (n // 2 + 1, n - n // 2 - 1), 77, min_rms=1e-9, rel_bar=1e-5)
 
 
+def test_wind_many_notes_at_once(api, oracle):
+    # forty WIND notes sounding together in one synth (48 channels; every note its own ramp, state slot and start positions), some released: the mix sums
+    # the stream's ramps in job order
+    cfg, _ = api.voice_program(api.VOICE_WIND, 13, seed=21, n_channels=48)   # "Kettle whistle mixed": band-pass of order 7 and the sine
+    n = 24000
+    rows = [(17 * k, 0, 0, k + 1, 150.0 + 23 * k, 0.05 + 0.01 * (k % 7)) for k in range(40)]
+    rows += [(9000 + 31 * k, 0, 1, 3 * k + 1, 0.0, 0.0) for k in range(10)]
+    rows.sort(key=lambda r: r[0])
+    out, dropped, _ = check_against_oracle(api, oracle, cfg, rows, 1, n, (5000, n - 5000), 21, min_rms=1e-9, rel_bar=1e-5)
+    assert dropped == 0
+
+
 def test_wind_block_and_chunk_cuts_do_not_show(api, monkeypatch):
     # 64 synths x 3 held notes of "Bubbles" (order 129: five waves per band-pass chain) over one second: one block = ragged blocks = chunks of 4160 frames,
     # bit for bit (a noise voice's arithmetic does not depend on where a batch of 64 steps starts); synth s is not synth 0 (its own draws)
