@@ -15,7 +15,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 9)
 bad = 0
 worst = 0.0
 for ci in range(n_cfg):
-    sr = int(rng.choice([22050, 44100, 48000, 96000]))
+    sr = int(rng.choice([8000, 22050, 44100, 48000, 96000]))
     kw = dict(sample_rate=sr, seed=int(rng.integers(1, 1 << 40)), n_channels=int(rng.integers(1, 6)),
               pink_noise_bp_gain=float(rng.choice([0.0, 1.0, rng.uniform(0, 1)])), pink_noise_br_gain=float(rng.choice([0.0, 0.0, rng.uniform(0, 1)])),
               sine_gain=float(rng.choice([0.0, 0.1, rng.uniform(0, 1)])), order_filters=int(rng.choice([1, 2, 7, 32, 33, 64, 65, 129, 258, rng.integers(1, 259)])),
@@ -25,7 +25,7 @@ for ci in range(n_cfg):
               # sample_rate * 2.268^x steps per noise sample: from ~1 step up to seconds
               seconds_slow_iter_long_term=float(rng.uniform(np.log(1.2 / sr) / np.log(2.268), 1.0)),
               seconds_slow_iter_short_term=float(rng.uniform(np.log(1.0 / sr) / np.log(2.268), 0.0)),
-              interpolation=int(rng.integers(0, 23)), markov_start_node=int(rng.integers(0, 2)), markov_min_path_length=int(rng.integers(1, 8)),
+              interpolation=int(rng.integers(0, 23)), markov_start_node=int(rng.integers(0, 2)), markov_min_path_length=int(rng.integers(0, 8)), markov_pre_tries=int(rng.integers(0, 4)), markov_additional_tries=int(rng.integers(0, 4)),
               xfade_length_seconds=float(rng.uniform(0.0023, 0.0454)), random_pan=int(rng.integers(0, 2)), pan=float(rng.uniform(-1, 1)),
               loudness_compensation_amount=float(rng.uniform(0, 1)), seed_param=int(rng.choice([0, 1, 48])))
     if kw["pink_noise_bp_gain"] == 0 and kw["pink_noise_br_gain"] == 0 and kw["sine_gain"] == 0:
