@@ -16,13 +16,14 @@
 //   sine       phase = a running sum, loudness volume = a one-pole whose coefficient follows the increment: two scans over the 64 lanes;
 //   filters    band-pass = n low-pass sections then n high-pass sections in series over the pink samples (HighPassAlgo<LowPassAlgo<pink>>,
 //              audioelement.h:2163), band-reject = n low-pass sections + n high-pass sections, each over the pink samples (:2201-2203).
-//              Section s at time t needs section s - 1 at time t and itself at time t - 1: a systolic array.  A wave holds the sections of one
-//              chain, M consecutive ones per lane; in step tau lane l works on sample tau - l, its input handed over by lane l - 1 through one
-//              DPP move, its two coefficients read from a ring in LDS the wave fills 64 samples at a time.
+//              Section s at time t needs section s - 1 at time t and itself at time t - 1.  A chain of at most 64 sections runs as scans over time
+//              (ra_wind_scan_kernel: a one-pole with a coefficient per sample is an affine map of its state per sample); a longer one as a
+//              systolic pipeline of waves (ra_wind_chain_kernel), a section per lane: in step tau lane l works on sample tau - l, its input handed
+//              over by lane l - 1 through one DPP move, its coefficient read from a ring in LDS the wave fills 64 samples at a time.
 //   mix        Mix::imag's sum in voice order, the envelope, the ramp's and the note's gains, the ramps of a stream summed in job order.
-// Three kernels per chunk of a block: controls (+ sine) -> chains -> mix; the per-sample coefficients and voice outputs go through scratch in HBM.
+// Per chunk of a block: controls (+ sine) -> chains -> mix; the per-sample coefficients and voice outputs go through scratch in HBM; with short
+// chains the controls of the next chunk run on a queue of their own beside this chunk's chains (ra_capi.hip: voice_wind_block).
 
-__device__ inline int wind_wrap(int i, int len) { return i >= len ? i - len : i; }
 __device__ inline float wind_abs(double v) { return fabsf((float)v); } // AbsIter over BufferIter (the buffer's double narrowed to float)
 
 // NormalizedInterpolation<>::get_unfiltered_value(slow_it, n_steps, prev, *it) as decided: itp::interpolate in double on the float operands
